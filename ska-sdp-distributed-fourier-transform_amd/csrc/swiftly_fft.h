@@ -1,0 +1,286 @@
+// SwiFTly on MI355X (gfx950): workgroup-level FFT engine.
+//
+// One workgroup transforms RB rows of length N = 2^LOGN held entirely in
+// registers (P = 2^LOGP points per thread, T = N/P threads per row) with a
+// Stockham autosort schedule: each phase does a radix-2^LOGR DFT in registers
+// and exchanges data through LDS, so input and output are both in natural
+// order and no bit-reversal pass touches memory.  The first phase reads
+// straight from global memory through an index map (window x zero-pad x
+// cyclic shift x centred-FFT shift all folded into the map) and the last phase
+// writes straight to global memory through a second map (shift x crop x window
+// x accumulate), which is how every SwiFTly primitive (reference
+// fourier_transform/core.py:189-484) becomes ONE kernel with one HBM read and
+// one HBM write per element.
+//
+// Wavefronts are 64 wide; LDS exchange buffers are padded by one element per
+// 128 B (32 banks x 4 B) so that the strided scatter of a phase stays
+// conflict-free for ds_write_b32/b64/b128 alike.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+namespace swf {
+
+template <typename R>
+struct cx {
+    R x, y;
+};
+
+template <typename R>
+__device__ __forceinline__ cx<R> operator+(cx<R> a, cx<R> b) {
+    return {a.x + b.x, a.y + b.y};
+}
+template <typename R>
+__device__ __forceinline__ cx<R> operator-(cx<R> a, cx<R> b) {
+    return {a.x - b.x, a.y - b.y};
+}
+template <typename R>
+__device__ __forceinline__ cx<R> cmul(cx<R> a, cx<R> b) {
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
+// compile-time loop: f(std::integral_constant<int, i>) for i in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+constexpr int bitrev(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// cos(2 pi k / 64), first quadrant, exact at the ends
+constexpr double kCosQ[17] = {1.0,
+                              0.9951847266721969,
+                              0.9807852804032304,
+                              0.9569403357322088,
+                              0.9238795325112867,
+                              0.881921264348355,
+                              0.8314696123025452,
+                              0.773010453362737,
+                              0.7071067811865476,
+                              0.6343932841636455,
+                              0.5555702330196023,
+                              0.4713967368259978,
+                              0.38268343236508984,
+                              0.29028467725446233,
+                              0.19509032201612833,
+                              0.09801714032956077,
+                              0.0};
+constexpr double cos64(int k) {
+    k &= 63;
+    if (k <= 16) return kCosQ[k];
+    if (k <= 32) return -kCosQ[32 - k];
+    if (k <= 48) return -kCosQ[k - 32];
+    return kCosQ[64 - k];
+}
+constexpr double sin64(int k) { return cos64(k - 16); }
+
+// d * exp(-2 pi i NUM / 64) with the trivial cases special-cased
+template <typename R, int NUM>
+__device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
+    constexpr int n = NUM & 63;
+    if constexpr (n == 0) {
+        return d;
+    } else if constexpr (n == 16) {  // -i
+        return {d.y, -d.x};
+    } else if constexpr (n == 32) {
+        return {-d.x, -d.y};
+    } else if constexpr (n == 48) {  // +i
+        return {-d.y, d.x};
+    } else if constexpr (n == 8) {  // (1 - i)/sqrt2
+        constexpr R c = (R)0.7071067811865476;
+        return {(d.x + d.y) * c, (d.y - d.x) * c};
+    } else if constexpr (n == 24) {  // (-1 - i)/sqrt2
+        constexpr R c = (R)0.7071067811865476;
+        return {(d.y - d.x) * c, -(d.x + d.y) * c};
+    } else {
+        constexpr R c = (R)cos64(n), s = (R)(-sin64(n));
+        return {d.x * c - d.y * s, d.x * s + d.y * c};
+    }
+}
+
+// In-register radix-2^LOGR DIF FFT over x[OFF + r*STR], r < 2^LOGR.
+// Result element k ends up at x[OFF + bitrev(k)*STR].
+template <typename R, int LOGR, int STR, int OFF, int PTOT>
+__device__ __forceinline__ void fft_reg(cx<R> (&x)[PTOT]) {
+    constexpr int RAD = 1 << LOGR;
+    static_assert(LOGR <= 6, "radix too large for the constant table");
+    static_for<0, LOGR>([&](auto sI) {
+        constexpr int s = LOGR - 1 - decltype(sI)::value;
+        constexpr int half = 1 << s;
+        static_for<0, RAD / 2>([&](auto bI) {
+            constexpr int b = decltype(bI)::value;
+            constexpr int blk = b / half, k = b % half;
+            constexpr int i0 = OFF + (blk * 2 * half + k) * STR;
+            constexpr int i1 = i0 + half * STR;
+            cx<R> a = x[i0], c = x[i1];
+            x[i0] = a + c;
+            x[i1] = mul_w64<R, k*(32 / half)>(a - c);
+        });
+    });
+}
+
+// LDS element type helpers ---------------------------------------------------
+// Padded element index: one pad element per 128 B.
+template <int ELEM_BYTES>
+__device__ __forceinline__ int lds_pad(int e) {
+    constexpr int LOGPAD = ELEM_BYTES == 4 ? 5 : ELEM_BYTES == 8 ? 4 : 3;
+    return e + (e >> LOGPAD);
+}
+template <int ELEM_BYTES>
+constexpr int lds_pitch(int n) {
+    constexpr int LOGPAD = ELEM_BYTES == 4 ? 5 : ELEM_BYTES == 8 ? 4 : 3;
+    return n + (n >> LOGPAD);
+}
+
+// Geometry of one engine configuration.
+template <typename R, int LOGN_, int LOGP_, int NT_, bool SPLIT_>
+struct Geo {
+    static constexpr int LOGN = LOGN_, LOGP = LOGP_, NT = NT_;
+    static constexpr bool SPLIT = SPLIT_;
+    static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P;
+    static_assert(T >= 1 && NT % T == 0, "bad geometry");
+    static constexpr int RB = NT / T;  // rows per workgroup
+    static constexpr int ELEM = SPLIT ? (int)sizeof(R) : (int)(2 * sizeof(R));
+    static constexpr int PITCH = lds_pitch<ELEM>(N);
+    static constexpr size_t LDS_BYTES = (size_t)RB * PITCH * ELEM;
+};
+
+// Position of (row rb, element e) in the exchange buffer.  rowfast: the RB rows
+// of the workgroup are interleaved so that consecutive lanes (consecutive
+// rows) hit consecutive banks.
+template <class G>
+__device__ __forceinline__ int lds_pos(int rb, int e, bool rowfast) {
+    return rowfast ? e * G::RB + rb : rb * G::PITCH + lds_pad<G::ELEM>(e);
+}
+
+// Apply inter-phase twiddles w^r = exp(-2 pi i * kidx * r / N) to the
+// butterfly inputs x[U + r*NB], r = 1..RAD-1.  Powers of two come from the
+// table (tw[k] = exp(-2 pi i k / N)), the rest from at most log2(RAD)-1
+// complex products, which keeps the error at a few ulp.
+template <typename R, int LOGR, int NB, int U, int PTOT, int N>
+__device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx) {
+    constexpr int RAD = 1 << LOGR;
+    if constexpr (LOGR >= 5) {
+        // register-lean form: keep only the LOGR table values alive and build
+        // each w^r from the set bits of r
+        cx<R> wp[LOGR];
+        static_for<0, LOGR>([&](auto bI) {
+            constexpr int b = decltype(bI)::value;
+            wp[b] = tw[(kidx << b) & (N - 1)];
+        });
+        static_for<1, RAD>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            constexpr int hb = 31 - __builtin_clz(r);
+            cx<R> w = wp[hb];
+            static_for<0, hb>([&](auto cI) {
+                constexpr int c = decltype(cI)::value;
+                if constexpr ((r >> c) & 1) w = cmul(w, wp[c]);
+            });
+            x[U + r * NB] = cmul(x[U + r * NB], w);
+        });
+    } else {
+        cx<R> w[RAD];
+        static_for<0, LOGR>([&](auto bI) {
+            constexpr int b = decltype(bI)::value;
+            w[1 << b] = tw[(kidx << b) & (N - 1)];
+        });
+        static_for<1, RAD>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            constexpr int hb = 31 - __builtin_clz(r);
+            if constexpr (r != (1 << hb)) w[r] = cmul(w[1 << hb], w[r - (1 << hb)]);
+            x[U + r * NB] = cmul(x[U + r * NB], w[r]);
+        });
+    }
+}
+
+// One Stockham phase, compute part: twiddle + in-register DFTs.
+template <class G, typename R, int LOGNS, int LOGR>
+__device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<R>* __restrict__ tw) {
+    constexpr int RAD = 1 << LOGR, NB = G::P / RAD;
+    static_for<0, NB>([&](auto uI) {
+        constexpr int u = decltype(uI)::value;
+        if constexpr (LOGNS > 0) {
+            int j = t + u * G::T;
+            int k = j & ((1 << LOGNS) - 1);
+            // angle = -2 pi k r / (Ns * RAD)  ->  table index k * N/(Ns*RAD) * r
+            twiddle_inputs<R, LOGR, NB, u, G::P, G::N>(x, tw, k << (G::LOGN - LOGNS - LOGR));
+        }
+        fft_reg<R, LOGR, NB, u, G::P>(x);
+    });
+}
+
+// One Stockham phase, scatter part: f(e, value) for every output element of
+// this thread, e = natural-order index within the phase's output array.
+template <class G, typename R, int LOGNS, int LOGR, class F>
+__device__ __forceinline__ void phase_scatter(const cx<R> (&x)[G::P], int t, F&& f) {
+    constexpr int RAD = 1 << LOGR, NB = G::P / RAD;
+    static_for<0, NB>([&](auto uI) {
+        constexpr int u = decltype(uI)::value;
+        int j = t + u * G::T;
+        int k = j & ((1 << LOGNS) - 1);
+        int e0 = ((j - k) << LOGR) + k;
+        static_for<0, RAD>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            f(e0 + (r << LOGNS), x[u + bitrev(r, LOGR) * NB]);
+        });
+    });
+}
+
+// Exchange through LDS: scatter phase output, then gather x[v] = buf[t + v*T].
+template <class G, typename R, int LOGNS, int LOGR>
+__device__ __forceinline__ void phase_exchange(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds) {
+    if constexpr (!G::SPLIT) {
+        cx<R>* buf = reinterpret_cast<cx<R>*>(lds);
+        phase_scatter<G, R, LOGNS, LOGR>(x, t, [&](int e, cx<R> v) { buf[lds_pos<G>(rb, e, rowfast)] = v; });
+        __syncthreads();
+        static_for<0, G::P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v] = buf[lds_pos<G>(rb, t + v * G::T, rowfast)];
+        });
+        __syncthreads();
+    } else {
+        // re and im separately: halves the LDS footprint (N*8 B > 160 KiB case)
+        R* buf = reinterpret_cast<R*>(lds);
+        phase_scatter<G, R, LOGNS, LOGR>(x, t, [&](int e, cx<R> v) { buf[lds_pos<G>(rb, e, rowfast)] = v.x; });
+        __syncthreads();
+        // every old real part is in LDS now, so x[].x can take the new ones
+        static_for<0, G::P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v].x = buf[lds_pos<G>(rb, t + v * G::T, rowfast)];
+        });
+        __syncthreads();
+        phase_scatter<G, R, LOGNS, LOGR>(x, t, [&](int e, cx<R> v) { buf[lds_pos<G>(rb, e, rowfast)] = v.y; });
+        __syncthreads();
+        static_for<0, G::P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v].y = buf[lds_pos<G>(rb, t + v * G::T, rowfast)];
+        });
+        __syncthreads();
+    }
+}
+
+// Run all phases starting at LOGNS.  On entry x[v] = input[t + v*T] (natural
+// order); the last phase hands (natural-order output index, value) to `fin`.
+template <class G, typename R, int LOGNS, class F>
+__device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds,
+                                           const cx<R>* __restrict__ tw, F&& fin) {
+    constexpr int REM = G::LOGN - LOGNS;
+    constexpr int LOGR = REM < G::LOGP ? REM : G::LOGP;
+    phase_compute<G, R, LOGNS, LOGR>(x, t, tw);
+    if constexpr (LOGNS + LOGR == G::LOGN) {
+        phase_scatter<G, R, LOGNS, LOGR>(x, t, fin);
+    } else {
+        phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
+        fft_phases<G, R, LOGNS + LOGR>(x, t, rb, rowfast, lds, tw, fin);
+    }
+}
+
+}  // namespace swf

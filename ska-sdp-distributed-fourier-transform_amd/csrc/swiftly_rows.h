@@ -1,0 +1,188 @@
+// SwiFTly on MI355X: the generic "mapped row FFT" kernel.
+//
+//   value_in[i]  = in[row, src(i)] * win(i)         (or 0 outside the map)
+//   X            = FFT or iFFT of value_in           (centred, length N)
+//   out[row, dst(i)] (+)= X[i] * scale * win(i)      (or skipped)
+//
+// Every SwiFTly primitive that contains a transform is an instance of this
+// with different AxisMaps (see swiftly_abi.hip for the table that maps the
+// reference's core.py:189-484 onto it).
+#pragma once
+#include "swiftly_fft.h"
+
+namespace swf {
+
+// Maps a centred transform-domain index ci in [0, N) to a memory index:
+//   q = (ci + a) mod N ; valid iff q < len ; idx = (q + c) mod mod
+// win / win2 are optional real windows indexed by q.
+template <typename R>
+struct AxisMap {
+    int a;
+    int len;
+    int c;
+    int mod;
+    const R* win;
+    const R* win2;
+};
+
+template <typename R>
+struct RowsArgs {
+    const cx<R>* in;
+    cx<R>* out;
+    long long in_rs, out_rs;   // element stride between rows
+    unsigned in_cs, out_cs;    // element stride along the transform axis; (full length)*cs < 2^32 (host-checked)
+    int nrows;
+    AxisMap<R> ld, st;
+    R scale;
+    int accumulate;  // out += instead of out =
+    int conj_ld;     // conjugate on load   } inverse transform = conj(FFT(conj(x))) * scale,
+    int conj_st;     // conjugate on store  } split over two kernels for four-step transforms
+    int rowfast;     // lanes run over rows (use when in_rs == 1)
+    // Decomposed (four-step) transforms: the transform index i of this kernel
+    // is the plain full-length index  i*ld_mul + ld_add  on load and
+    // i*st_mul + st_add  on store, where *_add = (outer row index) * *_addmul.
+    // Plain (non-decomposed) use: mul = 1, addmul = 0, outer = 1.
+    int full_logn;       // log2 of the full transform length the maps refer to
+    int ld_mul, ld_addmul;
+    int st_mul, st_addmul;
+    int outer;           // rows are (inner, outer): row = inner*outer + o  -- see kernel
+    long long in_os, out_os;  // element stride of the outer index
+    const cx<R>* tw;     // exp(-2 pi i k / N), k < N  (this kernel's N)
+    const cx<R>* tw_full;  // exp(-2 pi i k / 2^full_logn) for the four-step twiddle, or null
+    int tw_on_store;     // multiply output i by tw_full[(i * o) ...] (four-step inter-pass twiddle)
+    int raw_ld, raw_st;  // bypass centred-shift + map on load / store (intermediate buffers)
+};
+
+template <class G, typename R>
+__global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N = G::N, P = G::P, T = G::T, RB = G::RB;
+    const int tid = threadIdx.x;
+    const bool rowfast = A.rowfast != 0;
+    int t, rb;
+    if (rowfast) {
+        rb = tid % RB;
+        t = tid / RB;
+    } else {
+        t = tid % T;
+        rb = tid / T;
+    }
+    // rows are enumerated as (o, inner): consecutive rows share the outer index
+    const long long grow = (long long)blockIdx.x * RB + rb;
+    const long long total = (long long)A.nrows * A.outer;
+    const bool live = grow < total;
+    const int o = live ? (int)(grow / A.nrows) : 0;
+    const long long row = live ? grow % A.nrows : 0;
+    const int FN = 1 << A.full_logn;
+    const cx<R>* __restrict__ in = A.in + row * A.in_rs + (long long)o * A.in_os;
+    cx<R>* __restrict__ out = A.out + row * A.out_rs + (long long)o * A.out_os;
+    const R csign_ld = A.conj_ld ? (R)-1 : (R)1;
+    const R csign_st = A.conj_st ? (R)-1 : (R)1;
+
+    cx<R> x[P];
+    const int ld_add = o * A.ld_addmul;
+    static_for<0, P>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        const int i = t + v * T;
+        cx<R> val = {(R)0, (R)0};
+        if (live) {
+            if (A.raw_ld) {
+                val = in[(size_t)((unsigned)i * A.in_cs)];
+            } else {
+                const int pi = i * A.ld_mul + ld_add;             // plain full-length index
+                const int ci = (pi + (FN >> 1)) & (FN - 1);       // centred index
+                const int q = (ci + A.ld.a) & (FN - 1);
+                if (q < A.ld.len) {
+                    int idx = q + A.ld.c;
+                    if (idx >= A.ld.mod) idx -= A.ld.mod;
+                    val = in[(size_t)((unsigned)idx * A.in_cs)];
+                    R w = (R)1;
+                    if (A.ld.win) w = A.ld.win[q];
+                    if (A.ld.win2) w *= A.ld.win2[q];
+                    val.x *= w;
+                    val.y *= w;
+                }
+            }
+            val.y *= csign_ld;
+        }
+        x[v] = val;
+    });
+
+    const int st_add = o * A.st_addmul;
+    fft_phases<G, R, 0>(x, t, rb, rowfast, smem, A.tw, [&](int e, cx<R> v) {
+        if (!live) return;
+        if (A.tw_on_store) {
+            // four-step twiddle exp(-/+ 2 pi i * e * o / FN)
+            cx<R> w = A.tw_full[((unsigned)e * (unsigned)o) & (unsigned)(FN - 1)];
+            v = cmul(v, w);
+        }
+        v.x *= A.scale;
+        v.y *= A.scale * csign_st;
+        if (A.raw_st) {
+            cx<R>* p = out + (size_t)((unsigned)e * A.out_cs);
+            if (A.accumulate) {
+                cx<R> old = *p;
+                v.x += old.x;
+                v.y += old.y;
+            }
+            *p = v;
+            return;
+        }
+        const int pk = e * A.st_mul + st_add;
+        const int ck = (pk + (FN >> 1)) & (FN - 1);
+        const int d = (ck + A.st.a) & (FN - 1);
+        if (d < A.st.len) {
+            int idx = d + A.st.c;
+            if (idx >= A.st.mod) idx -= A.st.mod;
+            R w = (R)1;
+            if (A.st.win) w = A.st.win[d];
+            if (A.st.win2) w *= A.st.win2[d];
+            v.x *= w;
+            v.y *= w;
+            cx<R>* p = out + (size_t)((unsigned)idx * A.out_cs);
+            if (A.accumulate) {
+                cx<R> old = *p;
+                v.x += old.x;
+                v.y += old.y;
+            }
+            *p = v;
+        }
+    });
+}
+
+// Engine configuration per transform length ---------------------------------
+// float : LOGP = ceil(LOGN / ceil(LOGN/4)) (radix <= 16), N = 32768 uses radix 32
+//         with the split re/im exchange (256 KiB of points > 160 KiB LDS).
+// double: radix 8 throughout (register budget), N <= 8192.
+constexpr int logp_for(int logn, bool dbl) {
+    if (dbl) return logn < 3 ? logn : 3;
+    if (logn <= 4) return logn < 3 ? logn : 3;
+    if (logn == 15) return 5;
+    int k = (logn + 3) / 4;
+    return (logn + k - 1) / k;
+}
+constexpr int nt_for(int logn, int logp) {
+    int t = 1 << (logn - logp);
+    return t > 256 ? t : 256;
+}
+
+template <typename R, int LOGN>
+struct GeoFor {
+    static constexpr bool DBL = sizeof(R) == 8;
+    static constexpr int LOGP = logp_for(LOGN, DBL);
+    static constexpr int NT = nt_for(LOGN, LOGP);
+    static constexpr bool SPLIT = (!DBL && LOGN == 15);
+    using type = Geo<R, LOGN, LOGP, NT, SPLIT>;
+};
+
+constexpr int kMinLogN = 3;
+constexpr int kMaxLogNFloat = 15;
+constexpr int kMaxLogNDouble = 13;
+
+// implemented in fft_rows_f32.hip / fft_rows_f64.hip
+int launch_fft_rows(int logn, const RowsArgs<float>& a, hipStream_t s);
+int launch_fft_rows(int logn, const RowsArgs<double>& a, hipStream_t s);
+int init_fft_rows_f32();
+int init_fft_rows_f64();
+
+}  // namespace swf

@@ -1,0 +1,100 @@
+"""
+ctypes binding of libswiftly_hip.so (C ABI: include/swiftly_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``csrc/Makefile``.  There is deliberately NO fallback: if the shared object is
+missing, or no HIP device is visible when a core is constructed, the product
+path raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswiftly_hip.so")
+
+C64, C128 = 0, 1
+ERR_PARAM, ERR_UNSUPPORTED, ERR_HIP = 1, 2, 3
+
+_lib = None
+
+
+class SwiftlyHipError(RuntimeError):
+    """HIP runtime / launch failure reported by libswiftly_hip.so"""
+
+
+def _declare(lib):
+    i64, vp = c_int64, c_void_p
+    lib.swiftly_hip_last_error.restype = c_char_p
+    lib.swiftly_hip_last_error.argtypes = []
+    lib.swiftly_hip_version.restype = c_int
+    lib.swiftly_hip_device_count.restype = c_int
+    lib.swiftly_hip_create.restype = c_int
+    lib.swiftly_hip_create.argtypes = [POINTER(vp), i64, i64, i64, c_double, POINTER(c_double), c_int]
+    lib.swiftly_hip_destroy.restype = None
+    lib.swiftly_hip_destroy.argtypes = [vp]
+    lib.swiftly_hip_contribution_size.restype = i64
+    lib.swiftly_hip_contribution_size.argtypes = [vp]
+    # (h, dtype, in, rows, [size,] in_rs, in_cs, out, out_rs, out_cs, off, [size, mask,] stream)
+    sized_in = [vp, c_int, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp]
+    plain = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, vp]
+    finish = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, vp, vp]
+    for name, args in [
+        ("prepare_facet", sized_in),
+        ("extract_from_facet", plain),
+        ("add_to_subgrid", plain),
+        ("finish_subgrid", finish),
+        ("prepare_subgrid", sized_in),
+        ("extract_from_subgrid", plain),
+        ("add_to_facet", plain),
+        ("finish_facet", finish),
+    ]:
+        fn = getattr(lib, "swiftly_hip_" + name)
+        fn.restype = c_int
+        fn.argtypes = args
+    lib.swiftly_hip_malloc.restype = c_int
+    lib.swiftly_hip_malloc.argtypes = [POINTER(vp), c_size_t]
+    lib.swiftly_hip_free.restype = c_int
+    lib.swiftly_hip_free.argtypes = [vp]
+    lib.swiftly_hip_memset_async.restype = c_int
+    lib.swiftly_hip_memset_async.argtypes = [vp, c_int, c_size_t, vp]
+    for name in ("swiftly_hip_memcpy_h2d", "swiftly_hip_memcpy_d2h"):
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = [vp, vp, c_size_t, vp]
+    lib.swiftly_hip_stream_synchronize.restype = c_int
+    lib.swiftly_hip_stream_synchronize.argtypes = [vp]
+
+
+def load():
+    """Load (once) and return the ctypes library object."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ska-sdp-distributed-fourier-transform_amd/csrc`. "
+            "The HIP backend has no CPU fallback."
+        )
+    # torch first: its bundled libamdhip64.so.7 then serves this library too, so
+    # device pointers and streams are shared with torch tensors.
+    import torch  # noqa: F401  pylint: disable=import-outside-toplevel,unused-import
+
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    _declare(lib)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Translate a non-zero ABI status into the exception the reference's
+    backends raise for the same condition."""
+    if rc == 0:
+        return
+    msg = load().swiftly_hip_last_error().decode("utf-8", "replace")
+    if rc == ERR_PARAM:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise SwiftlyHipError(msg)

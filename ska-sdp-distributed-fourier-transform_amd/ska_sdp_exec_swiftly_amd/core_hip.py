@@ -1,0 +1,386 @@
+"""
+``SwiftlyCoreHip`` -- the MI355X sibling of the reference's ``SwiftlyCore`` /
+``SwiftlyCoreFunc`` (reference src/ska_sdp_exec_swiftly/fourier_transform/
+core.py:20-484 and 487-929).
+
+It exposes the same duck-typed surface (constructor ``(W, N, xM_size,
+yN_size)``, attributes ``W N xM_size yN_size xM_yN_size``, properties
+``subgrid_off_step facet_off_step``, the eight primitives plus
+``add_to_subgrid_2d``, the ``out=`` convention of core.py:152-186 and the
+``ValueError`` behaviour), so it drops into ``api_helper``-style task bodies
+and into the reference's tests unchanged.  All arithmetic runs in hand-written
+HIP kernels behind the C ABI of ``libswiftly_hip.so`` (include/swiftly_hip.h);
+this file only marshals arrays.  There is no CPU path: constructing a core
+without a visible GPU raises.
+
+Array types.  numpy in -> numpy out (host<->device copies through torch,
+convenient and exactly what the reference's callers expect); torch CUDA tensor
+in -> torch CUDA tensor out, zero copy, asynchronous on the current torch
+stream (what the streaming classes in ``api.py`` use).  complex64 stays
+complex64, complex128 stays complex128, real input is promoted to the
+matching complex type (core.py:581-585).
+"""
+import ctypes
+
+import numpy
+import scipy.special
+
+from . import _lib
+
+__all__ = ["SwiftlyCoreHip", "calculate_pswf"]
+
+
+def calculate_pswf(W, yN_size):
+    """Host-side PSWF samples, as reference core.py:119-150: the zeroth-order
+    prolate spheroidal angular function of parameter ``pi*W/2`` at
+    ``2*(k - yN//2)/yN`` with element 0 zeroed.  scipy's ``pro_ang1`` is fed in
+    slices of 500 like the reference does (scipy crashes on long inputs), so
+    the constants are bit-identical to the reference's."""
+    half = yN_size // 2
+    hi = half if yN_size % 2 == 0 else half + 1
+    xs = 2.0 * numpy.arange(-half, hi, dtype=float) / yN_size
+    vals = numpy.empty(yN_size, dtype=float)
+    for start in range(1, yN_size, 500):
+        stop = start + 500
+        vals[start:stop] = scipy.special.pro_ang1(0, 0, numpy.pi * W / 2, xs[start:stop])[0]
+    vals[0] = 0.0
+    return vals
+
+
+def _torch():
+    import torch  # pylint: disable=import-outside-toplevel
+
+    return torch
+
+
+class SwiftlyCoreHip:
+    """SwiFTly primitives on one MI355X.
+
+    :param W: PSWF parameter (grid-space support)
+    :param N: total image size
+    :param xM_size: padded subgrid size
+    :param yN_size: padded facet size
+    :param device: HIP device index (default: torch's current device)
+    """
+
+    # pylint: disable=too-many-public-methods,too-many-arguments
+
+    def __init__(self, W, N, xM_size, yN_size, device=None):
+        self.W = W
+        self.N = N
+        self.xM_size = xM_size
+        self.yN_size = yN_size
+        self.check_params()
+        self.xM_yN_size = self.xM_size * self.yN_size // self.N
+        self._handle = None
+        self._lib = _lib.load()
+        torch = _torch()
+        if self._lib.swiftly_hip_device_count() <= 0 or not torch.cuda.is_available():
+            raise RuntimeError(
+                "SwiftlyCoreHip needs a HIP device (MI355X); none is visible and there is no CPU fallback"
+            )
+        self._device_index = torch.cuda.current_device() if device is None else int(device)
+        self._device = torch.device("cuda", self._device_index)
+        pswf = numpy.ascontiguousarray(calculate_pswf(W, yN_size))
+        handle = ctypes.c_void_p()
+        _lib.check(
+            self._lib.swiftly_hip_create(
+                ctypes.byref(handle),
+                N,
+                yN_size,
+                xM_size,
+                float(W),
+                pswf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                self._device_index,
+            )
+        )
+        self._handle = handle
+
+    def __del__(self):
+        handle = getattr(self, "_handle", None)
+        if handle:
+            try:
+                self._lib.swiftly_hip_destroy(handle)
+            except Exception:  # pylint: disable=broad-except
+                pass
+            self._handle = None
+
+    # Pickle support like SwiftlyCoreFunc (core.py:512-525): only the four
+    # parameters travel, the native handle is rebuilt on the receiving side.
+    def __getstate__(self):
+        return {"W": self.W, "N": self.N, "xM_size": self.xM_size, "yN_size": self.yN_size}
+
+    def __setstate__(self, state):
+        self.__init__(**state)
+
+    def check_params(self):
+        """Validate sizes (core.py:55-74)."""
+        if self.N % self.yN_size != 0:
+            raise ValueError(f"Image size {self.N} not divisible by facet size {self.yN_size}!")
+        if self.N % self.xM_size != 0:
+            raise ValueError(f"Image size {self.N} not divisible by subgrid size {self.xM_size}!")
+        if (self.xM_size * self.yN_size) % self.N != 0:
+            raise ValueError(
+                f"Contribution size not integer with image size {self.N}, "
+                f"subgrid size {self.xM_size} and facet size {self.yN_size}!"
+            )
+
+    @property
+    def subgrid_off_step(self):
+        """All subgrid offsets must be divisible by this (core.py:76-83)."""
+        return self.N // self.yN_size
+
+    @property
+    def facet_off_step(self):
+        """All facet offsets must be divisible by this (core.py:85-92)."""
+        return self.N // self.xM_size
+
+    @property
+    def device(self):
+        """torch device the core computes on"""
+        return self._device
+
+    def __repr__(self):
+        return (
+            f"{self.__class__.__name__}(W={self.W}, N={self.N}, "
+            f"xM_size={self.xM_size}, yN_size={self.yN_size})"
+        )
+
+    # ------------------------------------------------------------------ marshalling
+    def _as_device(self, arr, like_dtype=None):
+        """Return (complex CUDA tensor, was_numpy)."""
+        torch = _torch()
+        was_numpy = not isinstance(arr, torch.Tensor)
+        if was_numpy:
+            arr = numpy.asarray(arr)
+            if not numpy.iscomplexobj(arr):
+                arr = arr.astype(numpy.complex64 if arr.dtype == numpy.float32 else numpy.complex128)
+            elif arr.dtype not in (numpy.complex64, numpy.complex128):
+                arr = arr.astype(numpy.complex128)
+            ten = torch.from_numpy(numpy.ascontiguousarray(arr)).to(self._device)
+        else:
+            ten = arr
+            if not ten.is_complex():
+                ten = ten.to(torch.complex64 if ten.dtype == torch.float32 else torch.complex128)
+            if ten.device != self._device:
+                ten = ten.to(self._device)
+        if like_dtype is not None and ten.dtype != like_dtype:
+            ten = ten.to(like_dtype)
+        return ten, was_numpy
+
+    @staticmethod
+    def _code(ten):
+        torch = _torch()
+        return _lib.C64 if ten.dtype == torch.complex64 else _lib.C128
+
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self._device).cuda_stream)
+
+    def _real_vec(self, vec, cdtype, size):
+        """Optional real window (mask) as a device vector of the precision that
+        matches the complex dtype."""
+        if vec is None:
+            return None
+        torch = _torch()
+        rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
+        if not isinstance(vec, torch.Tensor):
+            vec = torch.from_numpy(numpy.ascontiguousarray(numpy.asarray(vec, dtype=float)))
+        vec = vec.to(device=self._device, dtype=rdtype).contiguous()
+        if vec.numel() != size:
+            raise ValueError(f"Mask has {vec.numel()} elements, expected {size}!")
+        return vec
+
+    def _axis_call(self, fname, arr, in_size, out_size, axis, out, accumulate, off, size_arg=None, mask=None):
+        """Run one single-axis primitive.
+
+        ``in_size`` (or None) is the length the transform axis must have,
+        ``size_arg`` the facet / subgrid size parameter some entry points take.
+        """
+        torch = _torch()
+        out_dtype = None
+        if out is not None:
+            out_dtype = (
+                out.dtype
+                if isinstance(out, torch.Tensor)
+                else {numpy.dtype(numpy.complex64): torch.complex64}.get(numpy.asarray(out).dtype, torch.complex128)
+            )
+        xin, was_numpy = self._as_device(arr, out_dtype)
+        dims = xin.dim()
+        if dims == 1:
+            x2 = xin.unsqueeze(0)
+            ax = 1
+        elif dims == 2:
+            if axis not in (0, 1):
+                raise ValueError(f"Invalid axis {axis} for shape {tuple(xin.shape)}!")
+            x2 = xin
+            ax = axis
+        else:
+            raise ValueError(f"Invalid number of dimensions in input array: {dims}")
+        if in_size is not None and x2.shape[ax] != in_size:
+            raise ValueError(f"Input has size {x2.shape[ax]} along axis {axis}, expected {in_size}!")
+        shape2 = list(x2.shape)
+        shape2[ax] = out_size
+        shape = tuple(shape2) if dims == 2 else (out_size,)
+
+        out_numpy = None
+        if out is None:
+            o_t = (torch.zeros if accumulate else torch.empty)(shape, dtype=xin.dtype, device=self._device)
+        else:
+            if tuple(out.shape) != shape:
+                raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {shape}!")
+            if isinstance(out, torch.Tensor):
+                if out.device != self._device or not out.is_complex():
+                    raise ValueError("out= tensor must be a complex tensor on the core's device")
+                o_t = out
+            else:
+                out_numpy = out
+                o_t = (
+                    torch.from_numpy(numpy.ascontiguousarray(out)).to(self._device)
+                    if accumulate
+                    else torch.empty(shape, dtype=xin.dtype, device=self._device)
+                )
+        o2 = o_t.unsqueeze(0) if dims == 1 else o_t
+        if any(s < 0 for s in x2.stride()) or any(s < 0 for s in o2.stride()):
+            raise ValueError("negative strides are not supported")
+        other = 1 - ax
+        rows = x2.shape[other]
+        args = [self._handle, self._code(xin), ctypes.c_void_p(x2.data_ptr()), rows]
+        if fname in ("prepare_facet", "prepare_subgrid"):
+            args.append(size_arg)
+        args += [x2.stride(other), x2.stride(ax), ctypes.c_void_p(o2.data_ptr()), o2.stride(other), o2.stride(ax), int(off)]
+        keep = None
+        if fname in ("finish_subgrid", "finish_facet"):
+            keep = self._real_vec(mask, xin.dtype, size_arg)
+            args += [size_arg, ctypes.c_void_p(keep.data_ptr()) if keep is not None else None]
+        args.append(self._stream())
+        _lib.check(getattr(self._lib, "swiftly_hip_" + fname)(*args))
+        del keep
+        if out_numpy is not None:
+            out_numpy[...] = o_t.cpu().numpy()
+            return out_numpy
+        if was_numpy and out is None:
+            return o_t.cpu().numpy()
+        return o_t
+
+    # ------------------------------------------------------------------ facet -> subgrid
+    def prepare_facet(self, facet, facet_off, axis, out=None):
+        """Window with 1/PSWF, zero-pad to ``yN_size``, shift by ``facet_off``
+        and inverse-transform along ``axis`` (core.py:189-222)."""
+        size = facet.shape[axis] if len(facet.shape) > 1 else facet.shape[0]
+        return self._axis_call(
+            "prepare_facet", facet, None, self.yN_size, axis, out, False, facet_off, size_arg=int(size)
+        )
+
+    def extract_from_facet(self, prep_facet, subgrid_off, axis, out=None):
+        """Cut the ``xM_yN_size`` window of a prepared facet that contributes to
+        the subgrid at ``subgrid_off`` (core.py:224-253).  Bit-exact copy."""
+        return self._axis_call(
+            "extract_from_facet", prep_facet, self.yN_size, self.xM_yN_size, axis, out, False, subgrid_off
+        )
+
+    def add_to_subgrid(self, facet_contrib, facet_off, axis, out=None):
+        """Transform a contribution, weight with Fn and ADD it at its place in
+        the padded subgrid (core.py:255-285)."""
+        return self._axis_call(
+            "add_to_subgrid", facet_contrib, self.xM_yN_size, self.xM_size, axis, out, True, facet_off
+        )
+
+    def add_to_subgrid_2d(self, facet_contrib, facet_off0, facet_off1, out=None):
+        """Both axes of :py:meth:`add_to_subgrid` (core.py:752-778)."""
+        if len(facet_contrib.shape) != 2:
+            raise ValueError(f"Invalid number of dimensions in input array: {len(facet_contrib.shape)}")
+        dev, was_numpy = self._as_device(facet_contrib)
+        tmp = self.add_to_subgrid(dev, facet_off0, axis=0)
+        res = self.add_to_subgrid(tmp, facet_off1, axis=1, out=out)
+        if was_numpy and out is None:
+            return res.cpu().numpy()
+        return res
+
+    def finish_subgrid(self, summed_contribs, subgrid_off, subgrid_size, out=None, masks=None):
+        """Inverse-transform the summed contributions along every axis and cut
+        out the subgrid (core.py:287-325).  ``subgrid_off`` is an int for 1-D
+        input and a list for 2-D.  ``masks`` (extension, optional list of one
+        real vector or None per axis) multiplies the result like
+        api_helper.py:107-112 does after the fact."""
+        dims = len(summed_contribs.shape)
+        if not isinstance(subgrid_off, list):
+            if dims != 1:
+                raise ValueError("Subgrid offset must be given for every dimension!")
+            subgrid_off = [subgrid_off]
+        if len(subgrid_off) != dims:
+            raise ValueError("Subgrid offset must be given for every dimension!")
+        masks = list(masks) if masks is not None else [None] * dims
+        if dims == 1:
+            return self._axis_call(
+                "finish_subgrid", summed_contribs, self.xM_size, subgrid_size, 0, out, False,
+                subgrid_off[0], size_arg=int(subgrid_size), mask=masks[0],
+            )
+        if dims != 2:
+            raise ValueError(f"Invalid shape {tuple(summed_contribs.shape)}!")
+        # axis 1 first on all xM rows, then axis 0 on the surviving columns
+        dev, was_numpy = self._as_device(summed_contribs)
+        tmp = self._axis_call(
+            "finish_subgrid", dev, self.xM_size, subgrid_size, 1, None, False,
+            subgrid_off[1], size_arg=int(subgrid_size), mask=masks[1],
+        )
+        res = self._axis_call(
+            "finish_subgrid", tmp, self.xM_size, subgrid_size, 0, out, False,
+            subgrid_off[0], size_arg=int(subgrid_size), mask=masks[0],
+        )
+        if was_numpy and out is None:
+            return res.cpu().numpy()
+        return res
+
+    # ------------------------------------------------------------------ subgrid -> facet
+    def prepare_subgrid(self, subgrid, subgrid_off, out=None):
+        """Pad to ``xM_size``, align with the global grid origin and transform
+        along every axis (core.py:328-368)."""
+        dims = len(subgrid.shape)
+        if dims == 1 and not isinstance(subgrid_off, (tuple, list)):
+            subgrid_off = (subgrid_off,)
+        if len(subgrid_off) != dims:
+            raise ValueError("Dimensionality mismatch between subgrid and offsets!")
+        if dims == 1:
+            return self._axis_call(
+                "prepare_subgrid", subgrid, None, self.xM_size, 0, out, False,
+                subgrid_off[0], size_arg=int(subgrid.shape[0]),
+            )
+        if dims != 2:
+            raise ValueError(f"Invalid shape {tuple(subgrid.shape)}!")
+        dev, was_numpy = self._as_device(subgrid)
+        # axis 1 on the xA rows only, then axis 0 on all xM columns
+        tmp = self._axis_call(
+            "prepare_subgrid", dev, None, self.xM_size, 1, None, False,
+            subgrid_off[1], size_arg=int(subgrid.shape[1]),
+        )
+        res = self._axis_call(
+            "prepare_subgrid", tmp, None, self.xM_size, 0, out, False,
+            subgrid_off[0], size_arg=int(subgrid.shape[0]),
+        )
+        if was_numpy and out is None:
+            return res.cpu().numpy()
+        return res
+
+    def extract_from_subgrid(self, FSi, facet_off, axis, out=None):
+        """Cut the window of a prepared subgrid that lands on the facet at
+        ``facet_off``, weight with Fn and inverse-transform to contribution
+        size (core.py:370-406)."""
+        return self._axis_call(
+            "extract_from_subgrid", FSi, self.xM_size, self.xM_yN_size, axis, out, False, facet_off
+        )
+
+    def add_to_facet(self, subgrid_contrib, subgrid_off, axis, out=None):
+        """ADD a subgrid contribution at its place in the padded facet
+        (core.py:408-449).  Exact additions."""
+        return self._axis_call(
+            "add_to_facet", subgrid_contrib, self.xM_yN_size, self.yN_size, axis, out, True, subgrid_off
+        )
+
+    def finish_facet(self, MiNjSi_sum, facet_off, facet_size, axis, out=None, mask=None):
+        """Transform the accumulated contributions, cut the facet out and
+        multiply with 1/PSWF (core.py:452-484).  ``mask`` (extension) folds the
+        facet mask multiply of api_helper.py:175-176 / 195-196."""
+        return self._axis_call(
+            "finish_facet", MiNjSi_sum, self.yN_size, facet_size, axis, out, False,
+            facet_off, size_arg=int(facet_size), mask=mask,
+        )

@@ -1,0 +1,241 @@
+"""
+GPU parity tests of SwiftlyCoreHip (HIP kernels through the C ABI) against
+  (a) the golden vectors produced by the reference itself (tests/golden),
+  (b) the CPU oracle on seeded inputs,
+  (c) the reference's known-answer tests (tests/kat.py, from tests/test_core.py).
+
+Tolerances.  complex128: the HIP FFT differs from pocketfft only in rounding;
+bound 2e-13 * max|expected| (the reference's own tightest check is 1e-15 on an
+O(1e-3) quantity, i.e. relative 1e-12).  complex64: float32 arithmetic with
+float32 windows; the oracle computes in complex128, so the bound is the
+float32 round-off of a length-n transform amplified by the window dynamic range:
+relative RMSE <= 2e-6 and max-abs <= 2e-5 * max|expected| for these parameter
+sets.  Gathers / scatter-adds (extract_from_facet, add_to_facet) are bit exact
+in both precisions.
+"""
+import os
+
+import numpy
+import pytest
+
+import kat
+from oracle import swiftly_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TEST_PARAMS = kat.TEST_PARAMS
+SMALL_PARAMS = dict(W=13.5625, N=512, yB_size=208, yN_size=256, xA_size=100, xM_size=128)
+
+_cores = {}
+
+
+def hip_core(p):
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    key = (p["W"], p["N"], p["xM_size"], p["yN_size"])
+    if key not in _cores:
+        _cores[key] = SwiftlyCoreHip(p["W"], p["N"], p["xM_size"], p["yN_size"])
+    return _cores[key]
+
+
+def close(got, want, dtype):
+    got = numpy.asarray(got)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert got.dtype == dtype
+    scale = max(float(numpy.max(numpy.abs(want))), 1e-30)
+    err = numpy.abs(got - want)
+    if dtype == numpy.complex128:
+        assert err.max() <= 2e-13 * scale, err.max() / scale
+    else:
+        rms = numpy.sqrt(numpy.mean(err**2)) / max(numpy.sqrt(numpy.mean(numpy.abs(want) ** 2)), 1e-30)
+        assert rms <= 2e-6, rms
+        assert err.max() <= 2e-5 * scale, err.max() / scale
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex128, numpy.complex64])
+def test_golden_1d(golden_dir, dtype):
+    g = numpy.load(os.path.join(golden_dir, "prim1d.npz"))
+    p = TEST_PARAMS
+    core = hip_core(p)
+    fos, sos = g["facet_offs"], g["sg_offs"]
+    c = lambda a: a.astype(dtype)  # noqa: E731
+    for yB in (p["yB_size"], p["yB_size"] - 1):
+        for i, fo in enumerate(fos):
+            close(core.prepare_facet(c(g[f"facet_{yB}"]), int(fo), 0), g[f"prepare_facet_{yB}_{i}"], dtype)
+            close(core.finish_facet(c(g[f"facc_{yB}"]), int(fo), yB, 0), g[f"finish_facet_{yB}_{i}"], dtype)
+    for i, so in enumerate(sos):
+        got = core.extract_from_facet(c(g["prep"]), int(so), 0)
+        assert numpy.array_equal(got, c(g[f"extract_from_facet_{i}"]))
+        got = core.add_to_facet(c(g["contrib"]), int(so), 0)
+        assert numpy.array_equal(got, c(g[f"add_to_facet_{i}"]))
+    for i, fo in enumerate(fos):
+        close(core.add_to_subgrid(c(g["contrib"]), int(fo), 0), g[f"add_to_subgrid_{i}"], dtype)
+        close(core.extract_from_subgrid(c(g["sacc"]), int(fo), 0), g[f"extract_from_subgrid_{i}"], dtype)
+    for xA in (p["xA_size"], p["xA_size"] - 1):
+        for i, so in enumerate(sos):
+            close(core.finish_subgrid(c(g["sacc"]), int(so), xA), g[f"finish_subgrid_{xA}_{i}"], dtype)
+            close(core.prepare_subgrid(c(g[f"subgrid_{xA}"]), int(so)), g[f"prepare_subgrid_{xA}_{i}"], dtype)
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex128, numpy.complex64])
+def test_golden_2d(golden_dir, dtype):
+    g = numpy.load(os.path.join(golden_dir, "prim2d.npz"))
+    p = SMALL_PARAMS
+    core = hip_core(p)
+    fo0, fo1, so0, so1 = (int(v) for v in g["offs"])
+    xA, yB = p["xA_size"], p["yB_size"]
+    c = lambda a: a.astype(dtype)  # noqa: E731
+    close(core.prepare_facet(c(g["facet"]), fo0, 0), g["prepare_facet_a0"], dtype)
+    close(core.prepare_facet(c(g["facet"][:37]), fo1, 1), g["prepare_facet_a1"], dtype)
+    got = core.extract_from_facet(c(g["prepare_facet_a0"]), so0, 0)
+    assert numpy.array_equal(got, c(g["extract_from_facet_a0"]))
+    close(core.prepare_facet(c(g["extract_from_facet_a0"]), fo1, 1), g["extract_column"], dtype)
+    got = core.extract_from_facet(c(g["extract_column"]), so1, 1)
+    assert numpy.array_equal(got, c(g["contrib"]))
+    close(core.add_to_subgrid(c(g["contrib"]), fo0, 0), g["add_to_subgrid_a0"], dtype)
+    close(core.add_to_subgrid(c(g["add_to_subgrid_a0"]), fo1, 1), g["add_to_subgrid_a01"], dtype)
+    close(core.add_to_subgrid_2d(c(g["contrib"]), fo0, fo1), g["add_to_subgrid_a01"], dtype)
+    close(core.finish_subgrid(c(g["add_to_subgrid_a01"]), [so0, so1], xA), g["finish_subgrid"], dtype)
+    close(core.finish_subgrid(c(g["add_to_subgrid_a01"]), [so0, so1], xA - 1), g["finish_subgrid_odd"], dtype)
+    close(core.prepare_subgrid(c(g["subgrid"]), [so0, so1]), g["prepare_subgrid"], dtype)
+    close(core.extract_from_subgrid(c(g["prepare_subgrid"]), fo0, 0), g["extract_from_subgrid_a0"], dtype)
+    close(core.extract_from_subgrid(c(g["extract_from_subgrid_a0"]), fo1, 1), g["extract_from_subgrid_a01"], dtype)
+    got = core.add_to_facet(c(g["extract_from_subgrid_a01"]), so1, 1)
+    assert numpy.array_equal(got, c(g["add_to_facet_a1"]))
+    close(core.finish_facet(c(g["add_to_facet_a1"]), fo1, 61, 1), g["finish_facet_a1"], dtype)
+    got = core.add_to_facet(c(g["finish_facet_a1"]), so0, 0)
+    assert numpy.array_equal(got, c(g["add_to_facet_a0"]))
+    close(core.finish_facet(c(g["add_to_facet_a0"]), fo0, yB, 0), g["finish_facet_a0"], dtype)
+
+
+def test_out_and_accumulate_semantics():
+    """core.py:152-186: out= is shape-checked, written / accumulated in place
+    and returned; add_to_* accumulate."""
+    p = SMALL_PARAMS
+    core = hip_core(p)
+    ref = orc.OracleCore(p["W"], p["N"], p["xM_size"], p["yN_size"])
+    rng = numpy.random.default_rng(3)
+    m, xM, yN = core.xM_yN_size, p["xM_size"], p["yN_size"]
+    c1 = rng.standard_normal((m, 5)) + 1j * rng.standard_normal((m, 5))
+    c2 = rng.standard_normal((m, 5)) + 1j * rng.standard_normal((m, 5))
+    acc = core.add_to_subgrid(c1, 8, axis=0)
+    ret = core.add_to_subgrid(c2, -12, axis=0, out=acc)
+    assert ret is acc
+    want = ref.add_to_subgrid(c2, -12, 0, out=ref.add_to_subgrid(c1, 8, 0))
+    close(acc, want, numpy.complex128)
+    facc = core.add_to_facet(c1.T.copy(), 6, axis=1)
+    core.add_to_facet(c2.T.copy(), -4, axis=1, out=facc)
+    want = ref.add_to_facet(c2.T, -4, 1, out=ref.add_to_facet(c1.T, 6, 1))
+    assert numpy.array_equal(facc, want)
+    with pytest.raises(ValueError):
+        core.add_to_subgrid(c1, 8, axis=0, out=numpy.zeros((xM + 1, 5), dtype=complex))
+    with pytest.raises(ValueError):
+        core.finish_subgrid(numpy.zeros((xM, xM), dtype=complex), 0, 10)
+    with pytest.raises(ValueError):
+        core.prepare_subgrid(numpy.zeros((10, 10), dtype=complex), (0,))
+    with pytest.raises(ValueError):
+        core.prepare_facet(numpy.zeros((4, 4, 4), dtype=complex), 0, axis=0)
+    # torch in -> torch out, stays on device
+    import torch
+
+    t = torch.from_numpy(c1).cuda()
+    r = core.add_to_subgrid(t, 8, axis=0)
+    assert isinstance(r, torch.Tensor) and r.is_cuda and r.dtype == torch.complex128
+    close(r.cpu().numpy(), ref.add_to_subgrid(c1, 8, 0), numpy.complex128)
+    # real input is promoted (core.py:581-585)
+    r = core.prepare_facet(numpy.ones(p["yB_size"], dtype=numpy.float32), 0, axis=0)
+    assert r.dtype == numpy.complex64 and r.shape == (yN,)
+
+
+# ---- the reference's known-answer tests, complex128 with the reference's own
+# tolerances (decimal=15 / 8 / 13 / 11 -> 1.5e-15 etc.)
+P = TEST_PARAMS
+
+
+@pytest.mark.parametrize("xA", [P["xA_size"], P["xA_size"] - 1])
+@pytest.mark.parametrize("yB", [P["yB_size"], P["yB_size"] - 1])
+def test_kat_facet_to_subgrid_basic(xA, yB):
+    kat.facet_to_subgrid_basic(hip_core, xA, yB, thin=3)
+
+
+@pytest.mark.parametrize("xA,yB", [(P["xA_size"], P["yB_size"]), (P["xA_size"] - 1, P["yB_size"] - 1)])
+def test_kat_facet_to_subgrid_dft_1d(xA, yB):
+    kat.facet_to_subgrid_dft_1d(hip_core, xA, yB, thin=4)
+
+
+def test_kat_facet_to_subgrid_dft_2d():
+    kat.facet_to_subgrid_dft_2d(hip_core)
+
+
+@pytest.mark.parametrize("xA,yB", [(P["xA_size"], P["yB_size"]), (P["xA_size"] - 1, P["yB_size"] - 1)])
+def test_kat_subgrid_to_facet_basic(xA, yB):
+    kat.subgrid_to_facet_basic(hip_core, xA, yB, thin=4)
+
+
+@pytest.mark.parametrize("xA,yB", [(P["xA_size"], P["yB_size"]), (P["xA_size"] - 1, P["yB_size"] - 1)])
+def test_kat_subgrid_to_facet_dft(xA, yB):
+    kat.subgrid_to_facet_dft(hip_core, xA, yB, thin=4)
+
+
+def test_kat_subgrid_to_facet_dft_2d():
+    kat.subgrid_to_facet_dft_2d(hip_core)
+
+
+def test_kat_complex64():
+    """Same known answers in complex64 with float32-appropriate bounds
+    (values are O(1/N) ~ 1e-3 forward, O(1) backward)."""
+    kat.facet_to_subgrid_basic(hip_core, P["xA_size"], P["yB_size"], tol=3e-9, dtype=numpy.complex64, thin=5)
+    kat.facet_to_subgrid_dft_2d(hip_core, tol=5e-8, dtype=numpy.complex64)
+    kat.subgrid_to_facet_basic(hip_core, P["xA_size"], P["yB_size"], tol=2e-5, dtype=numpy.complex64, thin=6)
+
+
+@pytest.mark.parametrize("logn", range(3, 16))
+def test_fft_lengths_c64(logn):
+    """Every engine configuration (N = 8 .. 32768) through prepare_subgrid /
+    finish_subgrid, which are bare centred FFT / iFFT plus crop when
+    subgrid_size == xM_size."""
+    n = 1 << logn
+    # N = 2n, yN = n, xM = n -> m = n/2; any W works for the bare transform
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    core = SwiftlyCoreHip(4.0, 2 * n, n, n)
+    rng = numpy.random.default_rng(logn)
+    rows = 3 if logn > 12 else 11
+    x = (rng.standard_normal((rows, n)) + 1j * rng.standard_normal((rows, n))).astype(numpy.complex64)
+    import torch
+
+    xt = torch.from_numpy(x).cuda()
+    got = core._axis_call("prepare_subgrid", xt, None, n, 1, None, False, 0, size_arg=n).cpu().numpy()
+    want = orc.cfft(x.astype(complex), 1)
+    rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+    assert rel < 6e-7, rel
+    back = core._axis_call("finish_subgrid", torch.from_numpy(got).cuda(), n, n, 1, None, False, 0, size_arg=n).cpu().numpy()
+    rel = numpy.sqrt(numpy.mean(numpy.abs(back - x) ** 2) / numpy.mean(numpy.abs(x) ** 2))
+    assert rel < 1e-6, rel
+    # strided (axis 0) access path: lanes over rows
+    xt0 = torch.from_numpy(numpy.ascontiguousarray(x.T)).cuda()
+    got0 = core._axis_call("prepare_subgrid", xt0, None, n, 0, None, False, 0, size_arg=n).cpu().numpy()
+    assert numpy.allclose(got0.T, got, rtol=0, atol=1e-5 * numpy.abs(got).max())
+
+
+@pytest.mark.parametrize("logn", [3, 6, 9, 11, 13])
+def test_fft_lengths_c128(logn):
+    n = 1 << logn
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    core = SwiftlyCoreHip(4.0, 2 * n, n, n)
+    rng = numpy.random.default_rng(100 + logn)
+    x = rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))
+    got = core.prepare_subgrid(x[0], 0)
+    want = orc.cfft(x[0], 0)
+    assert numpy.abs(got - want).max() < 1e-12 * numpy.abs(want).max()
+
+
+def test_unsupported_length_raises():
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    # 96k[1]-n48k-512 style: yN = 3*2^k -> constructs (reference tests/test_core.py:82-90
+    # only constructs), but transforms of that length are refused loudly
+    core = SwiftlyCoreHip(11.0, 1536, 128, 768)
+    with pytest.raises(NotImplementedError):
+        core.prepare_facet(numpy.zeros(500, dtype=complex), 0, axis=0)
