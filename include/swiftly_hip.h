@@ -129,6 +129,60 @@ int swiftly_hip_finish_facet(swiftly_hip_t* h, int dtype, const void* in, int64_
                              int64_t in_col_stride, void* out, int64_t out_row_stride, int64_t out_col_stride,
                              int64_t facet_off, int64_t facet_size, const void* mask, void* stream);
 
+
+/* -- fused / batched forms used by the streaming classes ---------------------
+ *
+ * *_batch: `nbatch` independent problems of identical shape; item b reads
+ * in + b*in_batch_stride and writes out + b*out_batch_stride (strides in
+ * complex elements; in_batch_stride = 0 shares one input).  `offs` is a HOST
+ * array of nbatch per-item offsets, or NULL to use the scalar offset for all
+ * items.  `mask` (finish_*): item b uses mask + b*mask_batch_stride (real
+ * elements; 0 = one shared mask).  One launch covers up to 64 items. */
+
+/* api_helper.extract_column (api_helper.py:200-210) as one kernel:
+ * prepare_facet(extract_from_facet(BF_F, subgrid_off0, axis=0), facet_off1,
+ * axis=1).  in = BF_F[yN, facet_size] (row stride in_row_stride), out =
+ * NMBF_BF[m, yN].  The row gather is folded into the load. */
+int swiftly_hip_extract_column(swiftly_hip_t* h, int dtype, const void* in, int64_t facet_size,
+                               int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
+                               int64_t out_col_stride, int64_t subgrid_off0, int64_t facet_off1, void* stream);
+
+int swiftly_hip_extract_from_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
+                                         int64_t in_row_stride, int64_t in_col_stride, void* out,
+                                         int64_t out_row_stride, int64_t out_col_stride, int64_t subgrid_off,
+                                         int64_t nbatch, int64_t in_batch_stride, int64_t out_batch_stride,
+                                         const int64_t* subgrid_offs, void* stream);
+int swiftly_hip_add_to_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
+                                     int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
+                                     int64_t out_col_stride, int64_t facet_off, int64_t nbatch,
+                                     int64_t in_batch_stride, int64_t out_batch_stride, const int64_t* facet_offs,
+                                     void* stream);
+int swiftly_hip_finish_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
+                                     int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
+                                     int64_t out_col_stride, int64_t subgrid_off, int64_t subgrid_size,
+                                     const void* mask, int64_t nbatch, int64_t in_batch_stride,
+                                     int64_t out_batch_stride, const int64_t* subgrid_offs,
+                                     int64_t mask_batch_stride, void* stream);
+int swiftly_hip_prepare_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
+                                      int64_t subgrid_size, int64_t in_row_stride, int64_t in_col_stride, void* out,
+                                      int64_t out_row_stride, int64_t out_col_stride, int64_t subgrid_off,
+                                      int64_t nbatch, int64_t in_batch_stride, int64_t out_batch_stride,
+                                      const int64_t* subgrid_offs, void* stream);
+int swiftly_hip_extract_from_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
+                                           int64_t in_row_stride, int64_t in_col_stride, void* out,
+                                           int64_t out_row_stride, int64_t out_col_stride, int64_t facet_off,
+                                           int64_t nbatch, int64_t in_batch_stride, int64_t out_batch_stride,
+                                           const int64_t* facet_offs, void* stream);
+int swiftly_hip_add_to_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+                                   int64_t in_col_stride, void* out, int64_t out_row_stride, int64_t out_col_stride,
+                                   int64_t subgrid_off, int64_t nbatch, int64_t in_batch_stride,
+                                   int64_t out_batch_stride, const int64_t* subgrid_offs, void* stream);
+int swiftly_hip_finish_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+                                   int64_t in_col_stride, void* out, int64_t out_row_stride, int64_t out_col_stride,
+                                   int64_t facet_off, int64_t facet_size, const void* mask, int64_t nbatch,
+                                   int64_t in_batch_stride, int64_t out_batch_stride, const int64_t* facet_offs,
+                                   int64_t mask_batch_stride, void* stream);
+
 /* -- device memory helpers for callers that do not bring their own allocator
  *    (the Python mirror uses torch for device memory and never calls these) -- */
 int swiftly_hip_malloc(void** ptr, size_t bytes);

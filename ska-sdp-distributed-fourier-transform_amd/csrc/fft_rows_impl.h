@@ -8,12 +8,12 @@
 namespace swf {
 
 template <typename R, int LOGN>
-static int launch_one(const RowsArgs<R>& a, hipStream_t s) {
+static int launch_one(const RowsArgs<R>& a, const OffTab& tab, hipStream_t s) {
     using G = typename GeoFor<R, LOGN>::type;
     const long long total = (long long)a.nrows * a.outer;
     if (total <= 0) return 0;
     const unsigned grid = (unsigned)((total + G::RB - 1) / G::RB);
-    hipLaunchKernelGGL((fft_rows_kernel<G, R>), dim3(grid), dim3(G::NT), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((fft_rows_kernel<G, R>), dim3(grid, a.nbatch > 0 ? a.nbatch : 1), dim3(G::NT), G::LDS_BYTES, s, a, tab);
     return (int)hipGetLastError();
 }
 
@@ -26,9 +26,9 @@ static int init_one() {
 
 template <typename R, int LO, int HI>
 struct Dispatch {
-    static int launch(int logn, const RowsArgs<R>& a, hipStream_t s) {
-        if (logn == LO) return launch_one<R, LO>(a, s);
-        if constexpr (LO < HI) return Dispatch<R, LO + 1, HI>::launch(logn, a, s);
+    static int launch(int logn, const RowsArgs<R>& a, const OffTab& tab, hipStream_t s) {
+        if (logn == LO) return launch_one<R, LO>(a, tab, s);
+        if constexpr (LO < HI) return Dispatch<R, LO + 1, HI>::launch(logn, a, tab, s);
         return -1;
     }
     static int init() {

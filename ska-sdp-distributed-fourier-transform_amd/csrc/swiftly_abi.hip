@@ -17,6 +17,7 @@
 // centred (origin at index n//2).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -143,6 +144,9 @@ static int make_twiddles(swiftly_hip* h, int logn) {
 }
 
 static bool g_inited = false;
+// Transforms of length >= 2^kTwoPassMinLog along a STRIDED axis (rows contiguous) are decomposed into
+// two passes of short transforms so that every access is >= 128 B contiguous.
+static const int kTwoPassMinLog = 9;
 
 extern "C" {
 
@@ -209,7 +213,11 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
     if (!rc) rc = upload(h, &h->fn_d, fn);
     if (!rc) rc = upload(h, &h->fn_f, fnf);
     for (int l : {h->log_yN, h->log_xM, h->log_m})
-        if (!rc && l >= 0) rc = make_twiddles(h, l);
+        if (!rc && l >= 0) {
+            rc = make_twiddles(h, l);
+            if (!rc && l >= kTwoPassMinLog) rc = make_twiddles(h, l / 2);
+            if (!rc && l >= kTwoPassMinLog) rc = make_twiddles(h, l - l / 2);
+        }
     if (rc) {
         swiftly_hip_destroy(h);
         return rc;
@@ -229,16 +237,34 @@ int64_t swiftly_hip_contribution_size(const swiftly_hip_t* h) { return h ? h->m 
 }  // extern "C"
 
 // ---------------------------------------------------------------------------
+// Batch descriptor shared by all *_batch entry points: nbatch independent
+// problems of identical shape at in + b*in_bs / out + b*out_bs.  `offs`
+// (host array, may be null) gives a per-item offset, otherwise `off` applies
+// to every item.
+struct Batch {
+    int64_t n = 1, in_bs = 0, out_bs = 0;
+    const int64_t* offs = nullptr;
+    int64_t mask_bs = 0;
+    int64_t off_of(int64_t b, int64_t off) const { return offs ? offs[b] : off; }
+};
+
 // modular gather / scatter-add (extract_from_facet / add_to_facet)
 //   j < m ; i = (j - s) mod m ; big = (base + i + s) mod yN
 //   gather : out[row, j]   = in[row, big]
 //   scatter: out[row, big] += in[row, j]
+struct ModTab {
+    int s_m[kMaxBatch], base_s[kMaxBatch];
+};
+
 template <typename R, bool SCATTER>
 __global__ void modcopy_kernel(const cx<R>* __restrict__ in, cx<R>* __restrict__ out, long long rows, int m, int yN,
-                               int s_m, int base_s, long long in_rs, long long in_cs, long long out_rs,
-                               long long out_cs, int rowfast) {
+                               const ModTab tab, long long in_rs, long long in_cs, long long out_rs,
+                               long long out_cs, long long in_bs, long long out_bs, int rowfast) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= rows * m) return;
+    const int b = blockIdx.y;
+    in += (long long)b * in_bs;
+    out += (long long)b * out_bs;
     long long row;
     int j;
     if (rowfast) {
@@ -248,9 +274,9 @@ __global__ void modcopy_kernel(const cx<R>* __restrict__ in, cx<R>* __restrict__
         j = (int)(gid % m);
         row = gid / m;
     }
-    int i = j - s_m;
+    int i = j - tab.s_m[b];
     if (i < 0) i += m;
-    int big = base_s + i;  // base_s = (yN/2 - m/2 + s) mod yN
+    int big = tab.base_s[b] + i;  // base_s = (yN/2 - m/2 + s) mod yN
     if (big >= yN) big -= yN;
     if (SCATTER) {
         cx<R> v = in[row * in_rs + (long long)j * in_cs];
@@ -266,19 +292,26 @@ __global__ void modcopy_kernel(const cx<R>* __restrict__ in, cx<R>* __restrict__
 
 template <typename R, bool SCATTER>
 static int run_modcopy(swiftly_hip* h, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
-                       int64_t out_rs, int64_t out_cs, int64_t subgrid_off, hipStream_t st) {
-    if (rows <= 0) return 0;
-    const int64_t s = floordiv(subgrid_off * h->yN, h->N);
+                       int64_t out_rs, int64_t out_cs, int64_t subgrid_off, const Batch& bt, hipStream_t st) {
+    if (rows <= 0 || bt.n <= 0) return 0;
     const int m = (int)h->m, yN = (int)h->yN;
-    const int s_m = pmod(s, m);
-    const int base_s = pmod(yN / 2 - m / 2 + s, yN);
     const long long total = rows * (long long)m;
     const int rowfast = (in_rs == 1 && in_cs != 1) ? 1 : 0;
-    dim3 grid((unsigned)((total + 255) / 256));
-    hipLaunchKernelGGL((modcopy_kernel<R, SCATTER>), grid, dim3(256), 0, st, (const cx<R>*)in, (cx<R>*)out,
-                       (long long)rows, m, yN, s_m, base_s, (long long)in_rs, (long long)in_cs, (long long)out_rs,
-                       (long long)out_cs, rowfast);
-    HIP_TRY(hipGetLastError());
+    for (int64_t b0 = 0; b0 < bt.n; b0 += kMaxBatch) {
+        const int nb = (int)std::min<int64_t>(kMaxBatch, bt.n - b0);
+        ModTab tab;
+        for (int b = 0; b < nb; b++) {
+            const int64_t s = floordiv(bt.off_of(b0 + b, subgrid_off) * h->yN, h->N);
+            tab.s_m[b] = pmod(s, m);
+            tab.base_s[b] = pmod(yN / 2 - m / 2 + s, yN);
+        }
+        dim3 grid((unsigned)((total + 255) / 256), nb);
+        hipLaunchKernelGGL((modcopy_kernel<R, SCATTER>), grid, dim3(256), 0, st,
+                           (const cx<R>*)in + b0 * bt.in_bs, (cx<R>*)out + b0 * bt.out_bs, (long long)rows, m, yN, tab,
+                           (long long)in_rs, (long long)in_cs, (long long)out_rs, (long long)out_cs,
+                           (long long)bt.in_bs, (long long)bt.out_bs, rowfast);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -289,18 +322,19 @@ static AxisMap<R> identity_map(int n) {
 }
 
 template <typename R>
-static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, hipStream_t st) {
-    constexpr int maxlog = sizeof(R) == 8 ? kMaxLogNDouble : kMaxLogNFloat;
-    if (logn < kMinLogN || logn > maxlog)
-        return fail(SWIFTLY_ERR_UNSUPPORTED,
-                    "transform length %s is not supported by the HIP backend (power of two in [8, %d] required for %s)",
-                    logn < 0 ? "(not a power of two)" : std::to_string(1 << logn).c_str(), 1 << maxlog,
-                    sizeof(R) == 8 ? "complex128" : "complex64");
+static int launch_checked(int logn, const RowsArgs<R>& a, const OffTab& tab, hipStream_t st) {
+    int rc = launch_fft_rows(logn, a, tab, st);
+    if (rc) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return 0;
+}
+
+// Launch the mapped row FFT for `a` (batch of a.nbatch <= kMaxBatch items with
+// per-item offsets in `tab`).  Transforms of length >= 2^kTwoPassMinLog along
+// a strided axis are decomposed (four-step) through a stream-ordered scratch.
+template <typename R>
+static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab& tab, hipStream_t st) {
     a.tw = twiddles<R>(h, logn);
     if (!a.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table for 2^%d", logn);
-    const uint64_t n = uint64_t(1) << logn;
-    if (n * (uint64_t)a.in_cs >= (uint64_t(1) << 32) || n * (uint64_t)a.out_cs >= (uint64_t(1) << 32))
-        return fail(SWIFTLY_ERR_PARAM, "transform length * column stride must be < 2^32");
     a.full_logn = logn;
     a.ld_mul = a.st_mul = 1;
     a.ld_addmul = a.st_addmul = 0;
@@ -309,9 +343,95 @@ static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, hipStream_t st) {
     a.tw_full = nullptr;
     a.tw_on_store = 0;
     a.raw_ld = a.raw_st = 0;
-    if (a.nrows <= 0) return 0;
-    int rc = launch_fft_rows(logn, a, st);
-    if (rc) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (!(a.rowfast && logn >= kTwoPassMinLog)) return launch_checked(logn, a, tab, st);
+
+    // ---- four-step: N = n1 * n2, input index y = y1*n2 + y2, output index k = k1 + n1*k2
+    //   pass A (length n1 over y1, one per y2): scratch[k1*n2 + y2] = W_N^(y2 k1) * sum_y1 x[y1 n2 + y2] W_n1^(y1 k1)
+    //   pass B (length n2 over y2, one per k1): X[k1 + n1 k2]       = sum_y2 scratch[k1*n2 + y2] W_n2^(y2 k2)
+    const uint64_t n = uint64_t(1) << logn;
+    const int l1 = logn / 2, l2 = logn - l1;
+    const int n1 = 1 << l1, n2 = 1 << l2;
+    const cx<R>* tw1 = twiddles<R>(h, l1);
+    const cx<R>* tw2 = twiddles<R>(h, l2);
+    if (!tw1 || !tw2) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables for the two-pass transform");
+    const long long W = a.nrows;  // scratch row width (rows of the op are contiguous in memory)
+    if (n * (uint64_t)W >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "two-pass scratch exceeds 2^32 elements; split the call by columns");
+    const int nb = a.nbatch > 0 ? a.nbatch : 1;
+    void* scratch = nullptr;
+    HIP_TRY(hipMallocAsync(&scratch, (size_t)nb * n * (size_t)W * sizeof(cx<R>), st));
+    RowsArgs<R> A = a;
+    A.tw = tw1;
+    A.tw_full = a.tw;
+    A.tw_on_store = 1;
+    A.outer = n2;
+    A.ld_mul = n2;
+    A.ld_addmul = 1;
+    A.raw_st = 1;
+    A.out = (cx<R>*)scratch;
+    A.out_rs = 1;
+    A.out_cs = (unsigned)(n2 * W);
+    A.out_os = W;
+    A.out_bs = (long long)(n * W);
+    A.conj_st = 0;
+    A.scale = (R)1;
+    A.accumulate = 0;
+    int rc = launch_checked(l1, A, tab, st);
+    if (!rc) {
+        RowsArgs<R> B = a;
+        B.tw = tw2;
+        B.in = (const cx<R>*)scratch;
+        B.raw_ld = 1;
+        B.in_rs = 1;
+        B.in_cs = (unsigned)W;
+        B.in_os = (long long)n2 * W;
+        B.in_bs = (long long)(n * W);
+        B.rm_mod = 0;
+        B.outer = n1;
+        B.st_mul = n1;
+        B.st_addmul = 1;
+        B.conj_ld = 0;
+        rc = launch_checked(l2, B, tab, st);
+    }
+    hipError_t e = hipFreeAsync(scratch, st);
+    if (!rc && e != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// `fill(b, tab_index)` sets the per-item offsets of batch item b into the
+// OffTab; called once per item per chunk.
+template <typename R, class Fill>
+static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, const Batch& bt, int use_bits, Fill&& fill,
+                    hipStream_t st) {
+    constexpr int maxlog = sizeof(R) == 8 ? kMaxLogNDouble : kMaxLogNFloat;
+    if (logn < kMinLogN || logn > maxlog)
+        return fail(SWIFTLY_ERR_UNSUPPORTED,
+                    "transform length %s is not supported by the HIP backend (power of two in [8, %d] required for %s)",
+                    logn < 0 ? "(not a power of two)" : std::to_string(1 << logn).c_str(), 1 << maxlog,
+                    sizeof(R) == 8 ? "complex128" : "complex64");
+    const uint64_t n = uint64_t(1) << logn;
+    if (n * (uint64_t)a.in_cs >= (uint64_t(1) << 32) || n * (uint64_t)a.out_cs >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "transform length * column stride must be < 2^32");
+    if (a.nrows <= 0 || bt.n <= 0) return 0;
+    const cx<R>* in0 = a.in;
+    cx<R>* out0 = a.out;
+    const R* win0 = a.st.win;
+    for (int64_t b0 = 0; b0 < bt.n; b0 += kMaxBatch) {
+        const int nb = (int)std::min<int64_t>(kMaxBatch, bt.n - b0);
+        OffTab tab;
+        tab.use = bt.offs ? use_bits : 0;
+        if (tab.use)
+            for (int b = 0; b < nb; b++) fill(b0 + b, b, tab);
+        RowsArgs<R> c = a;
+        c.in = in0 + b0 * bt.in_bs;
+        c.out = out0 + b0 * bt.out_bs;
+        c.in_bs = bt.in_bs;
+        c.out_bs = bt.out_bs;
+        c.nbatch = nb;
+        c.st_win_bs = bt.mask_bs;
+        if (win0) c.st.win = win0 + b0 * bt.mask_bs;
+        if (int rc = run_rows_chunk(h, logn, c, tab, st)) return rc;
+    }
     return 0;
 }
 
@@ -322,6 +442,8 @@ static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, hipStream_t st) {
     if (in_cs < 0 || out_cs < 0 || in_cs >= (int64_t(1) << 32) || out_cs >= (int64_t(1) << 32)) \
         return fail(SWIFTLY_ERR_PARAM, "column strides must be in [0, 2^32)");                 \
     if (rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "too many rows");
+#define CHECK_BATCH()                                                                        \
+    if (nbatch < 0 || in_bs < 0 || out_bs < 0) return fail(SWIFTLY_ERR_PARAM, "bad batch description");
 
 template <typename R>
 static void fill_io(RowsArgs<R>& a, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
@@ -339,10 +461,16 @@ static void fill_io(RowsArgs<R>& a, const void* in, int64_t rows, int64_t in_rs,
     a.rowfast = (in_rs == 1 && in_cs != 1) ? 1 : 0;
 }
 
+static const auto kNoFill = [](int64_t, int, OffTab&) {};
+
+// row_gather_off: when not INT64_MIN, the rows of `in` are gathered like
+// extract_from_facet(subgrid_off = row_gather_off) would along the OTHER axis
+// (fuses api_helper.extract_column, api_helper.py:200-210, into one kernel).
 template <typename R>
 static int do_prepare_facet(swiftly_hip* h, const void* in, int64_t rows, int64_t yB, int64_t in_rs, int64_t in_cs,
-                            void* out, int64_t out_rs, int64_t out_cs, int64_t off, hipStream_t st) {
-    const int yN = (int)h->yN;
+                            void* out, int64_t out_rs, int64_t out_cs, int64_t off, int64_t row_gather_off,
+                            hipStream_t st) {
+    const int yN = (int)h->yN, m = (int)h->m;
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
     const int lo = yN / 2 - (int)(yB / 2);
@@ -350,26 +478,40 @@ static int do_prepare_facet(swiftly_hip* h, const void* in, int64_t rows, int64_
     a.st = identity_map<R>(yN);
     a.conj_ld = a.conj_st = 1;
     a.scale = (R)(1.0 / yN);
-    return run_rows(h, h->log_yN, a, st);
+    if (row_gather_off != INT64_MIN) {
+        const int64_t s = floordiv(row_gather_off * h->yN, h->N);
+        a.rm_mod = m;
+        a.rm_inner = pmod(-s, m);
+        a.rm_outer = pmod(yN / 2 - m / 2 + s, yN);
+        a.rm_full = yN;
+    }
+    return run_rows(h, h->log_yN, a, Batch{}, 0, kNoFill, st);
 }
 
 template <typename R>
 static int do_add_to_subgrid(swiftly_hip* h, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
-                             int64_t out_rs, int64_t out_cs, int64_t off, hipStream_t st) {
+                             int64_t out_rs, int64_t out_cs, int64_t off, const Batch& bt, hipStream_t st) {
     const int m = (int)h->m, xM = (int)h->xM;
-    const int64_t sp = floordiv(off * h->xM, h->N);
+    auto maps = [&](int64_t o, int& a_, int& c_) {
+        const int64_t sp = floordiv(o * h->xM, h->N);
+        a_ = pmod(-sp, m);
+        c_ = pmod(xM / 2 - m / 2 + sp, xM);
+    };
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
     a.ld = identity_map<R>(m);
-    a.st = AxisMap<R>{pmod(-sp, m), m, pmod(xM / 2 - m / 2 + sp, xM), xM, fnwin<R>(h), nullptr};
+    int a0, c0;
+    maps(off, a0, c0);
+    a.st = AxisMap<R>{a0, m, c0, xM, fnwin<R>(h), nullptr};
     a.accumulate = 1;
-    return run_rows(h, h->log_m, a, st);
+    return run_rows(h, h->log_m, a, bt, 4 | 8,
+                    [&](int64_t gb, int b, OffTab& t) { maps(bt.offs[gb], t.st_a[b], t.st_c[b]); }, st);
 }
 
 template <typename R>
 static int do_finish_subgrid(swiftly_hip* h, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
                              int64_t out_rs, int64_t out_cs, int64_t off, int64_t xA, const void* mask,
-                             hipStream_t st) {
+                             const Batch& bt, hipStream_t st) {
     const int xM = (int)h->xM;
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
@@ -377,47 +519,69 @@ static int do_finish_subgrid(swiftly_hip* h, const void* in, int64_t rows, int64
     a.st = AxisMap<R>{pmod(-(xM / 2 - xA / 2 + off), xM), (int)xA, 0, (int)xA, (const R*)mask, nullptr};
     a.conj_ld = a.conj_st = 1;
     a.scale = (R)(1.0 / xM);
-    return run_rows(h, h->log_xM, a, st);
+    return run_rows(h, h->log_xM, a, bt, 4,
+                    [&](int64_t gb, int b, OffTab& t) { t.st_a[b] = pmod(-(xM / 2 - xA / 2 + bt.offs[gb]), xM); }, st);
 }
 
 template <typename R>
 static int do_prepare_subgrid(swiftly_hip* h, const void* in, int64_t rows, int64_t xA, int64_t in_rs, int64_t in_cs,
-                              void* out, int64_t out_rs, int64_t out_cs, int64_t off, hipStream_t st) {
+                              void* out, int64_t out_rs, int64_t out_cs, int64_t off, const Batch& bt,
+                              hipStream_t st) {
     const int xM = (int)h->xM;
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
     a.ld = AxisMap<R>{pmod(-(xM / 2 - xA / 2 + off), xM), (int)xA, 0, (int)xA, nullptr, nullptr};
     a.st = identity_map<R>(xM);
-    return run_rows(h, h->log_xM, a, st);
+    return run_rows(h, h->log_xM, a, bt, 1,
+                    [&](int64_t gb, int b, OffTab& t) { t.ld_a[b] = pmod(-(xM / 2 - xA / 2 + bt.offs[gb]), xM); }, st);
 }
 
 template <typename R>
 static int do_extract_from_subgrid(swiftly_hip* h, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs,
-                                   void* out, int64_t out_rs, int64_t out_cs, int64_t off, hipStream_t st) {
+                                   void* out, int64_t out_rs, int64_t out_cs, int64_t off, const Batch& bt,
+                                   hipStream_t st) {
     const int m = (int)h->m, xM = (int)h->xM;
-    const int64_t sp = floordiv(off * h->xM, h->N);
+    auto maps = [&](int64_t o, int& a_, int& c_) {
+        const int64_t sp = floordiv(o * h->xM, h->N);
+        a_ = pmod(-sp, m);
+        c_ = pmod(xM / 2 - m / 2 + sp, xM);
+    };
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
-    a.ld = AxisMap<R>{pmod(-sp, m), m, pmod(xM / 2 - m / 2 + sp, xM), xM, fnwin<R>(h), nullptr};
+    int a0, c0;
+    maps(off, a0, c0);
+    a.ld = AxisMap<R>{a0, m, c0, xM, fnwin<R>(h), nullptr};
     a.st = identity_map<R>(m);
     a.conj_ld = a.conj_st = 1;
     a.scale = (R)(1.0 / m);
-    return run_rows(h, h->log_m, a, st);
+    return run_rows(h, h->log_m, a, bt, 1 | 2,
+                    [&](int64_t gb, int b, OffTab& t) { maps(bt.offs[gb], t.ld_a[b], t.ld_c[b]); }, st);
 }
 
 template <typename R>
 static int do_finish_facet(swiftly_hip* h, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
-                           int64_t out_rs, int64_t out_cs, int64_t off, int64_t yB, const void* mask, hipStream_t st) {
+                           int64_t out_rs, int64_t out_cs, int64_t off, int64_t yB, const void* mask, const Batch& bt,
+                           hipStream_t st) {
     const int yN = (int)h->yN;
     const int lo = yN / 2 - (int)(yB / 2);
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
     a.ld = identity_map<R>(yN);
-    a.st = AxisMap<R>{pmod(-(lo + off), yN), (int)yB, 0, (int)yB, invp<R>(h) + lo, (const R*)mask};
-    return run_rows(h, h->log_yN, a, st);
+    // mask goes to `win` (it is the per-item one), the PSWF window to `win2`
+    a.st = AxisMap<R>{pmod(-(lo + off), yN), (int)yB, 0, (int)yB, (const R*)mask, invp<R>(h) + lo};
+    return run_rows(h, h->log_yN, a, bt, 4,
+                    [&](int64_t gb, int b, OffTab& t) { t.st_a[b] = pmod(-(lo + bt.offs[gb]), yN); }, st);
 }
 
 #define DISPATCH(fn, ...) (dtype == SWIFTLY_C64 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
+#define CHECK_FACET_SIZE()                                                                                     \
+    if (facet_size <= 0 || facet_size >= h->yN)                                                                \
+        return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1 = %lld]", (long long)facet_size, \
+                    (long long)(h->yN - 1));
+#define CHECK_SUBGRID_SIZE()                                                                                      \
+    if (subgrid_size <= 0 || subgrid_size > h->xM)                                                                \
+        return fail(SWIFTLY_ERR_PARAM, "subgrid size %lld must be in [1, xM_size = %lld]", (long long)subgrid_size, \
+                    (long long)h->xM);
 
 extern "C" {
 
@@ -425,76 +589,141 @@ int swiftly_hip_prepare_facet(swiftly_hip_t* h, int dtype, const void* in, int64
                               int64_t in_rs, int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs,
                               int64_t facet_off, void* stream) {
     CHECK_COMMON();
-    if (facet_size <= 0 || facet_size >= h->yN)
-        return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1 = %lld]", (long long)facet_size,
-                    (long long)(h->yN - 1));
-    return DISPATCH(do_prepare_facet, h, in, rows, facet_size, in_rs, in_cs, out, out_rs, out_cs, facet_off,
+    CHECK_FACET_SIZE();
+    return DISPATCH(do_prepare_facet, h, in, rows, facet_size, in_rs, in_cs, out, out_rs, out_cs, facet_off, INT64_MIN,
                     (hipStream_t)stream);
 }
 
+int swiftly_hip_extract_column(swiftly_hip_t* h, int dtype, const void* in, int64_t facet_size, int64_t in_rs,
+                               int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t subgrid_off0,
+                               int64_t facet_off1, void* stream) {
+    const int64_t rows = h ? h->m : 0;
+    CHECK_COMMON();
+    CHECK_FACET_SIZE();
+    return DISPATCH(do_prepare_facet, h, in, rows, facet_size, in_rs, in_cs, out, out_rs, out_cs, facet_off1,
+                    subgrid_off0, (hipStream_t)stream);
+}
+
+int swiftly_hip_extract_from_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
+                                         int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs,
+                                         int64_t subgrid_off, int64_t nbatch, int64_t in_bs, int64_t out_bs,
+                                         const int64_t* subgrid_offs, void* stream) {
+    CHECK_COMMON();
+    CHECK_BATCH();
+    Batch bt{nbatch, in_bs, out_bs, subgrid_offs, 0};
+    if (dtype == SWIFTLY_C64)
+        return run_modcopy<float, false>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, bt, (hipStream_t)stream);
+    return run_modcopy<double, false>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, bt, (hipStream_t)stream);
+}
 int swiftly_hip_extract_from_facet(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
                                    int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t subgrid_off,
                                    void* stream) {
-    CHECK_COMMON();
-    if (dtype == SWIFTLY_C64)
-        return run_modcopy<float, false>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, (hipStream_t)stream);
-    return run_modcopy<double, false>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, (hipStream_t)stream);
+    return swiftly_hip_extract_from_facet_batch(h, dtype, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, 1,
+                                                0, 0, nullptr, stream);
 }
 
+int swiftly_hip_add_to_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
+                                     int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t facet_off,
+                                     int64_t nbatch, int64_t in_bs, int64_t out_bs, const int64_t* facet_offs,
+                                     void* stream) {
+    CHECK_COMMON();
+    CHECK_BATCH();
+    Batch bt{nbatch, in_bs, out_bs, facet_offs, 0};
+    return DISPATCH(do_add_to_subgrid, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, bt, (hipStream_t)stream);
+}
 int swiftly_hip_add_to_subgrid(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
                                int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t facet_off,
                                void* stream) {
-    CHECK_COMMON();
-    return DISPATCH(do_add_to_subgrid, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, (hipStream_t)stream);
+    return swiftly_hip_add_to_subgrid_batch(h, dtype, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, 1, 0, 0,
+                                            nullptr, stream);
 }
 
+int swiftly_hip_finish_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
+                                     int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t subgrid_off,
+                                     int64_t subgrid_size, const void* mask, int64_t nbatch, int64_t in_bs,
+                                     int64_t out_bs, const int64_t* subgrid_offs, int64_t mask_bs, void* stream) {
+    CHECK_COMMON();
+    CHECK_BATCH();
+    CHECK_SUBGRID_SIZE();
+    Batch bt{nbatch, in_bs, out_bs, subgrid_offs, mask ? mask_bs : 0};
+    return DISPATCH(do_finish_subgrid, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, subgrid_size, mask,
+                    bt, (hipStream_t)stream);
+}
 int swiftly_hip_finish_subgrid(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
                                int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t subgrid_off,
                                int64_t subgrid_size, const void* mask, void* stream) {
-    CHECK_COMMON();
-    if (subgrid_size <= 0 || subgrid_size > h->xM)
-        return fail(SWIFTLY_ERR_PARAM, "subgrid size %lld must be in [1, xM_size = %lld]", (long long)subgrid_size,
-                    (long long)h->xM);
-    return DISPATCH(do_finish_subgrid, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, subgrid_size, mask,
-                    (hipStream_t)stream);
+    return swiftly_hip_finish_subgrid_batch(h, dtype, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off,
+                                            subgrid_size, mask, 1, 0, 0, nullptr, 0, stream);
 }
 
+int swiftly_hip_prepare_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t subgrid_size,
+                                      int64_t in_rs, int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs,
+                                      int64_t subgrid_off, int64_t nbatch, int64_t in_bs, int64_t out_bs,
+                                      const int64_t* subgrid_offs, void* stream) {
+    CHECK_COMMON();
+    CHECK_BATCH();
+    CHECK_SUBGRID_SIZE();
+    Batch bt{nbatch, in_bs, out_bs, subgrid_offs, 0};
+    return DISPATCH(do_prepare_subgrid, h, in, rows, subgrid_size, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, bt,
+                    (hipStream_t)stream);
+}
 int swiftly_hip_prepare_subgrid(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t subgrid_size,
                                 int64_t in_rs, int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs,
                                 int64_t subgrid_off, void* stream) {
-    CHECK_COMMON();
-    if (subgrid_size <= 0 || subgrid_size > h->xM)
-        return fail(SWIFTLY_ERR_PARAM, "subgrid size %lld must be in [1, xM_size = %lld]", (long long)subgrid_size,
-                    (long long)h->xM);
-    return DISPATCH(do_prepare_subgrid, h, in, rows, subgrid_size, in_rs, in_cs, out, out_rs, out_cs, subgrid_off,
-                    (hipStream_t)stream);
+    return swiftly_hip_prepare_subgrid_batch(h, dtype, in, rows, subgrid_size, in_rs, in_cs, out, out_rs, out_cs,
+                                             subgrid_off, 1, 0, 0, nullptr, stream);
 }
 
+int swiftly_hip_extract_from_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
+                                           int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs,
+                                           int64_t facet_off, int64_t nbatch, int64_t in_bs, int64_t out_bs,
+                                           const int64_t* facet_offs, void* stream) {
+    CHECK_COMMON();
+    CHECK_BATCH();
+    Batch bt{nbatch, in_bs, out_bs, facet_offs, 0};
+    return DISPATCH(do_extract_from_subgrid, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, bt,
+                    (hipStream_t)stream);
+}
 int swiftly_hip_extract_from_subgrid(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
                                      int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t facet_off,
                                      void* stream) {
-    CHECK_COMMON();
-    return DISPATCH(do_extract_from_subgrid, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off,
-                    (hipStream_t)stream);
+    return swiftly_hip_extract_from_subgrid_batch(h, dtype, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, 1,
+                                                  0, 0, nullptr, stream);
 }
 
+int swiftly_hip_add_to_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
+                                   int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t subgrid_off,
+                                   int64_t nbatch, int64_t in_bs, int64_t out_bs, const int64_t* subgrid_offs,
+                                   void* stream) {
+    CHECK_COMMON();
+    CHECK_BATCH();
+    Batch bt{nbatch, in_bs, out_bs, subgrid_offs, 0};
+    if (dtype == SWIFTLY_C64)
+        return run_modcopy<float, true>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, bt, (hipStream_t)stream);
+    return run_modcopy<double, true>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, bt, (hipStream_t)stream);
+}
 int swiftly_hip_add_to_facet(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs,
                              void* out, int64_t out_rs, int64_t out_cs, int64_t subgrid_off, void* stream) {
-    CHECK_COMMON();
-    if (dtype == SWIFTLY_C64)
-        return run_modcopy<float, true>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, (hipStream_t)stream);
-    return run_modcopy<double, true>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, (hipStream_t)stream);
+    return swiftly_hip_add_to_facet_batch(h, dtype, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, 1, 0, 0,
+                                          nullptr, stream);
 }
 
+int swiftly_hip_finish_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
+                                   int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t facet_off,
+                                   int64_t facet_size, const void* mask, int64_t nbatch, int64_t in_bs,
+                                   int64_t out_bs, const int64_t* facet_offs, int64_t mask_bs, void* stream) {
+    CHECK_COMMON();
+    CHECK_BATCH();
+    CHECK_FACET_SIZE();
+    Batch bt{nbatch, in_bs, out_bs, facet_offs, mask ? mask_bs : 0};
+    return DISPATCH(do_finish_facet, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, facet_size, mask, bt,
+                    (hipStream_t)stream);
+}
 int swiftly_hip_finish_facet(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs,
                              void* out, int64_t out_rs, int64_t out_cs, int64_t facet_off, int64_t facet_size,
                              const void* mask, void* stream) {
-    CHECK_COMMON();
-    if (facet_size <= 0 || facet_size >= h->yN)
-        return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1 = %lld]", (long long)facet_size,
-                    (long long)(h->yN - 1));
-    return DISPATCH(do_finish_facet, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, facet_size, mask,
-                    (hipStream_t)stream);
+    return swiftly_hip_finish_facet_batch(h, dtype, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, facet_size,
+                                          mask, 1, 0, 0, nullptr, 0, stream);
 }
 
 int swiftly_hip_malloc(void** ptr, size_t bytes) {

@@ -51,12 +51,30 @@ struct RowsArgs {
     const cx<R>* tw_full;  // exp(-2 pi i k / 2^full_logn) for the four-step twiddle, or null
     int tw_on_store;     // multiply output i by tw_full[(i * o) ...] (four-step inter-pass twiddle)
     int raw_ld, raw_st;  // bypass centred-shift + map on load / store (intermediate buffers)
+    // Optional modular input-row map (fuses a row gather such as
+    // extract_from_facet along the other axis into the load):
+    //   in_row = (rm_outer + ((row + rm_inner) mod rm_mod)) mod rm_full   when rm_mod > 0
+    int rm_mod, rm_inner, rm_outer, rm_full;
+    // Batch dimension (blockIdx.y): independent problems of identical shape at
+    // in + b*in_bs / out + b*out_bs; per-item map offsets come from OffTab,
+    // per-item store windows (masks) from st.win + b*st_win_bs.
+    long long in_bs, out_bs;
+    int nbatch;
+    long long st_win_bs;
+};
+
+// Per-batch-item overrides of the map offsets (passed by value as a kernel
+// argument; kMaxBatch items per launch).
+constexpr int kMaxBatch = 64;
+struct OffTab {
+    int use;  // bit 0: ld_a, bit 1: ld_c, bit 2: st_a, bit 3: st_c
+    int ld_a[kMaxBatch], ld_c[kMaxBatch], st_a[kMaxBatch], st_c[kMaxBatch];
 };
 
 template <class G, typename R>
-__global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A) {
+__global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, const OffTab tab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int N = G::N, P = G::P, T = G::T, RB = G::RB;
+    constexpr int P = G::P, T = G::T, RB = G::RB;
     const int tid = threadIdx.x;
     const bool rowfast = A.rowfast != 0;
     int t, rb;
@@ -74,8 +92,22 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A) {
     const int o = live ? (int)(grow / A.nrows) : 0;
     const long long row = live ? grow % A.nrows : 0;
     const int FN = 1 << A.full_logn;
-    const cx<R>* __restrict__ in = A.in + row * A.in_rs + (long long)o * A.in_os;
-    cx<R>* __restrict__ out = A.out + row * A.out_rs + (long long)o * A.out_os;
+    long long in_row = row;
+    if (A.rm_mod > 0) {
+        int r1 = (int)row + A.rm_inner;
+        if (r1 >= A.rm_mod) r1 -= A.rm_mod;
+        r1 += A.rm_outer;
+        if (r1 >= A.rm_full) r1 -= A.rm_full;
+        in_row = r1;
+    }
+    const int b = blockIdx.y;
+    const cx<R>* __restrict__ in = A.in + in_row * A.in_rs + (long long)o * A.in_os + (long long)b * A.in_bs;
+    cx<R>* __restrict__ out = A.out + row * A.out_rs + (long long)o * A.out_os + (long long)b * A.out_bs;
+    const int ld_a = (tab.use & 1) ? tab.ld_a[b] : A.ld.a;
+    const int ld_c = (tab.use & 2) ? tab.ld_c[b] : A.ld.c;
+    const int st_a = (tab.use & 4) ? tab.st_a[b] : A.st.a;
+    const int st_c = (tab.use & 8) ? tab.st_c[b] : A.st.c;
+    const R* __restrict__ st_win = A.st.win ? A.st.win + (long long)b * A.st_win_bs : nullptr;
     const R csign_ld = A.conj_ld ? (R)-1 : (R)1;
     const R csign_st = A.conj_st ? (R)-1 : (R)1;
 
@@ -91,9 +123,9 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A) {
             } else {
                 const int pi = i * A.ld_mul + ld_add;             // plain full-length index
                 const int ci = (pi + (FN >> 1)) & (FN - 1);       // centred index
-                const int q = (ci + A.ld.a) & (FN - 1);
+                const int q = (ci + ld_a) & (FN - 1);
                 if (q < A.ld.len) {
-                    int idx = q + A.ld.c;
+                    int idx = q + ld_c;
                     if (idx >= A.ld.mod) idx -= A.ld.mod;
                     val = in[(size_t)((unsigned)idx * A.in_cs)];
                     R w = (R)1;
@@ -130,12 +162,12 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A) {
         }
         const int pk = e * A.st_mul + st_add;
         const int ck = (pk + (FN >> 1)) & (FN - 1);
-        const int d = (ck + A.st.a) & (FN - 1);
+        const int d = (ck + st_a) & (FN - 1);
         if (d < A.st.len) {
-            int idx = d + A.st.c;
+            int idx = d + st_c;
             if (idx >= A.st.mod) idx -= A.st.mod;
             R w = (R)1;
-            if (A.st.win) w = A.st.win[d];
+            if (st_win) w = st_win[d];
             if (A.st.win2) w *= A.st.win2[d];
             v.x *= w;
             v.y *= w;
@@ -180,8 +212,8 @@ constexpr int kMaxLogNFloat = 15;
 constexpr int kMaxLogNDouble = 13;
 
 // implemented in fft_rows_f32.hip / fft_rows_f64.hip
-int launch_fft_rows(int logn, const RowsArgs<float>& a, hipStream_t s);
-int launch_fft_rows(int logn, const RowsArgs<double>& a, hipStream_t s);
+int launch_fft_rows(int logn, const RowsArgs<float>& a, const OffTab& tab, hipStream_t s);
+int launch_fft_rows(int logn, const RowsArgs<double>& a, const OffTab& tab, hipStream_t s);
 int init_fft_rows_f32();
 int init_fft_rows_f64();
 

@@ -52,6 +52,21 @@ def _declare(lib):
         fn = getattr(lib, "swiftly_hip_" + name)
         fn.restype = c_int
         fn.argtypes = args
+    pi64 = POINTER(i64)
+    batch = [i64, i64, i64, pi64]  # nbatch, in_bs, out_bs, offs
+    for name, args in [
+        ("extract_column", [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, vp]),
+        ("extract_from_facet_batch", plain[:-1] + batch + [vp]),
+        ("add_to_subgrid_batch", plain[:-1] + batch + [vp]),
+        ("finish_subgrid_batch", finish[:-1] + batch + [i64, vp]),
+        ("prepare_subgrid_batch", sized_in[:-1] + batch + [vp]),
+        ("extract_from_subgrid_batch", plain[:-1] + batch + [vp]),
+        ("add_to_facet_batch", plain[:-1] + batch + [vp]),
+        ("finish_facet_batch", finish[:-1] + batch + [i64, vp]),
+    ]:
+        fn = getattr(lib, "swiftly_hip_" + name)
+        fn.restype = c_int
+        fn.argtypes = args
     lib.swiftly_hip_malloc.restype = c_int
     lib.swiftly_hip_malloc.argtypes = [POINTER(vp), c_size_t]
     lib.swiftly_hip_free.restype = c_int

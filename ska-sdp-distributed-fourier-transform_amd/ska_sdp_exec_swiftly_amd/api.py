@@ -1,0 +1,449 @@
+"""
+Streaming API: ``SwiftlyConfig`` / ``SwiftlyForward`` / ``SwiftlyBackward``
+with the constructor signatures, method names and semantics of the reference
+(src/ska_sdp_exec_swiftly/api.py:107-463), executed on one MI355X per process
+instead of a Dask cluster.
+
+What changes relative to the reference, and why:
+
+* ``backend="hip"`` selects :class:`SwiftlyCoreHip` at the reference's own seam
+  (api.py:137-143); any other value raises ``ValueError("Unknown SwiFTly
+  backend")`` like the reference does.  No Dask client is needed
+  (``dask_client`` / ``client`` are accepted and ignored).
+* "Tasks" are device tensors: work is enqueued asynchronously on the current
+  HIP stream, so ``get_subgrid_task`` returns immediately with a tensor whose
+  contents are ready in stream order (the counterpart of a Dask future);
+  ``queue_size`` bounds how many finished subgrids stay referenced.
+* facets and all intermediates (``BF_F`` per facet, the per-``off0`` column
+  cache of ``lru_forward`` / ``lru_backward`` entries) live in HBM for the
+  whole run.
+* ``get_subgrid_tasks`` / ``add_new_subgrid_tasks`` (extensions) process a
+  whole subgrid column ("wave") per launch sequence; the single-subgrid
+  methods are the same code with a wave of one.
+"""
+import logging
+
+import numpy
+
+from .core_hip import SwiftlyCoreHip
+
+__all__ = [
+    "FacetConfig",
+    "SubgridConfig",
+    "SwiftlyConfig",
+    "SwiftlyForward",
+    "SwiftlyBackward",
+    "LRUCache",
+    "make_full_facet_cover",
+    "make_full_subgrid_cover",
+    "make_full_cover_config",
+    "make_mask_from_slice",
+]
+
+log = logging.getLogger("fourier-logger")
+
+
+def make_mask_from_slice(slice_list, mask_size):
+    """0/1 float vector that is 1 inside the given slices (reference
+    api_helper.py:243-253)."""
+    mask = numpy.zeros((mask_size,))
+    for piece in slice_list:
+        mask[piece] = 1
+    return mask
+
+
+class _ChunkConfig:
+    """Offsets, size and masks of one facet or subgrid (reference
+    api.py:39-104).  A mask may be an array, ``None`` or ``[[slices], size]``."""
+
+    def __init__(self, off0, off1, size, mask0=None, mask1=None):
+        self.off0 = off0
+        self.off1 = off1
+        self.size = size
+        self._mask0 = mask0
+        self._mask1 = mask1
+
+    @staticmethod
+    def _expand(mask):
+        if isinstance(mask, list):
+            return make_mask_from_slice(mask[0], mask[1])
+        return mask
+
+    @property
+    def mask0(self):
+        """mask along axis 0"""
+        return self._expand(self._mask0)
+
+    @property
+    def mask1(self):
+        """mask along axis 1"""
+        return self._expand(self._mask1)
+
+
+class FacetConfig(_ChunkConfig):
+    """Facet configuration (reference api.py:39-70)"""
+
+
+class SubgridConfig(_ChunkConfig):
+    """Subgrid configuration (reference api.py:73-104)"""
+
+
+def make_full_cover_config(N, chunk_size, class_name):
+    """Cover the N x N plane with ``chunk_size`` pieces at multiples of
+    ``chunk_size``; where neighbours overlap (also across the wrap-around) the
+    masks hand each pixel to exactly one piece by cutting half way between the
+    two offsets (reference api_helper.py:213-240)."""
+    count = -(-N // chunk_size)
+    offsets = [chunk_size * i for i in range(count)]
+    cuts = [(offsets[i] + (offsets[i + 1] if i + 1 < count else N + offsets[0])) // 2 for i in range(count)]
+    spans = []
+    for i, off in enumerate(offsets):
+        lo = (cuts[i - 1] - off + chunk_size // 2) % N
+        hi = cuts[i] - off + chunk_size // 2
+        spans.append((lo, hi))
+    return [
+        class_name(o0, o1, chunk_size, [[slice(*spans[i0])], chunk_size], [[slice(*spans[i1])], chunk_size])
+        for i0, o0 in enumerate(offsets)
+        for i1, o1 in enumerate(offsets)
+    ]
+
+
+def make_full_subgrid_cover(swiftlyconfig):
+    """Subgrid configs covering the whole grid (reference api.py:593-601)"""
+    return make_full_cover_config(swiftlyconfig.image_size, swiftlyconfig.max_subgrid_size, SubgridConfig)
+
+
+def make_full_facet_cover(swiftlyconfig):
+    """Facet configs covering the whole image (reference api.py:604-612)"""
+    return make_full_cover_config(swiftlyconfig.image_size, swiftlyconfig.max_facet_size, FacetConfig)
+
+
+class SwiftlyConfig:
+    """SwiFTly parameters + the core that implements them (reference
+    api.py:107-214)."""
+
+    # pylint: disable=too-many-arguments,too-many-instance-attributes
+    def __init__(
+        self, W, fov, N, yB_size, yN_size, xA_size, xM_size, dask_client=None, backend="hip", **_other_args
+    ):
+        self._W = W
+        self._fov = fov
+        self._N = N
+        self._yB_size = yB_size
+        self._yN_size = yN_size
+        self._xA_size = xA_size
+        self._xM_size = xM_size
+        self.dask_client = dask_client  # unused: there is no Dask in this backend
+        if backend == "hip":
+            self._core = SwiftlyCoreHip(W, N, xM_size, yN_size)
+        else:
+            raise ValueError(f"Unknown SwiFTly backend: {backend}")
+        # the reference wraps a scattered core in dask.delayed (api.py:145-147)
+        self.core_task = self._core
+
+    @property
+    def core(self):
+        """the SwiftlyCoreHip instance"""
+        return self._core
+
+    @property
+    def image_size(self):
+        """Size of the entire (virtual) image in pixels"""
+        return self._N
+
+    @property
+    def max_facet_size(self):
+        """Maximum size of a facet in pixels"""
+        return self._yB_size
+
+    @property
+    def max_subgrid_size(self):
+        """Maximum size of a subgrid in pixels"""
+        return self._xA_size
+
+    @property
+    def pswf_parameter(self):
+        """PSWF window parameter W"""
+        return self._W
+
+    @property
+    def internal_facet_size(self):
+        """Padded facet size used internally"""
+        return self._yN_size
+
+    @property
+    def internal_subgrid_size(self):
+        """Padded subgrid size used internally"""
+        return self._xM_size
+
+    @property
+    def facet_off_step(self):
+        """All facet offsets must be divisible by this"""
+        return self._core.facet_off_step
+
+    @property
+    def subgrid_off_step(self):
+        """All subgrid offsets must be divisible by this"""
+        return self._core.subgrid_off_step
+
+
+class LRUCache:
+    """Least-recently-used cache with the interface of reference
+    api.py:525-590: ``get`` refreshes, ``set`` returns the evicted
+    ``(key, value)`` or ``(None, None)``, ``pop_all`` drains oldest first."""
+
+    def __init__(self, cache_size):
+        self.cache_size = cache_size
+        self._items = {}  # insertion order == recency order
+
+    def get(self, key):
+        """value or None; marks the key most recently used"""
+        if key not in self._items:
+            return None
+        val = self._items.pop(key)
+        self._items[key] = val
+        return val
+
+    def set(self, key, value):
+        """insert / refresh; returns evicted (key, value) or (None, None)"""
+        self._items.pop(key, None)
+        self._items[key] = value
+        if len(self._items) <= self.cache_size:
+            return None, None
+        old_key = next(iter(self._items))
+        return old_key, self._items.pop(old_key)
+
+    def pop_all(self):
+        """yield and remove all entries, least recently used first"""
+        while self._items:
+            old_key = next(iter(self._items))
+            yield old_key, self._items.pop(old_key)
+
+
+def _torch():
+    import torch  # pylint: disable=import-outside-toplevel
+
+    return torch
+
+
+def _mask_table(core, configs, which, size, cdtype):
+    """[len(configs), size] real device table of the masks (ones where a config
+    has no mask), or None when no config has one."""
+    torch = _torch()
+    masks = [getattr(c, which) for c in configs]
+    if all(m is None for m in masks):
+        return None
+    rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
+    tab = numpy.ones((len(configs), size))
+    for i, m in enumerate(masks):
+        if m is not None:
+            tab[i] = numpy.asarray(m, dtype=float)
+    return torch.from_numpy(tab).to(device=core.device, dtype=rdtype).contiguous()
+
+
+class SwiftlyForward:
+    """Facet -> subgrid streaming transform (reference api.py:217-324).
+
+    :param swiftly_config: SwiftlyConfig
+    :param facet_tasks: list of ``(FacetConfig, facet_data)``; data may be a
+        numpy array or a torch tensor (complex64 or complex128; it is uploaded
+        once and stays in HBM)
+    :param lru_forward: number of subgrid columns (distinct ``off0``) whose
+        prepared facet columns ``NMBF_BF`` are kept
+    :param queue_size: kept for signature compatibility (bounds in-flight
+        subgrid tasks in the reference; here the HIP stream is the queue)
+    """
+
+    # pylint: disable=too-many-arguments,too-many-instance-attributes
+    def __init__(self, swiftly_config, facet_tasks, lru_forward=1, queue_size=20, client=None):
+        self.config = swiftly_config
+        self.core = swiftly_config.core
+        self.facet_tasks = facet_tasks
+        self.facet_configs = [cfg for cfg, _ in facet_tasks]
+        self.queue_size = queue_size
+        self._client = client
+        self.lru = LRUCache(lru_forward)
+        self.BF_Fs_persist = None
+        torch = _torch()
+        self._facets = []
+        for _, data in facet_tasks:
+            ten, _ = self.core._as_device(data)  # pylint: disable=protected-access
+            self._facets.append(ten)
+        dtypes = {t.dtype for t in self._facets}
+        if len(dtypes) > 1:
+            raise ValueError("all facets must have the same dtype")
+        self.dtype = dtypes.pop() if dtypes else torch.complex64
+        # facets grouped by off1 (api_helper.py:83): axis-0 sums are shared
+        self._groups = sorted({cfg.off1 for cfg in self.facet_configs})
+        self._group_of = [self._groups.index(cfg.off1) for cfg in self.facet_configs]
+
+    # -- stage 1: BF_F = prepare_facet(axis 0), once per facet (api.py:281-298)
+    def _get_BF_Fs(self):
+        if self.BF_Fs_persist is None:
+            self.BF_Fs_persist = [
+                self.core.prepare_facet(data, cfg.off0, axis=0)
+                for cfg, data in zip(self.facet_configs, self._facets)
+            ]
+        return self.BF_Fs_persist
+
+    # -- stage 2: per subgrid column (api.py:300-324)
+    def get_NMBF_BFs_off0(self, off0, BF_Fs=None):
+        """prepared facet columns for subgrid column ``off0`` (LRU cached)"""
+        if BF_Fs is None:
+            BF_Fs = self._get_BF_Fs()
+        cols = self.lru.get(off0)
+        if cols is None:
+            cols = [
+                self.core.extract_column(BF_F, off0, cfg.off1)
+                for cfg, BF_F in zip(self.facet_configs, BF_Fs)
+            ]
+            self.lru.set(off0, cols)
+        return cols
+
+    # -- stage 3: per subgrid (api.py:255-279 + api_helper.py:73-112)
+    def get_subgrid_task(self, subgrid_config):
+        """Finished (masked) subgrid ``[size, size]`` as a device tensor
+        (reference api.py:238-253)."""
+        return self.get_subgrid_tasks([subgrid_config])[0]
+
+    def get_subgrid_tasks(self, subgrid_configs):
+        """Finished subgrids for a list of configs; consecutive configs with the
+        same ``off0`` and ``size`` are processed as one wave."""
+        out = []
+        i = 0
+        while i < len(subgrid_configs):
+            j = i + 1
+            while (
+                j < len(subgrid_configs)
+                and subgrid_configs[j].off0 == subgrid_configs[i].off0
+                and subgrid_configs[j].size == subgrid_configs[i].size
+            ):
+                j += 1
+            res = self._wave(subgrid_configs[i:j])
+            out.extend(res[k] for k in range(j - i))
+            i = j
+        return out
+
+    def _wave(self, sgs):
+        torch = _torch()
+        core = self.core
+        m, xM, yN = core.xM_yN_size, core.xM_size, core.yN_size
+        off0, xA, S = sgs[0].off0, sgs[0].size, len(sgs)
+        F, G = len(self.facet_configs), len(self._groups)
+        cols = self.get_NMBF_BFs_off0(off0)
+        dev, dt = core.device, self.dtype
+        off1s = [sg.off1 for sg in sgs]
+        # K3: contributions [F, S, m, m] = extract_from_facet(axis 1)
+        contrib = torch.empty((F, S, m, m), dtype=dt, device=dev)
+        for j in range(F):
+            core.launch("extract_from_facet", cols[j], m, yN, 1, contrib[j], m, 1,
+                        nbatch=S, in_bs=0, out_bs=m * m, offs=off1s)
+        # K4a: axis-0 transform + placement, summed over the facets of one off1 group
+        colacc = torch.zeros((G, S, xM, m), dtype=dt, device=dev)
+        for j, cfg in enumerate(self.facet_configs):
+            core.launch("add_to_subgrid", contrib[j], m, 1, m, colacc[self._group_of[j]], 1, m, cfg.off0,
+                        nbatch=S, in_bs=m * m, out_bs=xM * m)
+        # K4b: axis-1 transform + placement, summed over groups
+        acc = torch.zeros((S, xM, xM), dtype=dt, device=dev)
+        for g, off1 in enumerate(self._groups):
+            core.launch("add_to_subgrid", colacc[g], xM, m, 1, acc, xM, 1, off1,
+                        nbatch=S, in_bs=xM * m, out_bs=xM * xM)
+        # K5: finish axis 1 (per-subgrid off1, mask1), then axis 0 (mask0)
+        mask1 = _mask_table(core, sgs, "mask1", xA, dt)
+        mask0 = _mask_table(core, sgs, "mask0", xA, dt)
+        tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
+        core.launch("finish_subgrid", acc, xM, xM, 1, tmp, xA, 1, 0, size=xA, mask=mask1,
+                    nbatch=S, in_bs=xM * xM, out_bs=xM * xA, offs=off1s, mask_bs=xA if mask1 is not None else 0)
+        res = torch.empty((S, xA, xA), dtype=dt, device=dev)
+        core.launch("finish_subgrid", tmp, xA, 1, xA, res, 1, xA, off0, size=xA, mask=mask0,
+                    nbatch=S, in_bs=xM * xA, out_bs=xA * xA, mask_bs=xA if mask0 is not None else 0)
+        return res
+
+
+class SwiftlyBackward:
+    """Subgrid -> facet streaming transform (reference api.py:327-463).
+
+    :param swiftly_config: SwiftlyConfig
+    :param facets_config_list: list of FacetConfig
+    :param lru_backward: number of subgrid columns (distinct ``off0``) whose
+        partial sums ``NAF_MNAF [m, yN]`` per facet stay in HBM before they are
+        folded into the facet accumulators
+    """
+
+    # pylint: disable=too-many-arguments,too-many-instance-attributes
+    def __init__(self, swiftly_config, facets_config_list, lru_backward=1, queue_size=20, client=None):
+        self.config = swiftly_config
+        self.core = swiftly_config.core
+        self.facets_config_list = facets_config_list
+        self.queue_size = queue_size
+        self._client = client
+        self.lru = LRUCache(lru_backward)
+        self.MNAF_BMNAFs_persist = [None for _ in facets_config_list]
+        self.dtype = None
+        self._off0s = sorted({cfg.off0 for cfg in facets_config_list})
+        self._off0_of = [self._off0s.index(cfg.off0) for cfg in facets_config_list]
+
+    def add_new_subgrid_task(self, subgrid_config, new_subgrid_task):
+        """Fold one subgrid into the facet sums (reference api.py:347-372)."""
+        torch = _torch()
+        core = self.core
+        m, xM, yN = core.xM_yN_size, core.xM_size, core.yN_size
+        F = len(self.facets_config_list)
+        sub, _ = core._as_device(new_subgrid_task)  # pylint: disable=protected-access
+        if self.dtype is None:
+            self.dtype = sub.dtype
+        elif sub.dtype != self.dtype:
+            sub = sub.to(self.dtype)
+        dev, dt = core.device, self.dtype
+        off0, off1 = subgrid_config.off0, subgrid_config.off1
+        # prepare_and_split_subgrid (api_helper.py:115-139)
+        prepared = core.prepare_subgrid(sub, [off0, off1])
+        D = len(self._off0s)
+        e0 = torch.empty((D, m, xM), dtype=dt, device=dev)
+        core.launch("extract_from_subgrid", prepared, xM, 1, xM, e0, 1, xM,
+                    nbatch=D, in_bs=0, out_bs=m * xM, offs=self._off0s)
+        parts = torch.empty((F, m, m), dtype=dt, device=dev)
+        for j, cfg in enumerate(self.facets_config_list):
+            core.launch("extract_from_subgrid", e0[self._off0_of[j]], m, xM, 1, parts[j], m, 1, cfg.off1)
+        # accumulate_column (api_helper.py:142-152), column cache keyed by off0 (api.py:402-438)
+        col = self.lru.get(off0)
+        if col is None:
+            col = torch.zeros((F, m, yN), dtype=dt, device=dev)
+        core.launch("add_to_facet", parts, m, m, 1, col, yN, 1, off1, nbatch=F, in_bs=m * m, out_bs=m * yN)
+        old_off0, old_col = self.lru.set(off0, col)
+        if old_off0 is not None and old_col is not None:
+            self.update_MNAF_BMNAFs(old_off0, old_col)
+        return col
+
+    def update_MNAF_BMNAFs(self, off0, NAF_MNAFs):
+        """accumulate_facet for every facet (reference api.py:440-463,
+        api_helper.py:155-179): finish axis 1 (+mask1), add along axis 0."""
+        torch = _torch()
+        core = self.core
+        m, yN = core.xM_yN_size, core.yN_size
+        dev, dt = core.device, self.dtype
+        for j, cfg in enumerate(self.facets_config_list):
+            yB = cfg.size
+            t = core.finish_facet(NAF_MNAFs[j], cfg.off1, yB, axis=1, mask=cfg.mask1)
+            if self.MNAF_BMNAFs_persist[j] is None:
+                self.MNAF_BMNAFs_persist[j] = torch.zeros((yN, yB), dtype=dt, device=dev)
+            core.launch("add_to_facet", t, yB, 1, yB, self.MNAF_BMNAFs_persist[j], 1, yB, off0)
+        return self.MNAF_BMNAFs_persist
+
+    def finish(self):
+        """Flush the column cache and finish all facets (reference
+        api.py:374-400, api_helper.py:182-197).  A facet that never received a
+        contribution is all zeros (the reference raises AttributeError there,
+        api_helper.py:184-187)."""
+        torch = _torch()
+        core = self.core
+        for old_off0, old_col in self.lru.pop_all():
+            self.update_MNAF_BMNAFs(old_off0, old_col)
+        out = []
+        for cfg, acc in zip(self.facets_config_list, self.MNAF_BMNAFs_persist):
+            if acc is None:
+                dt = self.dtype or torch.complex64
+                out.append(torch.zeros((cfg.size, cfg.size), dtype=dt, device=core.device))
+            else:
+                out.append(core.finish_facet(acc, cfg.off0, cfg.size, axis=0, mask=cfg.mask0))
+        return out

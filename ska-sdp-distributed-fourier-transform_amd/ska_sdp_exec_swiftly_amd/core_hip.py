@@ -262,6 +262,57 @@ class SwiftlyCoreHip:
             return o_t.cpu().numpy()
         return o_t
 
+
+    # ------------------------------------------------------------------ raw batched launches
+    def launch(
+        self, fname, src, rows, in_rs, in_cs, dst, out_rs, out_cs, off=0, *, size=None, mask=None,
+        nbatch=1, in_bs=0, out_bs=0, offs=None, mask_bs=0,
+    ):
+        """Enqueue one (batched) primitive on device tensors -- the zero-copy
+        path of the streaming classes.  ``fname`` is the ABI entry point without
+        the ``swiftly_hip_`` prefix and ``_batch`` suffix; strides are in
+        complex elements; ``offs`` is a sequence of per-item offsets or None.
+        See include/swiftly_hip.h for the batch contract."""
+        cvp = ctypes.c_void_p
+        args = [self._handle, self._code(src), cvp(src.data_ptr()), int(rows)]
+        if fname == "prepare_subgrid":
+            args.append(int(size))
+        args += [int(in_rs), int(in_cs), cvp(dst.data_ptr()), int(out_rs), int(out_cs), int(off)]
+        if fname in ("finish_subgrid", "finish_facet"):
+            args += [int(size), cvp(mask.data_ptr()) if mask is not None else None]
+        offs_arr = None
+        if offs is not None:
+            offs_arr = (ctypes.c_int64 * int(nbatch))(*[int(o) for o in offs])
+        args += [int(nbatch), int(in_bs), int(out_bs), offs_arr]
+        if fname in ("finish_subgrid", "finish_facet"):
+            args.append(int(mask_bs))
+        args.append(self._stream())
+        _lib.check(getattr(self._lib, f"swiftly_hip_{fname}_batch")(*args))
+
+    def extract_column(self, BF_F, subgrid_off0, facet_off1, out=None):
+        """``prepare_facet(extract_from_facet(BF_F, subgrid_off0, axis=0),
+        facet_off1, axis=1)`` (reference api_helper.py:200-210) as one kernel on
+        a device tensor ``BF_F[yN_size, facet_size]`` -> ``[xM_yN_size,
+        yN_size]``."""
+        torch = _torch()
+        if not isinstance(BF_F, torch.Tensor):
+            res = self.extract_column(self._as_device(BF_F)[0], subgrid_off0, facet_off1)
+            return res.cpu().numpy()
+        if BF_F.dim() != 2 or BF_F.shape[0] != self.yN_size:
+            raise ValueError(f"BF_F must have shape [{self.yN_size}, facet_size], got {tuple(BF_F.shape)}")
+        if out is None:
+            out = torch.empty((self.xM_yN_size, self.yN_size), dtype=BF_F.dtype, device=self._device)
+        elif tuple(out.shape) != (self.xM_yN_size, self.yN_size):
+            raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(self.xM_yN_size, self.yN_size)}!")
+        _lib.check(
+            self._lib.swiftly_hip_extract_column(
+                self._handle, self._code(BF_F), ctypes.c_void_p(BF_F.data_ptr()), int(BF_F.shape[1]),
+                BF_F.stride(0), BF_F.stride(1), ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1),
+                int(subgrid_off0), int(facet_off1), self._stream(),
+            )
+        )
+        return out
+
     # ------------------------------------------------------------------ facet -> subgrid
     def prepare_facet(self, facet, facet_off, axis, out=None):
         """Window with 1/PSWF, zero-pad to ``yN_size``, shift by ``facet_off``

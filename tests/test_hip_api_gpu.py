@@ -1,0 +1,113 @@
+"""
+GPU tests of the streaming classes (SwiftlyConfig / SwiftlyForward /
+SwiftlyBackward with backend="hip") against
+  * the reference-generated round-trip golden (tests/golden/roundtrip2d.npz),
+  * the oracle's serial replica of the reference dataflow,
+  * the reference's own end-to-end check (tests/test_api.py:56-125: one point
+    source, per-facet RMSE < 3e-10 after facet -> subgrid -> facet), for the
+    same (lru_forward, lru_backward, shuffle) combinations.
+"""
+import os
+import random
+
+import numpy
+import pytest
+
+from oracle import swiftly_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TEST_PARAMS = dict(W=13.5625, fov=1.0, N=1024, yB_size=416, yN_size=512, xA_size=228, xM_size=256)
+SMALL_PARAMS = dict(W=13.5625, fov=1.0, N=512, yB_size=208, yN_size=256, xA_size=100, xM_size=128)
+
+
+def small_problem(dtype):
+    import ska_sdp_exec_swiftly_amd as sw
+
+    cfg = sw.SwiftlyConfig(backend="hip", **SMALL_PARAMS)
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    sg_cfgs = sw.make_full_subgrid_cover(cfg)
+    yB = SMALL_PARAMS["yB_size"]
+    facets = []
+    for j, f in enumerate(facet_cfgs):
+        r = numpy.random.default_rng(1234 + j)
+        d = (r.standard_normal((yB, yB)) + 1j * r.standard_normal((yB, yB))).astype(numpy.complex64)
+        facets.append((d * f.mask0[:, None] * f.mask1[None, :]).astype(dtype))
+    return sw, cfg, facet_cfgs, sg_cfgs, facets
+
+
+@pytest.mark.parametrize("dtype,tol", [(numpy.complex128, 1e-11), (numpy.complex64, 3e-6)])
+def test_forward_backward_golden(golden_dir, dtype, tol):
+    g = numpy.load(os.path.join(golden_dir, "roundtrip2d.npz"))
+    sw, cfg, facet_cfgs, sg_cfgs, facets = small_problem(dtype)
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), lru_forward=2)
+    sgs = fwd.get_subgrid_tasks(sg_cfgs)  # waves of 6
+    got = numpy.array([s.cpu().numpy() for s in sgs])
+    assert got.dtype == dtype
+    scale = numpy.abs(g["subgrids_full"]).max()
+    assert numpy.abs(got[:, ::7, ::5] - g["subgrids_sample"]).max() < tol * scale
+    assert numpy.abs(got[g["subgrid_full_idx"]] - g["subgrids_full"]).max() < tol * scale
+    # one at a time gives the same answer as waves
+    one = fwd.get_subgrid_task(sg_cfgs[17]).cpu().numpy()
+    assert numpy.array_equal(one, got[17])
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=2)
+    for sg_cfg, data in zip(sg_cfgs, sgs):
+        bwd.add_new_subgrid_task(sg_cfg, data)
+    out = numpy.array([f.cpu().numpy() for f in bwd.finish()])
+    fscale = numpy.abs(g["facets_out_full"]).max()
+    btol = tol * 30  # 1/pswf window amplifies (max ~4.9e3 for this W)
+    assert numpy.abs(out[:, ::9, ::7] - g["facets_out_sample"]).max() < btol * fscale
+    assert numpy.abs(out[g["facet_full_idx"]] - g["facets_out_full"]).max() < btol * fscale
+
+
+@pytest.mark.parametrize(
+    "lru_forward,lru_backward,shuffle",
+    [(1, 1, False), (2, 1, False), (1, 2, False), (1, 1, True), (2, 1, True), (1, 2, True)],
+)
+def test_swiftly_api_roundtrip(lru_forward, lru_backward, shuffle):
+    """reference tests/test_api.py:42-125 on the HIP backend (complex128)."""
+    import ska_sdp_exec_swiftly_amd as sw
+
+    sources = [(1, 1, 0)]
+    cfg = sw.SwiftlyConfig(backend="hip", **TEST_PARAMS)
+    sg_cfgs = sw.make_full_subgrid_cover(cfg)
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    facet_tasks = [(fc, sw.make_facet(cfg.image_size, fc, sources)) for fc in facet_cfgs]
+    fwd = sw.SwiftlyForward(cfg, facet_tasks, lru_forward, 100)
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward, 100)
+    if shuffle:
+        random.Random(42).shuffle(sg_cfgs)
+    for sg_cfg in sg_cfgs:
+        sg = fwd.get_subgrid_task(sg_cfg)
+        assert sw.check_subgrid(cfg.image_size, sg_cfg, sg, sources) < 1e-9
+        bwd.add_new_subgrid_task(sg_cfg, sg)
+    for fc, facet in zip(facet_cfgs, bwd.finish()):
+        assert sw.check_facet(cfg.image_size, fc, facet, sources) < 3e-10
+
+
+def test_forward_matches_oracle_c64_bench_shape():
+    """A slice of the N=8192 benchmark shape (BASELINE config 2 parameters:
+    W=11, yB=1408, yN=2048, xA=1024, xM=2048, m=512): 2 facets x one subgrid
+    column of 3, complex64, against the oracle.  Tolerance: relative RMSE
+    1e-6 (SURVEY section 8d, W~11 family)."""
+    import ska_sdp_exec_swiftly_amd as sw
+
+    P = dict(W=11.0, fov=1.0, N=8192, yB_size=1408, yN_size=2048, xA_size=1024, xM_size=2048)
+    cfg = sw.SwiftlyConfig(backend="hip", **P)
+    facet_cfgs = [c for c in sw.make_full_facet_cover(cfg) if c.off0 == 1408 and c.off1 in (0, 2816)]
+    sg_cfgs = [c for c in sw.make_full_subgrid_cover(cfg) if c.off0 == 2048][:3]
+    facets = []
+    for j, f in enumerate(facet_cfgs):
+        r = numpy.random.default_rng(77 + j)
+        d = (r.standard_normal((1408, 1408)) + 1j * r.standard_normal((1408, 1408))).astype(numpy.complex64)
+        facets.append(d * f.mask0[:, None].astype(numpy.float32) * f.mask1[None, :].astype(numpy.float32))
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)))
+    got = [s.cpu().numpy() for s in fwd.get_subgrid_tasks(sg_cfgs)]
+    ref = orc.OracleCore(P["W"], P["N"], P["xM_size"], P["yN_size"])
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    sitems = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in sg_cfgs]
+    want = orc.forward_all(ref, items, [f.astype(complex) for f in facets], sitems)
+    for a, b in zip(got, want):
+        assert a.dtype == numpy.complex64
+        rel = numpy.sqrt(numpy.mean(numpy.abs(a - b) ** 2) / numpy.mean(numpy.abs(b) ** 2))
+        assert rel < 1e-6, rel

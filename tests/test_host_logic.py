@@ -1,0 +1,119 @@
+"""CPU tests of the host-side logic of the product package (no GPU, no
+kernels): covers and masks, config classes, LRU cache, truth generators,
+catalogue -- each against the reference-generated goldens or the oracle."""
+import os
+
+import numpy
+import pytest
+
+from oracle import swiftly_oracle as orc
+from ska_sdp_exec_swiftly_amd import api, api_helper
+from ska_sdp_exec_swiftly_amd.core_hip import calculate_pswf
+from ska_sdp_exec_swiftly_amd.swift_configs import SWIFT_CONFIGS
+
+SMALL = dict(N=512, yB_size=208, xA_size=100)
+
+
+class Cfg:
+    image_size = SMALL["N"]
+    max_facet_size = SMALL["yB_size"]
+    max_subgrid_size = SMALL["xA_size"]
+
+
+def test_full_cover_matches_reference(golden_dir):
+    g = numpy.load(os.path.join(golden_dir, "roundtrip2d.npz"))
+    for maker, offs, m0, m1 in (
+        (api.make_full_facet_cover, g["facet_offs"], g["facet_mask0"], g["facet_mask1"]),
+        (api.make_full_subgrid_cover, g["sg_offs"], g["sg_mask0"], g["sg_mask1"]),
+    ):
+        cover = maker(Cfg)
+        assert numpy.array_equal(numpy.array([[c.off0, c.off1] for c in cover]), offs)
+        assert numpy.array_equal(numpy.array([c.mask0 for c in cover]), m0)
+        assert numpy.array_equal(numpy.array([c.mask1 for c in cover]), m1)
+    assert isinstance(api.make_full_facet_cover(Cfg)[0], api.FacetConfig)
+    assert isinstance(api.make_full_subgrid_cover(Cfg)[0], api.SubgridConfig)
+
+
+def test_cover_partitions_every_pixel():
+    for N, chunk in ((512, 208), (512, 100), (1024, 416), (1024, 228), (96, 32)):
+        cover = api.make_full_cover_config(N, chunk, api.FacetConfig)
+        hits = numpy.zeros(N)
+        for c in cover:
+            if c.off1 != 0:
+                continue
+            idx = (numpy.arange(chunk) - chunk // 2 + c.off0) % N
+            numpy.add.at(hits, idx, c.mask0)
+        assert numpy.array_equal(hits, numpy.ones(N))
+
+
+def test_config_mask_forms():
+    arr = numpy.array([0.0, 1.0, 1.0, 0.0])
+    c = api.SubgridConfig(3, 5, 4, arr, [[slice(1, 3)], 4])
+    assert c.mask0 is arr
+    assert numpy.array_equal(c.mask1, arr)
+    assert api.FacetConfig(0, 0, 4).mask0 is None
+    assert numpy.array_equal(api.make_mask_from_slice([slice(0, 1), slice(2, 4)], 5), [1, 0, 1, 1, 0])
+
+
+def test_lru_cache_semantics():
+    """interface of reference api.py:525-590"""
+    lru = api.LRUCache(2)
+    assert lru.get("a") is None
+    assert lru.set("a", 1) == (None, None)
+    assert lru.set("b", 2) == (None, None)
+    assert lru.get("a") == 1  # refreshes a
+    assert lru.set("c", 3) == ("b", 2)  # b is now the oldest
+    assert lru.set("a", 10) == (None, None)  # update in place
+    assert list(lru.pop_all()) == [("c", 3), ("a", 10)]
+    assert list(lru.pop_all()) == []
+
+
+def test_unknown_backend():
+    with pytest.raises(ValueError, match="Unknown SwiFTly backend"):
+        api.SwiftlyConfig(13.5625, 1.0, 1024, 416, 512, 228, 256, backend="numpy-ish")
+
+
+def test_truth_generators_match_oracle():
+    rng = numpy.random.default_rng(5)
+    N = 256
+    for dims in (1, 2):
+        srcs = [(float(rng.standard_normal()), *rng.integers(-N // 2, N // 2, dims).tolist()) for _ in range(6)]
+        for size, off in ((40, 0), (41, 17), (40, -300), (33, 250)):
+            offs = [off, -off + 4][:dims]
+            masks = [rng.integers(0, 2, size).astype(float) for _ in range(dims)]
+            a = api_helper.make_facet_from_sources(srcs, N, size, offs, masks)
+            b = orc.make_facet_from_sources(srcs, N, size, offs, masks)
+            assert numpy.array_equal(a, b)
+            a = api_helper.make_subgrid_from_sources(srcs, N, size, offs, masks)
+            b = orc.make_subgrid_from_sources(srcs, N, size, offs, masks)
+            assert numpy.allclose(a, b, rtol=0, atol=1e-15)
+
+
+def test_check_helpers():
+    cfg = api.FacetConfig(8, -4, 16, None, None)
+    srcs = [(1.0, 9, -3), (0.5, 2, 2)]
+    f = api_helper.make_facet(64, cfg, srcs)
+    assert f.sum() == 1.5
+    assert api_helper.check_facet(64, cfg, f, srcs) == 0
+    assert api_helper.check_residual(numpy.ones((4, 4))) == 1
+    sg_cfg = api.SubgridConfig(4, 6, 10)
+    sg = api_helper.make_subgrid(64, sg_cfg, srcs)
+    assert api_helper.check_subgrid(64, sg_cfg, sg, srcs) == 0
+
+
+def test_pswf_matches_reference(golden_dir):
+    g = numpy.load(os.path.join(golden_dir, "constants.npz"))
+    assert numpy.array_equal(calculate_pswf(13.5625, 512), g["test_pswf"])
+    assert numpy.array_equal(calculate_pswf(11.0, 2048), g["bench8k_pswf"])
+
+
+def test_catalogue():
+    assert len(SWIFT_CONFIGS) == 244
+    first = next(iter(SWIFT_CONFIGS))
+    assert first == "128k[1]-n32k-512"
+    c = SWIFT_CONFIGS["64k[1]-n32k-1k"]
+    assert (c["W"], c["N"], c["yB_size"], c["yN_size"], c["xA_size"], c["xM_size"]) == (10.875, 65536, 22528, 32768, 928, 1024)
+    for c in SWIFT_CONFIGS.values():
+        # the three divisibility rules of core.py:55-74 hold for every entry
+        assert c["N"] % c["yN_size"] == 0 and c["N"] % c["xM_size"] == 0
+        assert (c["xM_size"] * c["yN_size"]) % c["N"] == 0
