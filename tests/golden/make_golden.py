@@ -67,6 +67,7 @@ def import_reference():
 
 TEST_PARAMS = dict(W=13.5625, N=1024, yB_size=416, yN_size=512, xA_size=228, xM_size=256)
 SMALL_PARAMS = dict(W=13.5625, N=512, yB_size=208, yN_size=256, xA_size=100, xM_size=128)
+SMALL11_PARAMS = dict(W=11.0, N=512, yB_size=176, yN_size=256, xA_size=96, xM_size=128)
 BENCH8K_PARAMS = dict(W=11.0, N=8192, yB_size=1408, yN_size=2048, xA_size=1024, xM_size=2048)
 
 
@@ -80,7 +81,7 @@ def main():
 
     # ---------------------------------------------------------------- consts
     consts = {}
-    for name, p in [("test", TEST_PARAMS), ("small", SMALL_PARAMS), ("bench8k", BENCH8K_PARAMS)]:
+    for name, p in [("test", TEST_PARAMS), ("small", SMALL_PARAMS), ("small11", SMALL11_PARAMS), ("bench8k", BENCH8K_PARAMS)]:
         core = SwiftlyCore(p["W"], p["N"], p["xM_size"], p["yN_size"])
         pswf = core._calculate_pswf()
         consts[f"{name}_pswf"] = pswf
@@ -249,8 +250,64 @@ def main():
     rt["roundtrip_rmse"] = numpy.array(err)
     # store facets as seeds only (regenerated in the test); outputs c128
     numpy.savez_compressed(os.path.join(HERE, "roundtrip2d.npz"), **rt)
-    for f in ("constants.npz", "prim1d.npz", "prim2d.npz", "roundtrip2d.npz"):
+    make_roundtrip11(SwiftlyCore, helper, api)
+    for f in ("constants.npz", "prim1d.npz", "prim2d.npz", "roundtrip2d.npz", "roundtrip2d_w11.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+def make_roundtrip11(SwiftlyCore, helper, api):
+    """Forward + backward through the reference for the W=11 small parameter set
+    (max 1/pswf ~ 90, the regime the complex64 path is specified for)."""
+    p = SMALL11_PARAMS
+    N, yB, xA = p["N"], p["yB_size"], p["xA_size"]
+    core = SwiftlyCore(p["W"], N, p["xM_size"], p["yN_size"])
+
+    class Cfg:
+        image_size = N
+        max_facet_size = yB
+        max_subgrid_size = xA
+
+    facet_cfgs = api.make_full_facet_cover(Cfg)
+    sg_cfgs = api.make_full_subgrid_cover(Cfg)
+    facets = []
+    for j, f in enumerate(facet_cfgs):
+        r = numpy.random.default_rng(4321 + j)
+        g = (r.standard_normal((yB, yB)) + 1j * r.standard_normal((yB, yB))).astype(numpy.complex64).astype(complex)
+        facets.append(g * f.mask0[:, None] * f.mask1[None, :])
+    BF_Fs = [core.prepare_facet(d, f.off0, axis=0) for f, d in zip(facet_cfgs, facets)]
+    subgrids = []
+    cache = {}
+    for s in sg_cfgs:
+        if s.off0 not in cache:
+            cache = {s.off0: [helper.extract_column(core, BF, s.off0, f.off1) for f, BF in zip(facet_cfgs, BF_Fs)]}
+        contribs = [core.extract_from_facet(c, s.off1, axis=1) for c in cache[s.off0]]
+        subgrids.append(helper.sum_and_finish_subgrid(core, contribs, facet_cfgs, s))
+    F = len(facet_cfgs)
+    MN, cols, order = [None] * F, {}, []
+    for s, data in zip(sg_cfgs, subgrids):
+        parts = helper.prepare_and_split_subgrid(core, data, [s.off0, s.off1], facet_cfgs)
+        if s.off0 not in cols:
+            cols[s.off0] = [None] * F
+            order.append(s.off0)
+        cols[s.off0] = [helper.accumulate_column(core, pp, old, s.off1) for pp, old in zip(parts, cols[s.off0])]
+    for off0 in order:
+        MN = [helper.accumulate_facet(core, c, acc, f, off0) for f, c, acc in zip(facet_cfgs, cols[off0], MN)]
+    out_facets = numpy.array([helper.finish_facet(core, acc, f) for f, acc in zip(facet_cfgs, MN)])
+    sgs = numpy.array(subgrids)
+    err = max(numpy.sqrt(numpy.mean(numpy.abs(a - b) ** 2)) for a, b in zip(out_facets, facets))
+    print("reference round-trip RMSE (W=11 small params):", err)
+    numpy.savez_compressed(
+        os.path.join(HERE, "roundtrip2d_w11.npz"),
+        n_facets=numpy.array(F),
+        n_subgrids=numpy.array(len(sg_cfgs)),
+        subgrids_sample=sgs[:, ::5, ::3],
+        subgrid_full_idx=numpy.array([0, 7, 20]),
+        subgrids_full=sgs[[0, 7, 20]],
+        facets_out_sample=out_facets[:, ::9, ::7],
+        facet_full_idx=numpy.array([4]),
+        facets_out_full=out_facets[[4]],
+        roundtrip_rmse=numpy.array(err),
+    )
 
 
 if __name__ == "__main__":
