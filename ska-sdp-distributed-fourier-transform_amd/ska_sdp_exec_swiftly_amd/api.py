@@ -38,6 +38,7 @@ __all__ = [
     "make_full_subgrid_cover",
     "make_full_cover_config",
     "make_mask_from_slice",
+    "sum_and_finish_wave",
 ]
 
 log = logging.getLogger("fourier-logger")
@@ -273,9 +274,6 @@ class SwiftlyForward:
         if len(dtypes) > 1:
             raise ValueError("all facets must have the same dtype")
         self.dtype = dtypes.pop() if dtypes else torch.complex64
-        # facets grouped by off1 (api_helper.py:83): axis-0 sums are shared
-        self._groups = sorted({cfg.off1 for cfg in self.facet_configs})
-        self._group_of = [self._groups.index(cfg.off1) for cfg in self.facet_configs]
 
     # -- stage 1: BF_F = prepare_facet(axis 0), once per facet (api.py:281-298)
     def _get_BF_Fs(self):
@@ -324,40 +322,57 @@ class SwiftlyForward:
             i = j
         return out
 
-    def _wave(self, sgs):
+    def wave_contributions(self, sgs):
+        """Contributions of every (local) facet to the subgrids ``sgs`` (same
+        ``off0``): tensor ``[F, S, m, m]`` -- the data the reference ships
+        between Dask workers (api.py:263-277) and the multi-GPU path ships
+        through the all-to-all."""
         torch = _torch()
         core = self.core
-        m, xM, yN = core.xM_yN_size, core.xM_size, core.yN_size
-        off0, xA, S = sgs[0].off0, sgs[0].size, len(sgs)
-        F, G = len(self.facet_configs), len(self._groups)
-        cols = self.get_NMBF_BFs_off0(off0)
-        dev, dt = core.device, self.dtype
+        m, yN = core.xM_yN_size, core.yN_size
+        S, F = len(sgs), len(self.facet_configs)
+        cols = self.get_NMBF_BFs_off0(sgs[0].off0)
+        contrib = torch.empty((F, S, m, m), dtype=self.dtype, device=core.device)
         off1s = [sg.off1 for sg in sgs]
-        # K3: contributions [F, S, m, m] = extract_from_facet(axis 1)
-        contrib = torch.empty((F, S, m, m), dtype=dt, device=dev)
         for j in range(F):
             core.launch("extract_from_facet", cols[j], m, yN, 1, contrib[j], m, 1,
                         nbatch=S, in_bs=0, out_bs=m * m, offs=off1s)
-        # K4a: axis-0 transform + placement, summed over the facets of one off1 group
-        colacc = torch.zeros((G, S, xM, m), dtype=dt, device=dev)
-        for j, cfg in enumerate(self.facet_configs):
-            core.launch("add_to_subgrid", contrib[j], m, 1, m, colacc[self._group_of[j]], 1, m, cfg.off0,
-                        nbatch=S, in_bs=m * m, out_bs=xM * m)
-        # K4b: axis-1 transform + placement, summed over groups
-        acc = torch.zeros((S, xM, xM), dtype=dt, device=dev)
-        for g, off1 in enumerate(self._groups):
-            core.launch("add_to_subgrid", colacc[g], xM, m, 1, acc, xM, 1, off1,
-                        nbatch=S, in_bs=xM * m, out_bs=xM * xM)
-        # K5: finish axis 1 (per-subgrid off1, mask1), then axis 0 (mask0)
-        mask1 = _mask_table(core, sgs, "mask1", xA, dt)
-        mask0 = _mask_table(core, sgs, "mask0", xA, dt)
-        tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
-        core.launch("finish_subgrid", acc, xM, xM, 1, tmp, xA, 1, 0, size=xA, mask=mask1,
-                    nbatch=S, in_bs=xM * xM, out_bs=xM * xA, offs=off1s, mask_bs=xA if mask1 is not None else 0)
-        res = torch.empty((S, xA, xA), dtype=dt, device=dev)
-        core.launch("finish_subgrid", tmp, xA, 1, xA, res, 1, xA, off0, size=xA, mask=mask0,
-                    nbatch=S, in_bs=xM * xA, out_bs=xA * xA, mask_bs=xA if mask0 is not None else 0)
-        return res
+        return contrib
+
+    def _wave(self, sgs):
+        return sum_and_finish_wave(self.core, self.wave_contributions(sgs), self.facet_configs, sgs)
+
+
+def sum_and_finish_wave(core, contrib, facet_configs, sgs):
+    """``sum_and_finish_subgrid`` (reference api_helper.py:73-112) for a wave of
+    subgrids that share ``off0`` and ``size``: ``contrib[F, S, m, m]`` (facet
+    order = ``facet_configs``) -> finished, masked subgrids ``[S, xA, xA]``."""
+    torch = _torch()
+    m, xM = core.xM_yN_size, core.xM_size
+    off0, xA, S = sgs[0].off0, sgs[0].size, len(sgs)
+    dev, dt = core.device, contrib.dtype
+    groups = sorted({cfg.off1 for cfg in facet_configs})  # facets grouped by off1 (api_helper.py:83)
+    off1s = [sg.off1 for sg in sgs]
+    # K4a: axis-0 transform + placement, summed over the facets of one off1 group
+    colacc = torch.zeros((len(groups), S, xM, m), dtype=dt, device=dev)
+    for j, cfg in enumerate(facet_configs):
+        core.launch("add_to_subgrid", contrib[j], m, 1, m, colacc[groups.index(cfg.off1)], 1, m, cfg.off0,
+                    nbatch=S, in_bs=m * m, out_bs=xM * m)
+    # K4b: axis-1 transform + placement, summed over groups
+    acc = torch.zeros((S, xM, xM), dtype=dt, device=dev)
+    for g, off1 in enumerate(groups):
+        core.launch("add_to_subgrid", colacc[g], xM, m, 1, acc, xM, 1, off1,
+                    nbatch=S, in_bs=xM * m, out_bs=xM * xM)
+    # K5: finish axis 1 (per-subgrid off1, mask1), then axis 0 (mask0)
+    mask1 = _mask_table(core, sgs, "mask1", xA, dt)
+    mask0 = _mask_table(core, sgs, "mask0", xA, dt)
+    tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
+    core.launch("finish_subgrid", acc, xM, xM, 1, tmp, xA, 1, 0, size=xA, mask=mask1,
+                nbatch=S, in_bs=xM * xM, out_bs=xM * xA, offs=off1s, mask_bs=xA if mask1 is not None else 0)
+    res = torch.empty((S, xA, xA), dtype=dt, device=dev)
+    core.launch("finish_subgrid", tmp, xA, 1, xA, res, 1, xA, off0, size=xA, mask=mask0,
+                nbatch=S, in_bs=xM * xA, out_bs=xA * xA, mask_bs=xA if mask0 is not None else 0)
+    return res
 
 
 class SwiftlyBackward:
