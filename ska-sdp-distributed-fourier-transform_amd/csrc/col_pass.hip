@@ -1,0 +1,62 @@
+// instantiations + dispatch of the lean column-tile pass (complex64)
+#include "swiftly_colpass.h"
+
+namespace swf {
+
+template <int LOGN>
+struct CGeoFor {
+    static constexpr int LOGP = LOGN < 5 ? LOGN : 5;
+    // 256 rows x 64 columns x 8 B = 128 KiB: exchange re and im separately (64 KiB, 2 workgroups / CU)
+    using type = CGeo<LOGN, LOGP, (LOGN >= 8)>;
+};
+
+template <int LOGN, int MODE>
+static int launch_mode(const ColPassArgs& a, int outer, int nbatch, hipStream_t s) {
+    using G = typename CGeoFor<LOGN>::type;
+    dim3 grid((unsigned)((a.ncols + 63) / 64), (unsigned)outer, (unsigned)nbatch);
+    hipLaunchKernelGGL((col_pass_kernel<G, MODE>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
+                       a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full);
+    return (int)hipGetLastError();
+}
+template <int LOGN>
+static int launch_one(int mode, const ColPassArgs& a, int outer, int nbatch, hipStream_t s) {
+    if (mode == 0) return launch_mode<LOGN, 0>(a, outer, nbatch, s);
+    if (mode == 1) return launch_mode<LOGN, 1>(a, outer, nbatch, s);
+    return launch_mode<LOGN, 2>(a, outer, nbatch, s);
+}
+template <int LOGN, int MODE>
+static int init_mode() {
+    using G = typename CGeoFor<LOGN>::type;
+    if (G::LDS_BYTES == 0) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+}
+template <int LOGN>
+static int init_one() {
+    int rc = init_mode<LOGN, 0>();
+    if (!rc) rc = init_mode<LOGN, 1>();
+    if (!rc) rc = init_mode<LOGN, 2>();
+    return rc;
+}
+
+template <int LO, int HI>
+struct CDispatch {
+    static int launch(int logn, int mode, const ColPassArgs& a, int outer, int nbatch, hipStream_t s) {
+        if (logn == LO) return launch_one<LO>(mode, a, outer, nbatch, s);
+        if constexpr (LO < HI) return CDispatch<LO + 1, HI>::launch(logn, mode, a, outer, nbatch, s);
+        return -1;
+    }
+    static int init() {
+        int rc = init_one<LO>();
+        if (rc) return rc;
+        if constexpr (LO < HI) return CDispatch<LO + 1, HI>::init();
+        return 0;
+    }
+};
+
+int launch_col_pass(int logn, int mode, const ColPassArgs& a, int outer, int nbatch, hipStream_t s) {
+    return CDispatch<kColPassMinLog, kColPassMaxLog>::launch(logn, mode, a, outer, nbatch, s);
+}
+int init_col_pass() { return CDispatch<kColPassMinLog, kColPassMaxLog>::init(); }
+
+}  // namespace swf

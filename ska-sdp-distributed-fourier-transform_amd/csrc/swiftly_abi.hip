@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/swiftly_hip.h"
+#include "swiftly_colpass.h"
 #include "swiftly_rows.h"
 
 using namespace swf;
@@ -179,6 +180,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
     if (!g_inited) {
         if (int rc = init_fft_rows_f32()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (f32): %d", rc);
         if (int rc = init_fft_rows_f64()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (f64): %d", rc);
+        if (int rc = init_col_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (col pass): %d", rc);
         g_inited = true;
     }
     swiftly_hip* h = new (std::nothrow) swiftly_hip();
@@ -328,6 +330,85 @@ static int launch_checked(int logn, const RowsArgs<R>& a, const OffTab& tab, hip
     return 0;
 }
 
+// Lean path for complex64 transforms along the strided axis of row-major
+// arrays (columns contiguous): swiftly_colpass.h.  Returns false when the call
+// does not fit its constraints (the generic kernel handles it then).
+static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, const OffTab& tab, hipStream_t st,
+                         int* rc_out) {
+    if (!a.rowfast || a.in_rs != 1 || a.out_rs != 1 || tab.use != 0 || a.rm_mod > 0) return false;
+    const bool two = logn >= kTwoPassMinLog;
+    const int l1 = two ? logn / 2 : logn, l2 = logn - l1;
+    if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return false;
+    const uint64_t n = uint64_t(1) << logn, lim = uint64_t(1) << 32;
+    const uint64_t W = (uint64_t)a.nrows;
+    // all element offsets inside one batch item are 32 bit
+    if (n * (uint64_t)a.in_cs + W >= lim || n * (uint64_t)a.out_cs + W >= lim || n * W >= lim) return false;
+    const int nb = a.nbatch > 0 ? a.nbatch : 1;
+    ColPassArgs c;
+    std::memset(&c, 0, sizeof c);
+    c.ncols = a.nrows;
+    c.full_logn = logn;
+    c.in_bs = a.in_bs;
+    c.out_bs = a.out_bs;
+    c.ld_a = a.ld.a; c.ld_len = a.ld.len; c.ld_c = a.ld.c; c.ld_mod = a.ld.mod;
+    c.ld_win = a.ld.win; c.ld_win2 = a.ld.win2;
+    c.st_a = a.st.a; c.st_len = a.st.len; c.st_c = a.st.c; c.st_mod = a.st.mod;
+    c.st_win = a.st.win; c.st_win2 = a.st.win2; c.st_win_bs = a.st_win_bs;
+    c.st_rowmap = nullptr;
+    c.scale = a.scale;
+    c.conj_ld = a.conj_ld; c.conj_st = a.conj_st; c.accumulate = a.accumulate;
+    c.ld_mul = c.st_mul = 1;
+    auto launch = [&](int lg, int mode, const ColPassArgs& args, int outer) -> int {
+        int e = launch_col_pass(lg, mode, args, outer, nb, st);
+        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        return 0;
+    };
+    if (!two) {
+        c.in = a.in; c.out = a.out;
+        c.in_pitch = a.in_cs; c.out_pitch = a.out_cs;
+        c.tw = twiddles<float>(h, logn);
+        if (!c.tw) return false;
+        *rc_out = launch(logn, 2, c, 1);
+        return true;
+    }
+    const int n1 = 1 << l1, n2 = 1 << l2;
+    const cx<float>* tw1 = twiddles<float>(h, l1);
+    const cx<float>* tw2 = twiddles<float>(h, l2);
+    const cx<float>* twf = twiddles<float>(h, logn);
+    if (!tw1 || !tw2 || !twf) return false;
+    void* scratch = nullptr;
+    hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * W * sizeof(cx<float>), st);
+    if (he != hipSuccess) {
+        *rc_out = fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
+        return true;
+    }
+    // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
+    ColPassArgs A = c;
+    A.in = a.in; A.in_pitch = a.in_cs;
+    A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)W; A.out_bs = (long long)(n * W);
+    A.ld_mul = n2;
+    A.out_i_rows = n2; A.out_o_rows = 1;
+    A.tw = tw1; A.tw_full = twf;
+    A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
+    int rc = launch(l1, 0, A, n2);
+    if (!rc) {
+        // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
+        ColPassArgs B = c;
+        B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)W; B.in_bs = (long long)(n * W);
+        B.in_i_rows = 1; B.in_o_rows = n2;
+        B.out = a.out; B.out_pitch = a.out_cs;
+        B.st_mul = n1;
+        B.tw = tw2; B.tw_full = twf;
+        B.conj_ld = 0;
+        rc = launch(l2, 1, B, n1);
+    }
+    he = hipFreeAsync(scratch, st);
+    if (!rc && he != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(he));
+    *rc_out = rc;
+    return true;
+}
+
+
 // Launch the mapped row FFT for `a` (batch of a.nbatch <= kMaxBatch items with
 // per-item offsets in `tab`).  Transforms of length >= 2^kTwoPassMinLog along
 // a strided axis are decomposed (four-step) through a stream-ordered scratch.
@@ -343,6 +424,10 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     a.tw_full = nullptr;
     a.tw_on_store = 0;
     a.raw_ld = a.raw_st = 0;
+    if constexpr (std::is_same<R, float>::value) {
+        int rc = 0;
+        if (try_col_pass(h, logn, a, tab, st, &rc)) return rc;
+    }
     if (!(a.rowfast && logn >= kTwoPassMinLog)) return launch_checked(logn, a, tab, st);
 
     // ---- four-step: N = n1 * n2, input index y = y1*n2 + y2, output index k = k1 + n1*k2
