@@ -6,8 +6,10 @@ namespace swf {
 template <int LOGN>
 struct CGeoFor {
     static constexpr int LOGP = LOGN < 5 ? LOGN : 5;
-    // 256 rows x 64 columns x 8 B = 128 KiB: exchange re and im separately (64 KiB, 2 workgroups / CU)
-    using type = CGeo<LOGN, LOGP, (LOGN >= 8)>;
+    // exchange re and im separately from 128 rows on: 32 KiB (n = 128) / 64 KiB (n = 256) of LDS per
+    // workgroup keep 16 waves per CU resident, which is what hides the HBM latency (measured:
+    // 8 waves/CU -> 84 % of wave cycles waiting, 2.2 TB/s; 16 waves/CU -> 4.7 TB/s)
+    using type = CGeo<LOGN, LOGP, (LOGN >= 7)>;
 };
 
 template <int LOGN, int MODE>

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -337,7 +338,8 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
                          int* rc_out) {
     if (!a.rowfast || a.in_rs != 1 || a.out_rs != 1 || tab.use != 0 || a.rm_mod > 0) return false;
     const bool two = logn >= kTwoPassMinLog;
-    const int l1 = two ? logn / 2 : logn, l2 = logn - l1;
+    static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
+    const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
     if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return false;
     const uint64_t n = uint64_t(1) << logn, lim = uint64_t(1) << 32;
     const uint64_t W = (uint64_t)a.nrows;

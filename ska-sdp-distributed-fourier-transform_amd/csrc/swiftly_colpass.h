@@ -53,15 +53,22 @@ struct CGeo {
     static constexpr int ELEM = SPLIT ? 4 : 8;
     static constexpr int PITCH = 0;  // unused (interleaved-rows layout)
     static constexpr size_t LDS_BYTES = T > 1 ? (size_t)N * RB * ELEM : 0;
+    // minimum waves per SIMD the register allocator must leave room for
+    static constexpr int MINW = T >= 4 ? 4 : 1;
 };
 
 // MODE: 0 = pass A (mapped load, four-step twiddle, raw store to scratch)
 //       1 = pass B (raw load from scratch, mapped store)
 //       2 = single pass (mapped load, mapped store)
-// The read-only tables are separate __restrict__ parameters so that their
-// wave-uniform loads become scalar loads.
+//
+// Row bookkeeping is done LANE-PARALLEL once per wave: lane v works out
+// source row / validity / window of the wave's v-th input row, lane s the
+// destination row / window / four-step twiddle of its s-th output row (one
+// coalesced vector load per table instead of P dependent scalar loads), and
+// the main loops fetch the values with v_readlane.  The output-side
+// bookkeeping is issued before the butterflies so its latency hides under them.
 template <class G, int MODE>
-__global__ __launch_bounds__(G::NT) void col_pass_kernel(const ColPassArgs A, const cx<float>* __restrict__ gin,
+__global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassArgs A, const cx<float>* __restrict__ gin,
                                                          cx<float>* __restrict__ gout,
                                                          const float* __restrict__ ld_win,
                                                          const float* __restrict__ ld_win2,
@@ -72,19 +79,13 @@ __global__ __launch_bounds__(G::NT) void col_pass_kernel(const ColPassArgs A, co
                                                          const cx<float>* __restrict__ tw_full) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = G::P, T = G::T;
+    static_assert(P <= 64, "one lane per row slot");
     constexpr bool RAW_LD = MODE == 1, RAW_ST = MODE == 0;
-    // Views of the read-only tables in the constant address space: their loads
-    // are invariant, so wave-uniform indices turn into scalar (SMEM) loads.
-    typedef const float __attribute__((address_space(4))) * cfp;
-    typedef const int __attribute__((address_space(4))) * cip;
-    typedef const cx<float> __attribute__((address_space(4))) * ccp;
-    const cfp c_ld_win = (cfp)(uintptr_t)ld_win, c_ld_win2 = (cfp)(uintptr_t)ld_win2;
-    const cfp c_st_win = (cfp)(uintptr_t)(st_win ? st_win + (long long)blockIdx.z * A.st_win_bs : st_win);
-    const cfp c_st_win2 = (cfp)(uintptr_t)st_win2;
-    const cip c_rowmap = (cip)(uintptr_t)st_rowmap;
-    const ccp c_twf = (ccp)(uintptr_t)tw_full;
+    // last Stockham phase: radix 2^LR at stride 2^LNS  (phases are LOGP, LOGP, ..., remainder)
+    constexpr int LR = G::LOGN <= G::LOGP ? G::LOGN : (G::LOGN % G::LOGP == 0 ? G::LOGP : G::LOGN % G::LOGP);
+    constexpr int LNS = G::LOGN - LR;
     const int lane = threadIdx.x & 63;
-    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform
+    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id
     const int o = blockIdx.y;
     const int col = blockIdx.x * 64 + lane;
     const bool live = col < A.ncols;
@@ -93,72 +94,103 @@ __global__ __launch_bounds__(G::NT) void col_pass_kernel(const ColPassArgs A, co
     cx<float>* __restrict__ out = gout + (long long)blockIdx.z * A.out_bs + col;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
+    const int slot = lane & (P - 1);
 
-    cx<float> x[P];
-    static_for<0, P>([&](auto vI) {
-        constexpr int v = decltype(vI)::value;
-        const int i = t + v * T;  // uniform
-        cx<float> val = {0.f, 0.f};
+    // ---- input rows: lane `slot` describes row i = t + slot*T
+    int in_row;         // element offset row*pitch is formed later; -1 = zero (padding)
+    float in_w = 1.f;
+    {
+        const int i = t + slot * T;
         if constexpr (RAW_LD) {
-            const unsigned row = (unsigned)(o * A.in_o_rows + i * A.in_i_rows);
-            if (live) val = in[row * A.in_pitch];
+            in_row = o * A.in_o_rows + i * A.in_i_rows;
         } else {
             const int pi = i * A.ld_mul + o;
             const int ci = (pi + (FN >> 1)) & (FN - 1);
             const int q = (ci + A.ld_a) & (FN - 1);
-            if (q < A.ld_len) {  // uniform branch
-                int idx = q + A.ld_c;
-                if (idx >= A.ld_mod) idx -= A.ld_mod;
-                if (live) val = in[(unsigned)idx * A.in_pitch];
-                float w = 1.f;
-                if (ld_win) w *= c_ld_win[q];
-                if (ld_win2) w *= c_ld_win2[q];
-                val.x *= w;
-                val.y *= w * sg_ld;
-            }
+            int idx = q + A.ld_c;
+            if (idx >= A.ld_mod) idx -= A.ld_mod;
+            const bool ok = q < A.ld_len;
+            in_row = ok ? idx : -1;
+            const int qs = ok ? q : 0;
+            if (ld_win) in_w *= ld_win[qs];
+            if (ld_win2) in_w *= ld_win2[qs];
         }
-        if constexpr (RAW_LD) val.y *= sg_ld;
-        x[v] = val;
-    });
-
-    fft_phases<G, float, 0>(x, t, lane, true, smem, tw, [&](int e_, cx<float> v) {
-        // e_ only depends on the wave id: pin it to an SGPR so that all row bookkeeping stays scalar
-        const int e = __builtin_amdgcn_readfirstlane(e_);
+    }
+    // ---- output rows: lane `slot` describes the output the scatter calls slot (u, r)
+    int out_row;  // -1 = not stored
+    float out_w = A.scale;
+    cx<float> out_tw = {1.f, 0.f};
+    {
+        const int u = slot >> LR, r = slot & ((1 << LR) - 1);
+        const int j = t + u * T;
+        const int k = j & ((1 << LNS) - 1);
+        const int e = ((j - k) << LR) + k + (r << LNS);
         if constexpr (RAW_ST) {
-            {
-                const unsigned ti = ((unsigned)e * (unsigned)o) & (unsigned)(FN - 1);
-                const cx<float> wv = {c_twf[ti].x, c_twf[ti].y};
-                v = cmul(v, wv);
-            }
-            v.y *= sg_st;
-            const unsigned row = (unsigned)(o * A.out_o_rows + e * A.out_i_rows);
-            if (live) out[row * A.out_pitch] = v;
+            out_row = o * A.out_o_rows + e * A.out_i_rows;
+            out_tw = tw_full[((unsigned)e * (unsigned)o) & (unsigned)(FN - 1)];
         } else {
             const int pk = e * A.st_mul + o;
             const int ck = (pk + (FN >> 1)) & (FN - 1);
             const int d = (ck + A.st_a) & (FN - 1);
-            if (d < A.st_len) {  // uniform
-                int idx = d + A.st_c;
-                if (idx >= A.st_mod) idx -= A.st_mod;
-                float w = A.scale;
-                if (st_win) w *= c_st_win[d];
-                if (st_win2) w *= c_st_win2[d];
-                int row = idx;
-                if (st_rowmap) row = c_rowmap[idx];
-                if (row >= 0) {  // uniform
-                    v.x *= w;
-                    v.y *= w * sg_st;
-                    cx<float>* p = out + (unsigned)row * A.out_pitch;
-                    if (A.accumulate) {
-                        if (live) {
-                            const cx<float> old = *p;
-                            v.x += old.x;
-                            v.y += old.y;
-                        }
-                    }
-                    if (live) *p = v;
+            int idx = d + A.st_c;
+            if (idx >= A.st_mod) idx -= A.st_mod;
+            const bool ok = d < A.st_len;
+            const int ds = ok ? d : 0;
+            if (st_win) out_w *= st_win[(long long)blockIdx.z * A.st_win_bs + ds];
+            if (st_win2) out_w *= st_win2[ds];
+            int row = idx;
+            if (st_rowmap) row = st_rowmap[ok ? idx : 0];
+            out_row = ok ? row : -1;
+        }
+    }
+
+    // Issue ALL loads first (nothing in this loop consumes a loaded value, so the
+    // P loads of a lane are in flight together), then apply windows / conjugation.
+    cx<float> x[P];
+    static_for<0, P>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        const int row = __builtin_amdgcn_readlane(in_row, v);
+        cx<float> val = {0.f, 0.f};
+        if (row >= 0) {  // uniform
+            if (live) val = in[(unsigned)row * A.in_pitch];
+        }
+        x[v] = val;
+    });
+    static_for<0, P>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        if constexpr (!RAW_LD) {
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in_w), v));
+            x[v].x *= w;
+            x[v].y *= w * sg_ld;
+        } else {
+            x[v].y *= sg_ld;
+        }
+    });
+
+    fft_phases<G, float, 0>(x, t, lane, true, smem, tw, [&](int, cx<float> v, auto sI) {
+        constexpr int s = decltype(sI)::value;
+        const int row = __builtin_amdgcn_readlane(out_row, s);
+        if (row < 0) return;  // uniform
+        if constexpr (RAW_ST) {
+            cx<float> w;
+            w.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_tw.x), s));
+            w.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_tw.y), s));
+            v = cmul(v, w);
+            v.y *= sg_st;
+            if (live) out[(unsigned)row * A.out_pitch] = v;
+        } else {
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_w), s));
+            v.x *= w;
+            v.y *= w * sg_st;
+            cx<float>* p = out + (unsigned)row * A.out_pitch;
+            if (A.accumulate) {
+                if (live) {
+                    const cx<float> old = *p;
+                    v.x += old.x;
+                    v.y += old.y;
                 }
             }
+            if (live) *p = v;
         }
     });
 }

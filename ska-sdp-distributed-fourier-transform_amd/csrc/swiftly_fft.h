@@ -229,7 +229,11 @@ __device__ __forceinline__ void phase_scatter(const cx<R> (&x)[G::P], int t, F&&
         int e0 = ((j - k) << LOGR) + k;
         static_for<0, RAD>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
-            f(e0 + (r << LOGNS), x[u + bitrev(r, LOGR) * NB]);
+            // f(e, value) or f(e, value, slot) with slot = u*RAD + r as a compile-time constant
+            if constexpr (std::is_invocable_v<F, int, cx<R>, std::integral_constant<int, 0>>)
+                f(e0 + (r << LOGNS), x[u + bitrev(r, LOGR) * NB], std::integral_constant<int, u * RAD + r>{});
+            else
+                f(e0 + (r << LOGNS), x[u + bitrev(r, LOGR) * NB]);
         });
     });
 }
