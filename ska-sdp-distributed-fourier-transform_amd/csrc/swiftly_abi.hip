@@ -30,6 +30,7 @@
 
 #include "../../include/swiftly_hip.h"
 #include "swiftly_colpass.h"
+#include "swiftly_rowpass.h"
 #include "swiftly_rows.h"
 
 using namespace swf;
@@ -182,6 +183,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         if (int rc = init_fft_rows_f32()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (f32): %d", rc);
         if (int rc = init_fft_rows_f64()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (f64): %d", rc);
         if (int rc = init_col_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (col pass): %d", rc);
+        if (int rc = init_row_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (row pass): %d", rc);
         g_inited = true;
     }
     swiftly_hip* h = new (std::nothrow) swiftly_hip();
@@ -220,6 +222,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             rc = make_twiddles(h, l);
             if (!rc && l >= kTwoPassMinLog) rc = make_twiddles(h, l / 2);
             if (!rc && l >= kTwoPassMinLog) rc = make_twiddles(h, l - l / 2);
+            if (!rc && l == 15) rc = make_twiddles(h, 14);  // two-workgroup row kernel
         }
     if (rc) {
         swiftly_hip_destroy(h);
@@ -337,7 +340,7 @@ static int launch_checked(int logn, const RowsArgs<R>& a, const OffTab& tab, hip
 static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, const OffTab& tab, hipStream_t st,
                          int* rc_out) {
     if (!a.rowfast || a.in_rs != 1 || a.out_rs != 1 || tab.use != 0 || a.rm_mod > 0) return false;
-    const bool two = logn >= kTwoPassMinLog;
+    const bool two = logn > kColPassMaxLog;  // single pass up to 512 points (1024 threads x 32 points)
     static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
     const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
     if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return false;
@@ -411,6 +414,46 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
 }
 
 
+// Lean path for long complex64 transforms along the contiguous axis (one
+// workgroup per row): swiftly_rowpass.h.  Returns false when the call does not
+// fit (generic kernel handles it).
+static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, const OffTab& tab, hipStream_t st,
+                         int* rc_out) {
+    static const bool disabled = getenv("SWIFTLY_NO_ROWPASS") != nullptr;
+    if (disabled) return false;
+    if (a.rowfast || a.in_cs != 1 || a.out_cs != 1 || tab.use != 0 || (a.nbatch > 1)) return false;
+    if (logn < kRowPassMinLog || logn > kRowPassMaxLog) return false;
+    if (a.ld.win2 || a.st_win_bs != 0) return false;
+    const int n = 1 << logn;
+    const bool ident_ld = a.ld.a == 0 && a.ld.len == n && a.ld.c == 0 && !a.ld.win;
+    const bool ident_st = a.st.a == 0 && a.st.len == n && a.st.c == 0 && !a.st.win && !a.st.win2;
+    RowPassArgs r;
+    std::memset(&r, 0, sizeof r);
+    r.in = a.in; r.out = a.out;
+    r.in_pitch = a.in_rs; r.out_pitch = a.out_rs;
+    r.nrows = a.nrows;
+    r.rm_mod = a.rm_mod; r.rm_inner = a.rm_inner; r.rm_outer = a.rm_outer; r.rm_full = a.rm_full;
+    r.ld_a = a.ld.a; r.ld_len = a.ld.len; r.ld_c = a.ld.c; r.ld_mod = a.ld.mod; r.ld_win = a.ld.win;
+    r.st_a = a.st.a; r.st_len = a.st.len; r.st_c = a.st.c; r.st_mod = a.st.mod; r.st_win = a.st.win; r.st_win2 = a.st.win2;
+    r.tw = twiddles<float>(h, logn);
+    if (!r.tw) return false;
+    r.scale = a.scale; r.conj_ld = a.conj_ld; r.conj_st = a.conj_st; r.accumulate = a.accumulate;
+    const int mode = ident_st ? 0 : (ident_ld ? 1 : 2);
+    static const bool no_half = getenv("SWIFTLY_NO_HALF") != nullptr;
+    if (logn == 15 && mode == 0 && !a.accumulate && !no_half) {
+        const cx<float>* twh = twiddles<float>(h, 14);
+        if (twh) {
+            int e2 = launch_row_pass_half(r, twh, r.tw, st);
+            *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
+            return true;
+        }
+    }
+    int e = launch_row_pass(logn, mode, r, st);
+    *rc_out = e ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e)) : 0;
+    return true;
+}
+
+
 // Launch the mapped row FFT for `a` (batch of a.nbatch <= kMaxBatch items with
 // per-item offsets in `tab`).  Transforms of length >= 2^kTwoPassMinLog along
 // a strided axis are decomposed (four-step) through a stream-ordered scratch.
@@ -429,6 +472,7 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     if constexpr (std::is_same<R, float>::value) {
         int rc = 0;
         if (try_col_pass(h, logn, a, tab, st, &rc)) return rc;
+        if (try_row_pass(h, logn, a, tab, st, &rc)) return rc;
     }
     if (!(a.rowfast && logn >= kTwoPassMinLog)) return launch_checked(logn, a, tab, st);
 

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
 }
 
 constexpr int kColPassMinLog = 2;
-constexpr int kColPassMaxLog = 8;
+constexpr int kColPassMaxLog = 9;
 
 int launch_col_pass(int logn, int mode, const ColPassArgs& a, int outer, int nbatch, hipStream_t s);
 int init_col_pass();

@@ -1,0 +1,231 @@
+// SwiFTly on MI355X: lean single-workgroup transforms along the CONTIGUOUS axis
+// for long rows (N = 8192 .. 32768, complex64): K2 (extract_column =
+// row gather + prepare_facet axis 1), the axis-1 finish_facet of the backward
+// pass, and any other long contiguous-axis primitive.
+//
+// One workgroup = one row: the row base pointers are wave-uniform (SGPR base +
+// 32-bit lane offset addressing), the lane mapping is fixed at compile time,
+// all loads of a lane are issued before the first use, and the window loads
+// are batched the same way.  Register budget: P complex points + P window
+// values, no spills at 128 VGPRs.
+#pragma once
+#include "swiftly_fft.h"
+
+namespace swf {
+
+struct RowPassArgs {
+    const cx<float>* in;
+    cx<float>* out;
+    long long in_pitch, out_pitch;  // elements between rows
+    int nrows;
+    // optional modular input-row map (extract_from_facet along the other axis)
+    int rm_mod, rm_inner, rm_outer, rm_full;
+    // load map:  q = (ci + ld_a) mod N ; valid q < ld_len ; src = (q + ld_c) mod ld_mod ; window ld_win[q]
+    int ld_a, ld_len, ld_c, ld_mod;
+    const float* ld_win;
+    // store map: d = (ck + st_a) mod N ; valid d < st_len ; dst = (d + st_c) mod st_mod ; windows st_win[d]*st_win2[d]
+    int st_a, st_len, st_c, st_mod;
+    const float* st_win;
+    const float* st_win2;
+    const cx<float>* tw;
+    float scale;
+    int conj_ld, conj_st, accumulate;
+};
+
+template <int LOGN_, int LOGP_, bool SPLIT_>
+struct RGeo {
+    static constexpr int LOGN = LOGN_, LOGP = LOGP_;
+    static constexpr bool SPLIT = SPLIT_;
+    static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P, NT = T;
+    static constexpr int RB = 1;
+    static constexpr int ELEM = SPLIT ? 4 : 8;
+    static constexpr int PITCH = lds_pitch<ELEM>(N);
+    static constexpr size_t LDS_BYTES = (size_t)PITCH * ELEM;
+};
+
+__device__ const float kRowOne = 1.f;
+
+// MODE 0: mapped load (window, pad, shift), identity store   -- prepare_facet / prepare_subgrid style
+// MODE 1: identity load, mapped store (shift, crop, windows)  -- finish_facet / finish_subgrid style
+// MODE 2: both mapped
+template <class G, int MODE>
+__global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
+                                                         cx<float>* __restrict__ gout,
+                                                         const float* __restrict__ ld_win,
+                                                         const float* __restrict__ st_win,
+                                                         const float* __restrict__ st_win2,
+                                                         const cx<float>* __restrict__ tw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int P = G::P, T = G::T, N = G::N;
+    constexpr bool MAP_LD = MODE != 1, MAP_ST = MODE != 0;
+    constexpr int CH = P < 8 ? P : 8;  // loads are issued in chunks of CH; products trail one chunk behind
+    const int t = threadIdx.x;
+    const int row = blockIdx.x;  // uniform
+    int in_row = row;
+    if (A.rm_mod > 0) {
+        int r1 = row + A.rm_inner;
+        if (r1 >= A.rm_mod) r1 -= A.rm_mod;
+        r1 += A.rm_outer;
+        if (r1 >= A.rm_full) r1 -= A.rm_full;
+        in_row = r1;
+    }
+    const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;  // uniform base
+    cx<float>* __restrict__ out = gout + (long long)row * A.out_pitch;
+    const float sg_ld = A.conj_ld ? -1.f : 1.f;
+    const float sg_st = A.conj_st ? -1.f : 1.f;
+    const float* __restrict__ lw = ld_win ? ld_win : &kRowOne;
+    const int lws = ld_win ? 1 : 0;
+
+    cx<float> x[P];
+    if constexpr (MAP_LD) {
+        // branch-free: out-of-map points read element 0 (valid) and get weight 0, so the loop body has no
+        // control flow and the loads of a chunk stay in flight while the previous chunk is multiplied
+        float w[P];
+        static_for<0, P / CH + 1>([&](auto cI) {
+            constexpr int c = decltype(cI)::value;
+            if constexpr (c < P / CH) {
+                static_for<c * CH, (c + 1) * CH>([&](auto vI) {
+                    constexpr int v = decltype(vI)::value;
+                    const int ci = (t + v * T) ^ (N >> 1);
+                    const int q = (ci + A.ld_a) & (N - 1);
+                    const bool ok = q < A.ld_len;
+                    const int qs = ok ? q : 0;
+                    unsigned idx = (unsigned)(qs + A.ld_c);
+                    if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
+                    x[v] = in[idx];
+                    const float wv = lw[qs * lws];
+                    w[v] = ok ? wv : 0.f;
+                });
+            }
+            if constexpr (c > 0) {
+                static_for<(c - 1) * CH, c * CH>([&](auto vI) {
+                    constexpr int v = decltype(vI)::value;
+                    x[v].x *= w[v];
+                    x[v].y *= w[v] * sg_ld;
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    } else {
+        static_for<0, P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v] = in[(t + v * T) ^ (N >> 1)];
+        });
+        static_for<0, P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v].y *= sg_ld;
+        });
+    }
+
+    const float* __restrict__ sw1 = st_win ? st_win : &kRowOne;
+    const float* __restrict__ sw2 = st_win2 ? st_win2 : &kRowOne;
+    const int sw1s = st_win ? 1 : 0, sw2s = st_win2 ? 1 : 0;
+    fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
+        const int ck = e ^ (N >> 1);
+        if constexpr (!MAP_ST) {
+            v.x *= A.scale;
+            v.y *= A.scale * sg_st;
+            cx<float>* p = out + ck;
+            if (A.accumulate) {
+                const cx<float> old = *p;
+                v.x += old.x;
+                v.y += old.y;
+            }
+            *p = v;
+        } else {
+            const int d = (ck + A.st_a) & (N - 1);
+            const bool ok = d < A.st_len;
+            const int ds = ok ? d : 0;
+            unsigned idx = (unsigned)(ds + A.st_c);
+            if (idx >= (unsigned)A.st_mod) idx -= (unsigned)A.st_mod;
+            const float w = A.scale * sw1[ds * sw1s] * sw2[ds * sw2s];
+            v.x *= w;
+            v.y *= w * sg_st;
+            if (ok) {
+                cx<float>* p = out + idx;
+                if (A.accumulate) {
+                    const cx<float> old = *p;
+                    v.x += old.x;
+                    v.y += old.y;
+                }
+                *p = v;
+            }
+        }
+    });
+}
+
+// N = 2*G::N transform of one row by TWO workgroups (radix-2 decimation in
+// frequency on load): half h computes the outputs of parity h,
+//   X[2k'+h] = FFT_{N/2}( (x[j] + (-1)^h x[j+N/2]) * W_N^{h j} )[k'] .
+// Each half is an N/2-point problem (64 KB of LDS, < 128 VGPRs, no spills), so
+// two workgroups are resident per CU and one's HBM phase overlaps the other's
+// butterflies -- the single 32768-point workgroup (1 per CU, spilling) cannot.
+// Blocks 8i..8i+7 / 8i+8..8i+15 are the two halves of rows 8i..8i+7, so both
+// halves of a row run on the same XCD (block b -> XCD b mod 8): the second read
+// of the input row and the interleaved (stride-2) output lines meet in one L2.
+// MODE 0 only (mapped load, identity store): K2.
+template <class G>
+__global__ __launch_bounds__(G::NT) void row_pass_half_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
+                                                              cx<float>* __restrict__ gout,
+                                                              const float* __restrict__ ld_win,
+                                                              const cx<float>* __restrict__ tw,
+                                                              const cx<float>* __restrict__ tw_full) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int P = G::P, T = G::T, H = G::N, N = 2 * G::N;
+    const int t = threadIdx.x;
+    const int b = blockIdx.x;
+    const int h = (b >> 3) & 1;
+    const int row = ((b >> 4) << 3) + (b & 7);  // uniform
+    if (row >= A.nrows) return;
+    int in_row = row;
+    if (A.rm_mod > 0) {
+        int r1 = row + A.rm_inner;
+        if (r1 >= A.rm_mod) r1 -= A.rm_mod;
+        r1 += A.rm_outer;
+        if (r1 >= A.rm_full) r1 -= A.rm_full;
+        in_row = r1;
+    }
+    const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;
+    cx<float>* __restrict__ out = gout + (long long)row * A.out_pitch;
+    const float sg_ld = A.conj_ld ? -1.f : 1.f;
+    const float sg_st = A.conj_st ? -1.f : 1.f;
+    const float* __restrict__ lw = ld_win ? ld_win : &kRowOne;
+    const int lws = ld_win ? 1 : 0;
+    const float hs = h ? -1.f : 1.f;
+
+    cx<float> x[P];
+    static_for<0, P>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        const int j = t + v * T;
+        // plain index j -> centred j + N/2 ; plain j + N/2 -> centred j
+        const int qa = (j + H + A.ld_a) & (N - 1);
+        const int qb = (j + A.ld_a) & (N - 1);
+        const bool oka = qa < A.ld_len, okb = qb < A.ld_len;
+        const int qas = oka ? qa : 0, qbs = okb ? qb : 0;
+        unsigned ia = (unsigned)(qas + A.ld_c), ib = (unsigned)(qbs + A.ld_c);
+        if (ia >= (unsigned)A.ld_mod) ia -= (unsigned)A.ld_mod;
+        if (ib >= (unsigned)A.ld_mod) ib -= (unsigned)A.ld_mod;
+        const cx<float> a = in[ia], c = in[ib];
+        const float wa = oka ? lw[qas * lws] : 0.f;
+        const float wb = (okb ? lw[qbs * lws] : 0.f) * hs;
+        cx<float> y = {a.x * wa + c.x * wb, (a.y * wa + c.y * wb) * sg_ld};
+        if (h) y = cmul(y, tw_full[j]);
+        x[v] = y;
+    });
+
+    fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
+        const int ck = (2 * e + h) ^ H;
+        v.x *= A.scale;
+        v.y *= A.scale * sg_st;
+        out[ck] = v;
+    });
+}
+
+constexpr int kRowPassMinLog = 13;
+constexpr int kRowPassMaxLog = 15;
+int launch_row_pass(int logn, int mode, const RowPassArgs& a, hipStream_t s);
+int init_row_pass();
+// two-workgroup form for N = 32768 (MODE 0 only); tw_half = table of length N/2, tw_full of length N
+int launch_row_pass_half(const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s);
+
+}  // namespace swf

@@ -71,6 +71,13 @@ struct OffTab {
     int ld_a[kMaxBatch], ld_c[kMaxBatch], st_a[kMaxBatch], st_c[kMaxBatch];
 };
 
+template <typename R>
+struct kOneTable {
+    static __device__ const R value;
+};
+template <typename R>
+__device__ const R kOneTable<R>::value = (R)1;
+
 template <class G, typename R>
 __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, const OffTab tab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -111,34 +118,45 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
     const R csign_ld = A.conj_ld ? (R)-1 : (R)1;
     const R csign_st = A.conj_st ? (R)-1 : (R)1;
 
+    // Loads are branch-free: out-of-map elements read a clamped (always valid)
+    // address and are zeroed through the window factor.  With no data-dependent
+    // control flow in the loop the P loads of a thread stay in flight together;
+    // a predicated version exposes one memory latency per element.
     cx<R> x[P];
     const int ld_add = o * A.ld_addmul;
-    static_for<0, P>([&](auto vI) {
-        constexpr int v = decltype(vI)::value;
-        const int i = t + v * T;
-        cx<R> val = {(R)0, (R)0};
-        if (live) {
-            if (A.raw_ld) {
-                val = in[(size_t)((unsigned)i * A.in_cs)];
-            } else {
-                const int pi = i * A.ld_mul + ld_add;             // plain full-length index
-                const int ci = (pi + (FN >> 1)) & (FN - 1);       // centred index
-                const int q = (ci + ld_a) & (FN - 1);
-                if (q < A.ld.len) {
-                    int idx = q + ld_c;
-                    if (idx >= A.ld.mod) idx -= A.ld.mod;
-                    val = in[(size_t)((unsigned)idx * A.in_cs)];
-                    R w = (R)1;
-                    if (A.ld.win) w = A.ld.win[q];
-                    if (A.ld.win2) w *= A.ld.win2[q];
-                    val.x *= w;
-                    val.y *= w;
-                }
-            }
-            val.y *= csign_ld;
-        }
-        x[v] = val;
-    });
+    const R* __restrict__ win1 = A.ld.win ? A.ld.win : &kOneTable<R>::value;
+    const R* __restrict__ win2 = A.ld.win2 ? A.ld.win2 : &kOneTable<R>::value;
+    const int w1s = A.ld.win ? 1 : 0, w2s = A.ld.win2 ? 1 : 0;
+    const R live_f = live ? (R)1 : (R)0;
+    if (A.raw_ld) {  // uniform over the launch
+        static_for<0, P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v] = in[(size_t)((unsigned)(t + v * T) * A.in_cs)];
+        });
+        static_for<0, P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v].x *= live_f;
+            x[v].y *= live_f * csign_ld;
+        });
+    } else {
+        static_for<0, P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            const int i = t + v * T;
+            const int pi = i * A.ld_mul + ld_add;        // plain full-length index
+            const int ci = (pi + (FN >> 1)) & (FN - 1);  // centred index
+            const int q = (ci + ld_a) & (FN - 1);
+            const bool ok = q < A.ld.len;
+            const int qs = ok ? q : 0;
+            int idx = qs + ld_c;
+            if (idx >= A.ld.mod) idx -= A.ld.mod;
+            cx<R> val = in[(size_t)((unsigned)idx * A.in_cs)];
+            R w = win1[qs * w1s] * win2[qs * w2s];
+            w = ok ? w * live_f : (R)0;
+            val.x *= w;
+            val.y *= w * csign_ld;
+            x[v] = val;
+        });
+    }
 
     const int st_add = o * A.st_addmul;
     fft_phases<G, R, 0>(x, t, rb, rowfast, smem, A.tw, [&](int e, cx<R> v) {

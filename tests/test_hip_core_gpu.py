@@ -269,3 +269,28 @@ def test_unsupported_length_raises():
     core = SwiftlyCoreHip(11.0, 1536, 128, 768)
     with pytest.raises(NotImplementedError):
         core.prepare_facet(numpy.zeros(500, dtype=complex), 0, axis=0)
+
+
+def test_long_rows_yN32768_c64():
+    """The N = 32768 contiguous-axis kernels (two workgroups per row, radix-2 split on load) with window,
+    zero-padding, shift and the fused row gather: prepare_facet(axis=1) and extract_column vs the oracle."""
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    W, N, xM, yN = 10.875, 65536, 1024, 32768
+    core = SwiftlyCoreHip(W, N, xM, yN)
+    ref = orc.OracleCore(W, N, xM, yN)
+    rng = numpy.random.default_rng(11)
+    yB = 22528
+    rows = (rng.standard_normal((5, yB)) + 1j * rng.standard_normal((5, yB))).astype(numpy.complex64)
+    for off in (0, 64 * 352, -64 * 320):
+        got = core.prepare_facet(rows, off, axis=1)
+        want = ref.prepare_facet(rows.astype(complex), off, 1)
+        rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+        assert got.dtype == numpy.complex64 and rel < 2e-6, rel
+    # extract_column on a narrow BF_F [yN, 300]: row gather (window of m rows) + axis-1 prepare
+    bf = (rng.standard_normal((yN, 300)) + 1j * rng.standard_normal((yN, 300))).astype(numpy.complex64)
+    for so0, fo1 in ((928 * 3, 22528), (-928 * 17, 0)):
+        got = core.extract_column(bf, so0, fo1)
+        want = orc.extract_column(ref, bf.astype(complex), so0, fo1)
+        rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+        assert rel < 2e-6, rel
