@@ -124,7 +124,10 @@ def run_forward(sw, torch, cfg, fwd_factory, waves, timer=None):
     bfs = []
     for c, data in zip(fwd.facet_configs, fwd._facets):  # pylint: disable=protected-access
         t0 = timer.start()
-        bfs.append(core.prepare_facet(data, c.off0, axis=0))
+        if fwd._rowmap is None:  # pylint: disable=protected-access
+            bfs.append(core.prepare_facet(data, c.off0, axis=0))
+        else:
+            bfs.append(core.prepare_facet_rows(data, c.off0, fwd._rowmap, fwd._n_rows))  # pylint: disable=protected-access
         timer.stop("K1_prepare_facet_axis0", t0)
     fwd.BF_Fs_persist = bfs
     for wave in waves:
@@ -242,10 +245,13 @@ def main():
         facet_data[j] = torch.complex(re, im) * m0[:, None] * m1[None, :]
         del re, im
 
-    if world == 1:
+    force_dist = os.environ.get("SWIFTLY_BENCH_FORCE_DIST") == "1"  # exercise the multi-GPU code path on 1 GPU
+    if world == 1 and not force_dist:
 
         def factory():
-            return sw.SwiftlyForward(cfg, [(facet_cfgs[j], facet_data[j]) for j in range(F)], lru_forward=1)
+            return sw.SwiftlyForward(
+                cfg, [(facet_cfgs[j], facet_data[j]) for j in range(F)], lru_forward=1, subgrid_configs=sg_cfgs
+            )
 
         def one_pass(timer=None):
             return run_forward(sw, torch, cfg, factory, waves, timer)
@@ -253,7 +259,7 @@ def main():
     else:
 
         def one_pass(timer=None):  # pylint: disable=unused-argument
-            dfw = DistributedForward(cfg, facet_cfgs, facet_data, lru_forward=1)
+            dfw = DistributedForward(cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs)
             dfw.local._get_BF_Fs()  # pylint: disable=protected-access
             n = 0
             for wave in waves:
@@ -284,7 +290,7 @@ def main():
     stages = {}
     roofline = None
     total_bytes, parts = algorithmic_bytes(p, F, S, C)
-    if world == 1:
+    if world == 1 and not force_dist:
         timer = StageTimer(torch)
         one_pass(timer)
         torch.cuda.synchronize()

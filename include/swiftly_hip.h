@@ -147,6 +147,18 @@ int swiftly_hip_extract_column(swiftly_hip_t* h, int dtype, const void* in, int6
                                int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
                                int64_t out_col_stride, int64_t subgrid_off0, int64_t facet_off1, void* stream);
 
+/* Row-compacted BF_F (sparse subgrid sets): `rowmap` is a DEVICE int32 array of length yN; entry k is the
+ * physical row of BF_F that holds logical row k, or negative when no requested subgrid column reads row k.
+ * prepare_facet_rows = prepare_facet whose output index along the transform axis goes through the map
+ * (unmapped rows are never written); extract_column_rows = extract_column reading such a compacted BF_F. */
+int swiftly_hip_prepare_facet_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
+                                   int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
+                                   int64_t out_col_stride, int64_t facet_off, const int32_t* rowmap, void* stream);
+int swiftly_hip_extract_column_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t facet_size,
+                                    int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
+                                    int64_t out_col_stride, int64_t subgrid_off0, int64_t facet_off1,
+                                    const int32_t* rowmap, void* stream);
+
 int swiftly_hip_extract_from_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
                                          int64_t in_row_stride, int64_t in_col_stride, void* out,
                                          int64_t out_row_stride, int64_t out_col_stride, int64_t subgrid_off,

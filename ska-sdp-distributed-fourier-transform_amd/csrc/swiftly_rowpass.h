@@ -20,6 +20,7 @@ struct RowPassArgs {
     int nrows;
     // optional modular input-row map (extract_from_facet along the other axis)
     int rm_mod, rm_inner, rm_outer, rm_full;
+    const int* in_rowmap;  // optional: physical input row of logical input row (compacted BF_F)
     // load map:  q = (ci + ld_a) mod N ; valid q < ld_len ; src = (q + ld_c) mod ld_mod ; window ld_win[q]
     int ld_a, ld_len, ld_c, ld_mod;
     const float* ld_win;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, co
         if (r1 >= A.rm_full) r1 -= A.rm_full;
         in_row = r1;
     }
+    if (A.in_rowmap) in_row = A.in_rowmap[in_row];
     const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;  // uniform base
     cx<float>* __restrict__ out = gout + (long long)row * A.out_pitch;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_half_kernel(const RowPassArgs 
         if (r1 >= A.rm_full) r1 -= A.rm_full;
         in_row = r1;
     }
+    if (A.in_rowmap) in_row = A.in_rowmap[in_row];
     const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;
     cx<float>* __restrict__ out = gout + (long long)row * A.out_pitch;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;

@@ -61,6 +61,11 @@ struct RowsArgs {
     long long in_bs, out_bs;
     int nbatch;
     long long st_win_bs;
+    // Optional row compaction tables (device, int32): BF_F keeps only the rows some requested subgrid
+    // column reads.  st_rowmap: physical output index of logical store index (negative = not stored);
+    // in_rowmap: physical input row of logical input row.
+    const int* st_rowmap;
+    const int* in_rowmap;
 };
 
 // Per-batch-item overrides of the map offsets (passed by value as a kernel
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
         if (r1 >= A.rm_full) r1 -= A.rm_full;
         in_row = r1;
     }
+    if (A.in_rowmap) in_row = A.in_rowmap[in_row];
     const int b = blockIdx.y;
     const cx<R>* __restrict__ in = A.in + in_row * A.in_rs + (long long)o * A.in_os + (long long)b * A.in_bs;
     cx<R>* __restrict__ out = A.out + row * A.out_rs + (long long)o * A.out_os + (long long)b * A.out_bs;
@@ -184,6 +190,10 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
         if (d < A.st.len) {
             int idx = d + st_c;
             if (idx >= A.st.mod) idx -= A.st.mod;
+            if (A.st_rowmap) {
+                idx = A.st_rowmap[idx];
+                if (idx < 0) return;
+            }
             R w = (R)1;
             if (st_win) w = st_win[d];
             if (A.st.win2) w *= A.st.win2[d];

@@ -253,13 +253,21 @@ class SwiftlyForward:
         prepared facet columns ``NMBF_BF`` are kept
     :param queue_size: kept for signature compatibility (bounds in-flight
         subgrid tasks in the reference; here the HIP stream is the queue)
+    :param subgrid_configs: optional (extension) list of all subgrids that will
+        be requested; enables row-compacted ``BF_F`` for sparse subgrid sets
     """
 
     # pylint: disable=too-many-arguments,too-many-instance-attributes
-    def __init__(self, swiftly_config, facet_tasks, lru_forward=1, queue_size=20, client=None):
+    def __init__(self, swiftly_config, facet_tasks, lru_forward=1, queue_size=20, client=None, subgrid_configs=None):
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facet_tasks = facet_tasks
+        # optional plan (extension): when the caller knows up front which subgrids it will ask for (sparse
+        # covers, scripts/demo_sparse_facet.py style), BF_F only keeps the rows those columns read
+        self._rowmap, self._n_rows = None, None
+        if subgrid_configs is not None:
+            self._rowmap, self._n_rows = self.core.subgrid_column_rows([sg.off0 for sg in subgrid_configs])
+            self._planned_off0 = {int(sg.off0) for sg in subgrid_configs}
         self.facet_configs = [cfg for cfg, _ in facet_tasks]
         self.queue_size = queue_size
         self._client = client
@@ -278,10 +286,16 @@ class SwiftlyForward:
     # -- stage 1: BF_F = prepare_facet(axis 0), once per facet (api.py:281-298)
     def _get_BF_Fs(self):
         if self.BF_Fs_persist is None:
-            self.BF_Fs_persist = [
-                self.core.prepare_facet(data, cfg.off0, axis=0)
-                for cfg, data in zip(self.facet_configs, self._facets)
-            ]
+            if self._rowmap is None:
+                self.BF_Fs_persist = [
+                    self.core.prepare_facet(data, cfg.off0, axis=0)
+                    for cfg, data in zip(self.facet_configs, self._facets)
+                ]
+            else:
+                self.BF_Fs_persist = [
+                    self.core.prepare_facet_rows(data, cfg.off0, self._rowmap, self._n_rows)
+                    for cfg, data in zip(self.facet_configs, self._facets)
+                ]
         return self.BF_Fs_persist
 
     # -- stage 2: per subgrid column (api.py:300-324)
@@ -291,8 +305,10 @@ class SwiftlyForward:
             BF_Fs = self._get_BF_Fs()
         cols = self.lru.get(off0)
         if cols is None:
+            if self._rowmap is not None and int(off0) not in self._planned_off0:
+                raise ValueError(f"subgrid column off0={off0} was not in the subgrid_configs plan")
             cols = [
-                self.core.extract_column(BF_F, off0, cfg.off1)
+                self.core.extract_column(BF_F, off0, cfg.off1, rowmap=self._rowmap)
                 for cfg, BF_F in zip(self.facet_configs, BF_Fs)
             ]
             self.lru.set(off0, cols)

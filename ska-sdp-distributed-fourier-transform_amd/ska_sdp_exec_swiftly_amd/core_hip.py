@@ -289,26 +289,66 @@ class SwiftlyCoreHip:
         args.append(self._stream())
         _lib.check(getattr(self._lib, f"swiftly_hip_{fname}_batch")(*args))
 
-    def extract_column(self, BF_F, subgrid_off0, facet_off1, out=None):
+    def extract_column(self, BF_F, subgrid_off0, facet_off1, out=None, rowmap=None):
         """``prepare_facet(extract_from_facet(BF_F, subgrid_off0, axis=0),
         facet_off1, axis=1)`` (reference api_helper.py:200-210) as one kernel on
         a device tensor ``BF_F[yN_size, facet_size]`` -> ``[xM_yN_size,
-        yN_size]``."""
+        yN_size]``.  With ``rowmap`` (int32 device tensor of length yN_size,
+        see :py:meth:`prepare_facet_rows`) ``BF_F`` is the row-compacted form."""
         torch = _torch()
         if not isinstance(BF_F, torch.Tensor):
             res = self.extract_column(self._as_device(BF_F)[0], subgrid_off0, facet_off1)
             return res.cpu().numpy()
-        if BF_F.dim() != 2 or BF_F.shape[0] != self.yN_size:
+        if BF_F.dim() != 2 or (rowmap is None and BF_F.shape[0] != self.yN_size):
             raise ValueError(f"BF_F must have shape [{self.yN_size}, facet_size], got {tuple(BF_F.shape)}")
         if out is None:
             out = torch.empty((self.xM_yN_size, self.yN_size), dtype=BF_F.dtype, device=self._device)
         elif tuple(out.shape) != (self.xM_yN_size, self.yN_size):
             raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(self.xM_yN_size, self.yN_size)}!")
+        args = [
+            self._handle, self._code(BF_F), ctypes.c_void_p(BF_F.data_ptr()), int(BF_F.shape[1]),
+            BF_F.stride(0), BF_F.stride(1), ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1),
+            int(subgrid_off0), int(facet_off1),
+        ]
+        if rowmap is None:
+            _lib.check(self._lib.swiftly_hip_extract_column(*args, self._stream()))
+        else:
+            _lib.check(
+                self._lib.swiftly_hip_extract_column_rows(*args, ctypes.c_void_p(rowmap.data_ptr()), self._stream())
+            )
+        return out
+
+    def subgrid_column_rows(self, subgrid_off0s):
+        """Row map for a sparse set of subgrid columns: which rows of
+        ``BF_F = prepare_facet(facet, off0, axis=0)`` does
+        ``extract_from_facet(., off0, axis=0)`` read for the given subgrid
+        ``off0`` values (core.py:243-253).  Returns ``(rowmap int32 device
+        tensor [yN_size] with -1 for unused rows, number of rows kept)``."""
+        torch = _torch()
+        yN, m = self.yN_size, self.xM_yN_size
+        keep = numpy.zeros(yN, dtype=bool)
+        for off0 in set(int(o) for o in subgrid_off0s):
+            s = off0 * yN // self.N
+            keep[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN] = True
+        rowmap = numpy.full(yN, -1, dtype=numpy.int32)
+        rowmap[keep] = numpy.arange(int(keep.sum()), dtype=numpy.int32)
+        return torch.from_numpy(rowmap).to(self._device), int(keep.sum())
+
+    def prepare_facet_rows(self, facet, facet_off, rowmap, n_rows, out=None):
+        """``prepare_facet(facet, facet_off, axis=0)`` keeping only the rows
+        ``rowmap`` selects (device tensors only): output ``[n_rows,
+        facet.shape[1]]``; rows no requested subgrid column reads are never
+        written, which removes their share of the HBM traffic and footprint."""
+        torch = _torch()
+        if facet.dim() != 2:
+            raise ValueError("prepare_facet_rows needs a 2-D device tensor")
+        if out is None:
+            out = torch.empty((n_rows, facet.shape[1]), dtype=facet.dtype, device=self._device)
         _lib.check(
-            self._lib.swiftly_hip_extract_column(
-                self._handle, self._code(BF_F), ctypes.c_void_p(BF_F.data_ptr()), int(BF_F.shape[1]),
-                BF_F.stride(0), BF_F.stride(1), ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1),
-                int(subgrid_off0), int(facet_off1), self._stream(),
+            self._lib.swiftly_hip_prepare_facet_rows(
+                self._handle, self._code(facet), ctypes.c_void_p(facet.data_ptr()), int(facet.shape[1]),
+                int(facet.shape[0]), facet.stride(1), facet.stride(0), ctypes.c_void_p(out.data_ptr()),
+                out.stride(1), out.stride(0), int(facet_off), ctypes.c_void_p(rowmap.data_ptr()), self._stream(),
             )
         )
         return out

@@ -85,7 +85,7 @@ class DistributedForward:
     (``facet_data[j]`` for ``j in sharding.local_facets``; other entries are
     ignored and may be ``None``)."""
 
-    def __init__(self, swiftly_config, facet_configs, facet_data, lru_forward=1, group=None):
+    def __init__(self, swiftly_config, facet_configs, facet_data, lru_forward=1, group=None, subgrid_configs=None):
         from .api import SwiftlyForward  # pylint: disable=import-outside-toplevel
 
         torch = _torch()
@@ -98,7 +98,10 @@ class DistributedForward:
         self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world)
         local = self.sharding.local_facets
         self.local = SwiftlyForward(
-            swiftly_config, [(self.facet_configs[j], facet_data[j]) for j in local], lru_forward=lru_forward
+            swiftly_config,
+            [(self.facet_configs[j], facet_data[j]) for j in local],
+            lru_forward=lru_forward,
+            subgrid_configs=subgrid_configs,
         )
 
     def get_subgrid_wave(self, sgs):

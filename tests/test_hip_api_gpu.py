@@ -132,3 +132,20 @@ def test_forward_matches_oracle_c64_bench_shape():
         assert a.dtype == numpy.complex64
         rel = numpy.sqrt(numpy.mean(numpy.abs(a - b) ** 2) / numpy.mean(numpy.abs(b) ** 2))
         assert rel < 2e-5, rel  # measured 1.1e-5; numpy float32 path: 6.9e-6
+
+
+def test_sparse_plan_is_bit_identical():
+    """Row-compacted BF_F (subgrid_configs= plan) gives exactly the same subgrids as the full BF_F, and
+    asking for an unplanned column is refused."""
+    sw, cfg, facet_cfgs, sg_cfgs, facets = small_problem(SMALL11_PARAMS, numpy.complex64, 4321)
+    wanted = [c for c in sg_cfgs if c.off0 in (0, 96 * 2, 96 * 5)]
+    full = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)))
+    plan = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=wanted)
+    a = [t.cpu().numpy() for t in full.get_subgrid_tasks(wanted)]
+    b = [t.cpu().numpy() for t in plan.get_subgrid_tasks(wanted)]
+    assert plan._n_rows < cfg.internal_facet_size  # really compacted
+    assert plan.BF_Fs_persist[0].shape[0] == plan._n_rows
+    for x, y in zip(a, b):
+        assert numpy.array_equal(x, y)
+    with pytest.raises(ValueError):
+        plan.get_subgrid_task([c for c in sg_cfgs if c.off0 == 96][0])
