@@ -195,6 +195,18 @@ int swiftly_hip_finish_facet_batch(swiftly_hip_t* h, int dtype, const void* in, 
                                    int64_t in_batch_stride, int64_t out_batch_stride, const int64_t* facet_offs,
                                    int64_t mask_batch_stride, void* stream);
 
+/* Fused second half of api_helper.sum_and_finish_subgrid (api_helper.py:96-112) along the contiguous axis,
+ * complex64: for every row of every subgrid b of a wave
+ *     out[b][row, :] = mask_b * finish_subgrid_axis1( sum_g add_to_subgrid_axis1(in[g][b][row, :], group_facet_offs[g]) )
+ * in[g][b] = [xM, m] (row stride in_row_stride), out[b] = [xM, subgrid_size].  Host arrays: group_facet_offs
+ * (ngroups <= 8 facet off1 values), subgrid_offs (nbatch subgrid off1 values).  The [xM, xM] accumulator never
+ * reaches HBM.  SWIFTLY_ERR_UNSUPPORTED for complex128 or (m, xM) pairs that are not instantiated. */
+int swiftly_hip_sum_finish_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t ngroups, int64_t in_group_stride,
+                                int64_t in_batch_stride, int64_t in_row_stride, const int64_t* group_facet_offs,
+                                void* out, int64_t out_batch_stride, int64_t out_row_stride,
+                                const int64_t* subgrid_offs, int64_t subgrid_size, const void* mask,
+                                int64_t mask_batch_stride, int64_t nbatch, void* stream);
+
 /* -- device memory helpers for callers that do not bring their own allocator
  *    (the Python mirror uses torch for device memory and never calls these) -- */
 int swiftly_hip_malloc(void** ptr, size_t bytes);

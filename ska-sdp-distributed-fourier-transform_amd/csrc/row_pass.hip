@@ -1,4 +1,6 @@
 // instantiations + dispatch of the lean long-row kernel (complex64)
+#include <cstdlib>
+
 #include "swiftly_rowpass.h"
 
 namespace swf {
@@ -45,19 +47,27 @@ int launch_row_pass(int logn, int mode, const RowPassArgs& a, hipStream_t s) {
         default: return -1;
     }
 }
-int launch_row_pass_half(const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s) {
-    using G = typename RGeoFor<14>::type;
-    if (a.nrows <= 0) return 0;
+template <class G>
+static int launch_half(const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s) {
     const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
     hipLaunchKernelGGL((row_pass_half_kernel<G>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
                        tw_half, tw_full);
     return (int)hipGetLastError();
 }
+using HalfGeoA = RGeo<14, 4, true>;  // 1024 threads x 16 points, 2 workgroups / CU
+using HalfGeoB = RGeo<14, 5, true>;  // 512 threads x 32 points (tuning alternative)
+int launch_row_pass_half(const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s) {
+    if (a.nrows <= 0) return 0;
+    static const bool alt = getenv("SWIFTLY_K2_P32") != nullptr;
+    return alt ? launch_half<HalfGeoB>(a, tw_half, tw_full, s) : launch_half<HalfGeoA>(a, tw_half, tw_full, s);
+}
 int init_row_pass() {
     {
-        using G = typename RGeoFor<14>::type;
-        int rc0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_half_kernel<G>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        int rc0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_half_kernel<HalfGeoA>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HalfGeoA::LDS_BYTES);
+        if (!rc0)
+            rc0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_half_kernel<HalfGeoB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HalfGeoB::LDS_BYTES);
         if (rc0) return rc0;
     }
     int rc = init_one<13>();

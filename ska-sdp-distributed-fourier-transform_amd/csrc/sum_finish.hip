@@ -1,0 +1,45 @@
+// instantiations of the fused sum + finish row kernel for the (m, xM) pairs of the catalogue families
+#include "swiftly_sumfinish.h"
+
+namespace swf {
+
+template <int LOGM, int LOGX>
+static int launch_one(const SumFinishArgs& a, int nbatch, hipStream_t s) {
+    using S = SFGeo<LOGM, LOGX>;
+    dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
+    hipLaunchKernelGGL((sum_finish_rows_kernel<LOGM, LOGX>), grid, dim3(256), S::LDS_BYTES, s, a);
+    return (int)hipGetLastError();
+}
+template <int LOGM, int LOGX>
+static int init_one() {
+    using S = SFGeo<LOGM, LOGX>;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&sum_finish_rows_kernel<LOGM, LOGX>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+}
+
+#define SF_PAIRS(X) X(7, 8) X(7, 10) X(8, 9) X(8, 10) X(9, 10) X(9, 11) X(10, 11)
+
+int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s) {
+#define SF_CASE(M, XX) \
+    if (logm == M && logx == XX) return launch_one<M, XX>(a, nbatch, s);
+    SF_PAIRS(SF_CASE)
+#undef SF_CASE
+    return -1;
+}
+int init_sum_finish_rows() {
+    int rc = 0;
+#define SF_INIT(M, XX) \
+    if (!rc) rc = init_one<M, XX>();
+    SF_PAIRS(SF_INIT)
+#undef SF_INIT
+    return rc;
+}
+bool sum_finish_supported(int logm, int logx) {
+#define SF_HAS(M, XX) \
+    if (logm == M && logx == XX) return true;
+    SF_PAIRS(SF_HAS)
+#undef SF_HAS
+    return false;
+}
+
+}  // namespace swf

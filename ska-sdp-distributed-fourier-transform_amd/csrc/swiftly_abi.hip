@@ -31,6 +31,7 @@
 #include "../../include/swiftly_hip.h"
 #include "swiftly_colpass.h"
 #include "swiftly_rowpass.h"
+#include "swiftly_sumfinish.h"
 #include "swiftly_rows.h"
 
 using namespace swf;
@@ -184,6 +185,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         if (int rc = init_fft_rows_f64()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (f64): %d", rc);
         if (int rc = init_col_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (col pass): %d", rc);
         if (int rc = init_row_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (row pass): %d", rc);
+        if (int rc = init_sum_finish_rows()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (sum finish): %d", rc);
         g_inited = true;
     }
     swiftly_hip* h = new (std::nothrow) swiftly_hip();
@@ -878,6 +880,49 @@ int swiftly_hip_finish_facet(swiftly_hip_t* h, int dtype, const void* in, int64_
                              const void* mask, void* stream) {
     return swiftly_hip_finish_facet_batch(h, dtype, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, facet_size,
                                           mask, 1, 0, 0, nullptr, 0, stream);
+}
+
+int swiftly_hip_sum_finish_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t ngroups, int64_t in_group_stride,
+                                int64_t in_batch_stride, int64_t in_row_stride, const int64_t* group_facet_offs,
+                                void* out, int64_t out_batch_stride, int64_t out_row_stride,
+                                const int64_t* subgrid_offs, int64_t subgrid_size, const void* mask,
+                                int64_t mask_batch_stride, int64_t nbatch, void* stream) {
+    if (!h || !in || !out || !group_facet_offs || !subgrid_offs) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    CHECK_SUBGRID_SIZE();
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_rows: complex64 only");
+    if (ngroups <= 0 || ngroups > kSumFinishMaxGroups)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_rows: 1..%d facet groups supported", kSumFinishMaxGroups);
+    if (!sum_finish_supported(h->log_m, h->log_xM))
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_rows: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
+                    (long long)h->xM);
+    if (nbatch <= 0) return 0;
+    const int xM = (int)h->xM, xA = (int)subgrid_size;
+    SumFinishArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in_gs = in_group_stride;
+    a.in_bs = in_batch_stride;
+    a.in_rs = in_row_stride;
+    a.out_bs = out_batch_stride;
+    a.out_rs = out_row_stride;
+    a.nrows = xM;
+    a.ngroups = (int)ngroups;
+    a.xA = xA;
+    for (int g = 0; g < ngroups; g++) a.sp[g] = (int)floordiv(group_facet_offs[g] * h->xM, h->N);
+    a.fn = h->fn_f;
+    a.mask_bs = mask ? mask_batch_stride : 0;
+    a.tw_m = twiddles<float>(h, h->log_m);
+    a.tw_x = twiddles<float>(h, h->log_xM);
+    if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
+    for (int64_t b0 = 0; b0 < nbatch; b0 += kSumFinishMaxBatch) {
+        const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nbatch - b0);
+        a.in = (const cx<float>*)in + b0 * in_batch_stride;
+        a.out = (cx<float>*)out + b0 * out_batch_stride;
+        a.mask = mask ? (const float*)mask + b0 * mask_batch_stride : nullptr;
+        for (int b = 0; b < nb; b++) a.st_a[b] = pmod(-(xM / 2 - xA / 2 + subgrid_offs[b0 + b]), xM);
+        int e = launch_sum_finish_rows(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
+        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    return 0;
 }
 
 int swiftly_hip_malloc(void** ptr, size_t bytes) {

@@ -1,0 +1,121 @@
+// SwiFTly on MI355X: fused "sum over facet groups + finish" along the
+// contiguous axis of a subgrid (complex64).
+//
+// For every row of every subgrid of a wave this does, on chip,
+//     acc   = sum_g  place_g( Fn * cfft_m( colacc[g][row, :] ) )        add_to_subgrid(axis=1), core.py:274-285,
+//                                                                       summed over the off1 groups, api_helper.py:96-99
+//     out_i = mask_i * cifft_xM(acc)[(xM/2 - xA//2 + i + off1) mod xM]  finish_subgrid(axis=1) + mask, core.py:316-323,
+//                                                                       api_helper.py:110-111
+// so the [xM, xM] accumulator never exists in HBM: one read of the group
+// column buffers, one write of the half-finished subgrid (vs. zero-fill +
+// read-modify-write per group + read/write of the finish in the unfused form).
+#pragma once
+#include "swiftly_fft.h"
+
+namespace swf {
+
+constexpr int kSumFinishMaxGroups = 8;
+constexpr int kSumFinishMaxBatch = 64;
+
+struct SumFinishArgs {
+    const cx<float>* in;   // colacc[g][b][row][m]
+    cx<float>* out;        // tmp[b][row][xA]
+    long long in_gs, in_bs, in_rs;  // element strides: group, subgrid, row
+    long long out_bs, out_rs;
+    int nrows;             // rows per subgrid (xM)
+    int ngroups, xA;
+    int sp[kSumFinishMaxGroups];       // s' = floor(facet_off1 * xM / N) per group
+    int st_a[kSumFinishMaxBatch];      // (-(xM/2 - xA//2 + off1_b)) mod xM per subgrid
+    const float* fn;       // Fn[m]
+    const float* mask;     // optional [nbatch][xA]
+    long long mask_bs;
+    const cx<float>* tw_m;
+    const cx<float>* tw_x;
+};
+
+template <int LOGM, int LOGX>
+struct SFGeo {
+    static constexpr int TR = 64;  // threads per row
+    static constexpr int NT = 256;
+    using GM = Geo<float, LOGM, LOGM - 6, NT, false>;
+    using GX = Geo<float, LOGX, LOGX - 6, NT, false>;
+    static_assert(LOGM >= 7, "at least two points per lane");
+    static_assert(GM::T == TR && GX::T == TR, "one wave per row");
+    static constexpr int RB = NT / TR;
+    static constexpr size_t LDS_M = (size_t)RB * GM::PITCH * 8;
+    static constexpr size_t LDS_X = (size_t)RB * GX::PITCH * 8;
+    static constexpr size_t LDS_BYTES = LDS_M + LDS_X;
+};
+
+template <int LOGM, int LOGX>
+__global__ __launch_bounds__(256) void sum_finish_rows_kernel(const SumFinishArgs A) {
+    using S = SFGeo<LOGM, LOGX>;
+    using GM = typename S::GM;
+    using GX = typename S::GX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cx<float>* ex_m = reinterpret_cast<cx<float>*>(smem);
+    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + S::LDS_M);
+    constexpr int M = GM::N, X = GX::N, PM = GM::P, PX = GX::P, TR = S::TR;
+    const int t = threadIdx.x % TR, rb = threadIdx.x / TR;
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * S::RB + rb;
+    const bool live = row < A.nrows;
+    const int rrow = live ? row : 0;
+
+    // zero the accumulator row
+    static_for<0, PX>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        acc[lds_pos<GX>(rb, t + v * TR, false)] = cx<float>{0.f, 0.f};
+    });
+    __syncthreads();
+
+    for (int g = 0; g < A.ngroups; g++) {
+        const cx<float>* __restrict__ in = A.in + (long long)g * A.in_gs + (long long)b * A.in_bs + (long long)rrow * A.in_rs;
+        cx<float> x[PM];
+        static_for<0, PM>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v] = in[(t + v * TR) ^ (M >> 1)];  // plain index -> centred element
+        });
+        const int sp = A.sp[g];
+        fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+            const int ck = e ^ (M >> 1);
+            const int k = (ck - sp) & (M - 1);
+            const int dest = (k + (X >> 1) - (M >> 1) + sp) & (X - 1);  // centred position in the padded subgrid
+            const float w = A.fn[k];
+            cx<float>* p = acc + lds_pos<GX>(rb, dest ^ (X >> 1), false);  // stored at its plain iFFT index
+            cx<float> o = *p;
+            o.x += v.x * w;
+            o.y += v.y * w;
+            *p = o;
+        });
+        __syncthreads();  // also protects ex_m reuse by the next group
+    }
+
+    cx<float> y[PX];
+    static_for<0, PX>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        cx<float> val = acc[lds_pos<GX>(rb, t + v * TR, false)];
+        val.y = -val.y;  // inverse transform = conj(FFT(conj(.)))
+        y[v] = val;
+    });
+    __syncthreads();
+    cx<float>* __restrict__ out = A.out + (long long)b * A.out_bs + (long long)rrow * A.out_rs;
+    const float* __restrict__ mask = A.mask ? A.mask + (long long)b * A.mask_bs : nullptr;
+    const int st_a = A.st_a[b];
+    const float scale = 1.f / (float)X;
+    fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
+        const int ck = e ^ (X >> 1);
+        const int d = (ck + st_a) & (X - 1);
+        if (d < A.xA && live) {
+            float w = scale;
+            if (mask) w *= mask[d];
+            out[d] = cx<float>{v.x * w, -v.y * w};
+        }
+    });
+}
+
+int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s);
+int init_sum_finish_rows();
+bool sum_finish_supported(int logm, int logx);
+
+}  // namespace swf

@@ -69,6 +69,8 @@ def _declare(lib):
         fn = getattr(lib, "swiftly_hip_" + name)
         fn.restype = c_int
         fn.argtypes = args
+    lib.swiftly_hip_sum_finish_rows.restype = c_int
+    lib.swiftly_hip_sum_finish_rows.argtypes = [vp, c_int, vp, i64, i64, i64, i64, pi64, vp, i64, i64, pi64, i64, vp, i64, i64, vp]
     lib.swiftly_hip_malloc.restype = c_int
     lib.swiftly_hip_malloc.argtypes = [POINTER(vp), c_size_t]
     lib.swiftly_hip_free.restype = c_int

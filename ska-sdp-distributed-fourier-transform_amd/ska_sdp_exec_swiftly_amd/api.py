@@ -371,20 +371,33 @@ def sum_and_finish_wave(core, contrib, facet_configs, sgs):
     off1s = [sg.off1 for sg in sgs]
     # K4a: axis-0 transform + placement, summed over the facets of one off1 group
     colacc = torch.zeros((len(groups), S, xM, m), dtype=dt, device=dev)
-    for j, cfg in enumerate(facet_configs):
-        core.launch("add_to_subgrid", contrib[j], m, 1, m, colacc[groups.index(cfg.off1)], 1, m, cfg.off0,
-                    nbatch=S, in_bs=m * m, out_bs=xM * m)
-    # K4b: axis-1 transform + placement, summed over groups
-    acc = torch.zeros((S, xM, xM), dtype=dt, device=dev)
-    for g, off1 in enumerate(groups):
-        core.launch("add_to_subgrid", colacc[g], xM, m, 1, acc, xM, 1, off1,
-                    nbatch=S, in_bs=xM * m, out_bs=xM * xM)
-    # K5: finish axis 1 (per-subgrid off1, mask1), then axis 0 (mask0)
+    off0s = sorted({cfg.off0 for cfg in facet_configs})
+    grid = [(cfg.off0, cfg.off1) for cfg in facet_configs] == [(a, b) for a in off0s for b in groups]
+    if grid and contrib.is_contiguous():
+        # facets form an off0 x off1 grid in row-major order (make_full_facet_cover): facets with the same
+        # off0 belong to different groups, so ONE launch per off0 handles all (group, subgrid) pairs --
+        # batch item z = g*S + b reads contrib[i*G + g, b] and adds into colacc[g, b]
+        G = len(groups)
+        for i, off0_f in enumerate(off0s):
+            core.launch("add_to_subgrid", contrib[i * G], m, 1, m, colacc, 1, m, off0_f,
+                        nbatch=G * S, in_bs=m * m, out_bs=xM * m)
+    else:
+        for j, cfg in enumerate(facet_configs):
+            core.launch("add_to_subgrid", contrib[j], m, 1, m, colacc[groups.index(cfg.off1)], 1, m, cfg.off0,
+                        nbatch=S, in_bs=m * m, out_bs=xM * m)
+    # K4b + K5 (axis 1): sum over groups and finish along axis 1, fused on chip where available
     mask1 = _mask_table(core, sgs, "mask1", xA, dt)
     mask0 = _mask_table(core, sgs, "mask0", xA, dt)
     tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
-    core.launch("finish_subgrid", acc, xM, xM, 1, tmp, xA, 1, 0, size=xA, mask=mask1,
-                nbatch=S, in_bs=xM * xM, out_bs=xM * xA, offs=off1s, mask_bs=xA if mask1 is not None else 0)
+    try:
+        core.sum_finish_rows(colacc, groups, tmp, off1s, xA, mask=mask1)
+    except NotImplementedError:
+        acc = torch.zeros((S, xM, xM), dtype=dt, device=dev)
+        for g, off1 in enumerate(groups):
+            core.launch("add_to_subgrid", colacc[g], xM, m, 1, acc, xM, 1, off1,
+                        nbatch=S, in_bs=xM * m, out_bs=xM * xM)
+        core.launch("finish_subgrid", acc, xM, xM, 1, tmp, xA, 1, 0, size=xA, mask=mask1,
+                    nbatch=S, in_bs=xM * xM, out_bs=xM * xA, offs=off1s, mask_bs=xA if mask1 is not None else 0)
     res = torch.empty((S, xA, xA), dtype=dt, device=dev)
     core.launch("finish_subgrid", tmp, xA, 1, xA, res, 1, xA, off0, size=xA, mask=mask0,
                 nbatch=S, in_bs=xM * xA, out_bs=xA * xA, mask_bs=xA if mask0 is not None else 0)

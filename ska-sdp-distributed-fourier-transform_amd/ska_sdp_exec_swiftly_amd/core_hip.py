@@ -289,6 +289,25 @@ class SwiftlyCoreHip:
         args.append(self._stream())
         _lib.check(getattr(self._lib, f"swiftly_hip_{fname}_batch")(*args))
 
+    def sum_finish_rows(self, colacc, group_off1s, out, subgrid_off1s, subgrid_size, mask=None):
+        """Fused axis-1 half of ``sum_and_finish_subgrid`` (reference
+        api_helper.py:96-112) for a wave: ``colacc[G, S, xM, m]`` (per off1
+        group, summed along axis 0 already) -> ``out[S, xM, subgrid_size]``;
+        raises NotImplementedError where the fused kernel is not available."""
+        G, S = colacc.shape[0], colacc.shape[1]
+        goffs = (ctypes.c_int64 * G)(*[int(o) for o in group_off1s])
+        soffs = (ctypes.c_int64 * S)(*[int(o) for o in subgrid_off1s])
+        _lib.check(
+            self._lib.swiftly_hip_sum_finish_rows(
+                self._handle, self._code(colacc), ctypes.c_void_p(colacc.data_ptr()), G, colacc.stride(0),
+                colacc.stride(1), colacc.stride(2), goffs, ctypes.c_void_p(out.data_ptr()), out.stride(0),
+                out.stride(1), soffs, int(subgrid_size),
+                ctypes.c_void_p(mask.data_ptr()) if mask is not None else None,
+                mask.stride(0) if mask is not None else 0, S, self._stream(),
+            )
+        )
+        return out
+
     def extract_column(self, BF_F, subgrid_off0, facet_off1, out=None, rowmap=None):
         """``prepare_facet(extract_from_facet(BF_F, subgrid_off0, axis=0),
         facet_off1, axis=1)`` (reference api_helper.py:200-210) as one kernel on

@@ -149,3 +149,33 @@ def test_sparse_plan_is_bit_identical():
         assert numpy.array_equal(x, y)
     with pytest.raises(ValueError):
         plan.get_subgrid_task([c for c in sg_cfgs if c.off0 == 96][0])
+
+
+def test_forward_c64_test_params_fused_paths():
+    """complex64 forward at the reference TEST_PARAMS sizes (m=128, xM=256): exercises the fused
+    sum+finish row kernel instance (7, 8) and the batched K4a path against the oracle.  W=13.56 has
+    max 1/pswf ~ 4.9e3, so float32 only reaches ~1e-2 here (tools/f32_emulation.py: 8e-3 for numpy's
+    own float32 path); the check is against that floor, the tight complex64 checks use W=11."""
+    import ska_sdp_exec_swiftly_amd as sw
+
+    cfg = sw.SwiftlyConfig(backend="hip", **TEST_PARAMS)
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    sg_cfgs = [c for c in sw.make_full_subgrid_cover(cfg) if c.off0 == 228 * 2]
+    rng = numpy.random.default_rng(5)
+    facets = []
+    for f in facet_cfgs:
+        d = (rng.standard_normal((416, 416)) + 1j * rng.standard_normal((416, 416))).astype(numpy.complex64)
+        facets.append((d * f.mask0[:, None] * f.mask1[None, :]).astype(numpy.complex64))
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)))
+    got = [s.cpu().numpy() for s in fwd.get_subgrid_tasks(sg_cfgs)]
+    ref = orc.OracleCore(TEST_PARAMS["W"], TEST_PARAMS["N"], TEST_PARAMS["xM_size"], TEST_PARAMS["yN_size"])
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    sitems = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in sg_cfgs]
+    want = orc.forward_all(ref, items, [f.astype(complex) for f in facets], sitems)
+    for a, b in zip(got, want):
+        assert relrms(a, b) < 3e-2
+    # and the same data in complex128 (unfused fallback) agrees to rounding
+    fwd2 = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, [f.astype(complex) for f in facets])))
+    got2 = [s.cpu().numpy() for s in fwd2.get_subgrid_tasks(sg_cfgs)]
+    for a, b in zip(got2, want):
+        assert relrms(a, b) < 1e-10
