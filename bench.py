@@ -135,11 +135,8 @@ def run_forward(sw, torch, cfg, fwd_factory, waves, timer=None):
         fwd.get_NMBF_BFs_off0(wave[0].off0)
         timer.stop("K2_extract_column", t0)
         t0 = timer.start()
-        contrib = fwd.wave_contributions(wave)
-        timer.stop("K3_extract_from_facet", t0)
-        t0 = timer.start()
-        res = sw.api.sum_and_finish_wave(core, contrib, fwd.facet_configs, wave)
-        timer.stop("K45_sum_and_finish", t0)
+        res = fwd._wave(wave)  # pylint: disable=protected-access
+        timer.stop("K345_extract_sum_finish", t0)
         count += res.shape[0]
     return count
 

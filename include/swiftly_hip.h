@@ -207,6 +207,18 @@ int swiftly_hip_sum_finish_rows(swiftly_hip_t* h, int dtype, const void* in, int
                                 const int64_t* subgrid_offs, int64_t subgrid_size, const void* mask,
                                 int64_t mask_batch_stride, int64_t nbatch, void* stream);
 
+/* K3 + K4a fused (complex64): for facet index f < nfacets and subgrid b < nsub
+ *     out[f][b] (+)= add_to_subgrid_axis0( extract_from_facet_axis1(in[f], subgrid_off1s[b]), facet_off0 )
+ * with in[f] = NMBF_BF [m, yN] at in + f*in_facet_stride (row stride in_row_stride) -- the output of
+ * extract_column -- and out[f][b] = [xM, m] at out + (f*nsub + b)*out_batch_stride (element (r, c) at
+ * r*out_col_stride + c).  The window gather of core.py:243-253 is folded into the load, so the [m, m]
+ * contribution never goes through HBM (single-GPU path; the multi-GPU path materialises it for the
+ * all-to-all).  All nfacets facets must share facet_off0.  ACCUMULATES. */
+int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t in_row_stride,
+                                            int64_t in_facet_stride, int64_t nfacets, void* out,
+                                            int64_t out_col_stride, int64_t out_batch_stride, int64_t facet_off0,
+                                            int64_t nsub, const int64_t* subgrid_off1s, void* stream);
+
 /* -- device memory helpers for callers that do not bring their own allocator
  *    (the Python mirror uses torch for device memory and never calls these) -- */
 int swiftly_hip_malloc(void** ptr, size_t bytes);

@@ -366,7 +366,8 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     c.conj_ld = a.conj_ld; c.conj_st = a.conj_st; c.accumulate = a.accumulate;
     c.ld_mul = c.st_mul = 1;
     auto launch = [&](int lg, int mode, const ColPassArgs& args, int outer) -> int {
-        int e = launch_col_pass(lg, mode, args, outer, nb, st);
+        static const ColGather no_gather{};
+        int e = launch_col_pass(lg, mode, args, no_gather, outer, nb, st);
         if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
         return 0;
     };
@@ -921,6 +922,78 @@ int swiftly_hip_sum_finish_rows(swiftly_hip_t* h, int dtype, const void* in, int
         for (int b = 0; b < nb; b++) a.st_a[b] = pmod(-(xM / 2 - xA / 2 + subgrid_offs[b0 + b]), xM);
         int e = launch_sum_finish_rows(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
         if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    return 0;
+}
+
+int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t in_row_stride,
+                                            int64_t in_facet_stride, int64_t nfacets, void* out,
+                                            int64_t out_col_stride, int64_t out_batch_stride, int64_t facet_off0,
+                                            int64_t nsub, const int64_t* subgrid_off1s, void* stream) {
+    if (!h || !in || !out || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: complex64 only");
+    const int m = (int)h->m, xM = (int)h->xM, yN = (int)h->yN;
+    if (h->log_m < kColPassMinLog || h->log_m > kColPassMaxLog || h->log_yN < 0)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: contribution size %d not supported", m);
+    if (nfacets <= 0 || nsub <= 0) return 0;
+    if ((uint64_t)m * (uint64_t)in_row_stride + (uint64_t)yN >= (uint64_t(1) << 32) ||
+        (uint64_t)xM * (uint64_t)out_col_stride + (uint64_t)m >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
+    const int64_t sp = floordiv(facet_off0 * h->xM, h->N);
+    ColPassArgs c;
+    std::memset(&c, 0, sizeof c);
+    c.ncols = m;
+    c.full_logn = h->log_m;
+    c.in_pitch = (unsigned)in_row_stride;
+    c.out_pitch = (unsigned)out_col_stride;
+    c.ld_mul = c.st_mul = 1;
+    c.ld_a = 0; c.ld_len = m; c.ld_c = 0; c.ld_mod = m;
+    c.st_a = pmod(-sp, m); c.st_len = m; c.st_c = pmod(xM / 2 - m / 2 + sp, xM); c.st_mod = xM;
+    c.st_win = h->fn_f;
+    c.scale = 1.f;
+    c.accumulate = 1;
+    c.tw = twiddles<float>(h, h->log_m);
+    if (!c.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table");
+    c.cg_mod = m;
+    c.cg_full = yN;
+    c.in_bs_hi = in_facet_stride;
+    c.in_bs = 0;
+    c.out_bs = out_batch_stride;
+    // batch item z = f*nb + b  (f: facet / group index, b: subgrid of this chunk)
+    const int per = (int)std::max<int64_t>(1, 64 / nfacets);
+    if (nfacets > 64) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: at most 64 facets per call");
+    for (int64_t b0 = 0; b0 < nsub; b0 += per) {
+        const int nb = (int)std::min<int64_t>(per, nsub - b0);
+        ColGather cg;
+        for (int f = 0; f < nfacets; f++)
+            for (int b = 0; b < nb; b++) {
+                const int64_t s = floordiv(subgrid_off1s[b0 + b] * h->yN, h->N);
+                cg.rot[f * nb + b] = pmod(-s, m);
+                cg.base[f * nb + b] = pmod(yN / 2 - m / 2 + s, yN);
+            }
+        c.in = (const cx<float>*)in;
+        c.in_bdiv = nb;
+        // out item (f, b) lives at out + (f*nsub + b0 + b) * out_batch_stride: not linear in z unless nb == nsub,
+        // so launch per facet when the chunk does not cover all subgrids
+        if (nb == nsub) {
+            c.out = (cx<float>*)out;
+            int e = launch_col_pass(h->log_m, 2, c, cg, 1, (int)nfacets * nb, (hipStream_t)stream);
+            if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        } else {
+            for (int f = 0; f < nfacets; f++) {
+                ColGather cg1;
+                for (int b = 0; b < nb; b++) {
+                    cg1.rot[b] = cg.rot[f * nb + b];
+                    cg1.base[b] = cg.base[f * nb + b];
+                }
+                c.in = (const cx<float>*)in + f * in_facet_stride;
+                c.in_bdiv = 0;
+                c.in_bs = 0;
+                c.out = (cx<float>*)out + (f * nsub + b0) * out_batch_stride;
+                int e = launch_col_pass(h->log_m, 2, c, cg1, 1, nb, (hipStream_t)stream);
+                if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+            }
+        }
     }
     return 0;
 }

@@ -20,6 +20,12 @@ struct ColPassArgs {
     cx<float>* out;
     unsigned in_pitch, out_pitch;  // elements between consecutive rows; (rows * pitch) < 2^32 (host-checked)
     long long in_bs, out_bs;        // batch strides (elements), blockIdx.z
+    // two-level batch on the input side: item z reads in + (z / in_bdiv)*in_bs_hi + (z % in_bdiv)*in_bs (in_bdiv > 0)
+    long long in_bs_hi;
+    int in_bdiv;
+    // optional column gather on load (fuses extract_from_facet along the contiguous axis, core.py:243-253):
+    //   source column = (cg.base[z] + ((col + cg.rot[z]) mod cg_mod)) mod cg_full
+    int cg_mod, cg_full;
     int ncols;                      // columns (= rows of the primitive)
     int full_logn;                  // log2 of the full transform length the maps refer to
     // load: raw -> row = o*in_o_rows + i*in_i_rows ; mapped -> plain index i*ld_mul + o through the map
@@ -41,6 +47,11 @@ struct ColPassArgs {
     int tw_on_store;
     float scale;
     int conj_ld, conj_st, accumulate;
+};
+
+// per-batch-item column gather parameters (by value)
+struct ColGather {
+    int rot[64], base[64];
 };
 
 template <int LOGN_, int LOGP_, bool SPLIT_>
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
                                                          const float* __restrict__ st_win2,
                                                          const int* __restrict__ st_rowmap,
                                                          const cx<float>* __restrict__ tw,
-                                                         const cx<float>* __restrict__ tw_full) {
+                                                         const cx<float>* __restrict__ tw_full, const ColGather cg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = G::P, T = G::T;
     static_assert(P <= 64, "one lane per row slot");
@@ -90,8 +101,16 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     const int col = blockIdx.x * 64 + lane;
     const bool live = col < A.ncols;
     const int FN = 1 << A.full_logn;
-    const cx<float>* __restrict__ in = gin + (long long)blockIdx.z * A.in_bs + col;
-    cx<float>* __restrict__ out = gout + (long long)blockIdx.z * A.out_bs + col;
+    const int z = blockIdx.z;
+    int scol = col;
+    if (A.cg_mod > 0) {  // uniform
+        const int i = (col + cg.rot[z]) & (A.cg_mod - 1);
+        scol = (cg.base[z] + i) & (A.cg_full - 1);
+    }
+    const long long in_off =
+        A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs : (long long)z * A.in_bs;
+    const cx<float>* __restrict__ in = gin + in_off + scol;
+    cx<float>* __restrict__ out = gout + (long long)z * A.out_bs + col;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
     const int slot = lane & (P - 1);
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
 constexpr int kColPassMinLog = 2;
 constexpr int kColPassMaxLog = 9;
 
-int launch_col_pass(int logn, int mode, const ColPassArgs& a, int outer, int nbatch, hipStream_t s);
+int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColGather& cg, int outer, int nbatch, hipStream_t s);
 int init_col_pass();
 
 }  // namespace swf

@@ -71,6 +71,8 @@ def _declare(lib):
         fn.argtypes = args
     lib.swiftly_hip_sum_finish_rows.restype = c_int
     lib.swiftly_hip_sum_finish_rows.argtypes = [vp, c_int, vp, i64, i64, i64, i64, pi64, vp, i64, i64, pi64, i64, vp, i64, i64, vp]
+    lib.swiftly_hip_add_to_subgrid_from_columns.restype = c_int
+    lib.swiftly_hip_add_to_subgrid_from_columns.argtypes = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, pi64, vp]
     lib.swiftly_hip_malloc.restype = c_int
     lib.swiftly_hip_malloc.argtypes = [POINTER(vp), c_size_t]
     lib.swiftly_hip_free.restype = c_int

@@ -307,10 +307,13 @@ class SwiftlyForward:
         if cols is None:
             if self._rowmap is not None and int(off0) not in self._planned_off0:
                 raise ValueError(f"subgrid column off0={off0} was not in the subgrid_configs plan")
-            cols = [
-                self.core.extract_column(BF_F, off0, cfg.off1, rowmap=self._rowmap)
-                for cfg, BF_F in zip(self.facet_configs, BF_Fs)
-            ]
+            torch = _torch()
+            core = self.core
+            cols = torch.empty(
+                (len(BF_Fs), core.xM_yN_size, core.yN_size), dtype=self.dtype, device=core.device
+            )
+            for j, (cfg, BF_F) in enumerate(zip(self.facet_configs, BF_Fs)):
+                core.extract_column(BF_F, off0, cfg.off1, out=cols[j], rowmap=self._rowmap)
             self.lru.set(off0, cols)
         return cols
 
@@ -356,7 +359,39 @@ class SwiftlyForward:
         return contrib
 
     def _wave(self, sgs):
-        return sum_and_finish_wave(self.core, self.wave_contributions(sgs), self.facet_configs, sgs)
+        # single-GPU route: the [m, m] contributions are never materialised -- the window gather is
+        # folded into the axis-0 accumulation kernel reading the column buffers directly
+        try:
+            colacc = _colacc_from_columns(self.core, self.get_NMBF_BFs_off0(sgs[0].off0), self.facet_configs, sgs)
+        except NotImplementedError:
+            return sum_and_finish_wave(self.core, self.wave_contributions(sgs), self.facet_configs, sgs)
+        return _finish_from_colacc(self.core, colacc, self.facet_configs, sgs)
+
+
+def _facet_grid(facet_configs):
+    """(off0 values, off1 values) when the facets form an off0 x off1 grid in row-major order
+    (make_full_facet_cover), else None."""
+    off0s = sorted({cfg.off0 for cfg in facet_configs})
+    off1s = sorted({cfg.off1 for cfg in facet_configs})
+    if [(cfg.off0, cfg.off1) for cfg in facet_configs] == [(a, b) for a in off0s for b in off1s]:
+        return off0s, off1s
+    return None
+
+
+def _colacc_from_columns(core, cols, facet_configs, sgs):
+    """K3+K4a fused: per-off1-group axis-0 sums ``colacc[G, S, xM, m]`` straight from the column
+    buffers ``cols[F, m, yN]``."""
+    torch = _torch()
+    grid = _facet_grid(facet_configs)
+    if grid is None:
+        raise NotImplementedError("fused path needs an off0 x off1 facet grid")
+    off0s, groups = grid
+    m, xM, S, G = core.xM_yN_size, core.xM_size, len(sgs), len(groups)
+    colacc = torch.zeros((G, S, xM, m), dtype=cols.dtype, device=core.device)
+    off1s = [sg.off1 for sg in sgs]
+    for i, off0_f in enumerate(off0s):
+        core.add_to_subgrid_from_columns(cols[i * G : (i + 1) * G], off0_f, colacc, off1s)
+    return colacc
 
 
 def sum_and_finish_wave(core, contrib, facet_configs, sgs):
@@ -365,27 +400,34 @@ def sum_and_finish_wave(core, contrib, facet_configs, sgs):
     order = ``facet_configs``) -> finished, masked subgrids ``[S, xA, xA]``."""
     torch = _torch()
     m, xM = core.xM_yN_size, core.xM_size
-    off0, xA, S = sgs[0].off0, sgs[0].size, len(sgs)
+    S = len(sgs)
     dev, dt = core.device, contrib.dtype
     groups = sorted({cfg.off1 for cfg in facet_configs})  # facets grouped by off1 (api_helper.py:83)
-    off1s = [sg.off1 for sg in sgs]
     # K4a: axis-0 transform + placement, summed over the facets of one off1 group
     colacc = torch.zeros((len(groups), S, xM, m), dtype=dt, device=dev)
-    off0s = sorted({cfg.off0 for cfg in facet_configs})
-    grid = [(cfg.off0, cfg.off1) for cfg in facet_configs] == [(a, b) for a in off0s for b in groups]
-    if grid and contrib.is_contiguous():
-        # facets form an off0 x off1 grid in row-major order (make_full_facet_cover): facets with the same
-        # off0 belong to different groups, so ONE launch per off0 handles all (group, subgrid) pairs --
-        # batch item z = g*S + b reads contrib[i*G + g, b] and adds into colacc[g, b]
+    grid = _facet_grid(facet_configs)
+    if grid is not None and contrib.is_contiguous():
+        # facets with the same off0 belong to different groups, so ONE launch per off0 handles all
+        # (group, subgrid) pairs -- batch item z = g*S + b reads contrib[i*G + g, b], adds into colacc[g, b]
         G = len(groups)
-        for i, off0_f in enumerate(off0s):
+        for i, off0_f in enumerate(grid[0]):
             core.launch("add_to_subgrid", contrib[i * G], m, 1, m, colacc, 1, m, off0_f,
                         nbatch=G * S, in_bs=m * m, out_bs=xM * m)
     else:
         for j, cfg in enumerate(facet_configs):
             core.launch("add_to_subgrid", contrib[j], m, 1, m, colacc[groups.index(cfg.off1)], 1, m, cfg.off0,
                         nbatch=S, in_bs=m * m, out_bs=xM * m)
-    # K4b + K5 (axis 1): sum over groups and finish along axis 1, fused on chip where available
+    return _finish_from_colacc(core, colacc, facet_configs, sgs)
+
+
+def _finish_from_colacc(core, colacc, facet_configs, sgs):
+    """axis-1 sum over groups + finish (fused where available), then finish along axis 0."""
+    torch = _torch()
+    m, xM = core.xM_yN_size, core.xM_size
+    off0, xA, S = sgs[0].off0, sgs[0].size, len(sgs)
+    dev, dt = core.device, colacc.dtype
+    groups = sorted({cfg.off1 for cfg in facet_configs})
+    off1s = [sg.off1 for sg in sgs]
     mask1 = _mask_table(core, sgs, "mask1", xA, dt)
     mask0 = _mask_table(core, sgs, "mask0", xA, dt)
     tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)

@@ -289,6 +289,21 @@ class SwiftlyCoreHip:
         args.append(self._stream())
         _lib.check(getattr(self._lib, f"swiftly_hip_{fname}_batch")(*args))
 
+    def add_to_subgrid_from_columns(self, cols, facet_off0, colacc, subgrid_off1s):
+        """K3 + K4a fused: ``colacc[f, b] += add_to_subgrid(extract_from_facet(cols[f], off1_b, axis=1),
+        facet_off0, axis=0)`` for the facets ``cols[F', m, yN]`` (all with the same ``off0``) and the
+        subgrids of a wave; ``colacc[F', S, xM, m]``.  NotImplementedError where unavailable."""
+        F, S = cols.shape[0], colacc.shape[1]
+        offs = (ctypes.c_int64 * S)(*[int(o) for o in subgrid_off1s])
+        _lib.check(
+            self._lib.swiftly_hip_add_to_subgrid_from_columns(
+                self._handle, self._code(cols), ctypes.c_void_p(cols.data_ptr()), cols.stride(1), cols.stride(0), F,
+                ctypes.c_void_p(colacc.data_ptr()), colacc.stride(2), colacc.stride(1), int(facet_off0), S, offs,
+                self._stream(),
+            )
+        )
+        return colacc
+
     def sum_finish_rows(self, colacc, group_off1s, out, subgrid_off1s, subgrid_size, mask=None):
         """Fused axis-1 half of ``sum_and_finish_subgrid`` (reference
         api_helper.py:96-112) for a wave: ``colacc[G, S, xM, m]`` (per off1
