@@ -63,6 +63,7 @@ struct CGeo {
     static constexpr int RB = 64;  // columns per tile == lanes
     static constexpr int ELEM = SPLIT ? 4 : 8;
     static constexpr int PITCH = 0;  // unused (interleaved-rows layout)
+    static constexpr int LOGPAD = 4;  // unused
     static constexpr size_t LDS_BYTES = T > 1 ? (size_t)N * RB * ELEM : 0;
     // minimum waves per SIMD the register allocator must leave room for
     static constexpr int MINW = T >= 4 ? 4 : 1;

@@ -127,17 +127,13 @@ __device__ __forceinline__ void fft_reg(cx<R> (&x)[PTOT]) {
     });
 }
 
-// LDS element type helpers ---------------------------------------------------
-// Padded element index: one pad element per 128 B.
-template <int ELEM_BYTES>
-__device__ __forceinline__ int lds_pad(int e) {
-    constexpr int LOGPAD = ELEM_BYTES == 4 ? 5 : ELEM_BYTES == 8 ? 4 : 3;
-    return e + (e >> LOGPAD);
-}
-template <int ELEM_BYTES>
-constexpr int lds_pitch(int n) {
-    constexpr int LOGPAD = ELEM_BYTES == 4 ? 5 : ELEM_BYTES == 8 ? 4 : 3;
-    return n + (n >> LOGPAD);
+// LDS exchange buffer layout ---------------------------------------------------
+// Row-per-workgroup-row layout: element e of row rb sits at rb*PITCH + e + (e >> LOGPAD): one pad element
+// per 2^LOGPAD elements (128 B worth, but never more than the radix so that every phase's scatter and
+// gather addresses are  base + compile-time constant  -- see phase_exchange).
+constexpr int natural_logpad(int elem_bytes) { return elem_bytes == 4 ? 5 : elem_bytes == 8 ? 4 : 3; }
+constexpr int eff_logpad(int elem_bytes, int logp) {
+    return natural_logpad(elem_bytes) < logp ? natural_logpad(elem_bytes) : (logp > 0 ? logp : 1);
 }
 
 // Geometry of one engine configuration.
@@ -149,7 +145,8 @@ struct Geo {
     static_assert(T >= 1 && NT % T == 0, "bad geometry");
     static constexpr int RB = NT / T;  // rows per workgroup
     static constexpr int ELEM = SPLIT ? (int)sizeof(R) : (int)(2 * sizeof(R));
-    static constexpr int PITCH = lds_pitch<ELEM>(N);
+    static constexpr int LOGPAD = eff_logpad(ELEM, LOGP);
+    static constexpr int PITCH = N + (N >> LOGPAD);
     static constexpr size_t LDS_BYTES = (size_t)RB * PITCH * ELEM;
 };
 
@@ -158,7 +155,13 @@ struct Geo {
 // rows) hit consecutive banks.
 template <class G>
 __device__ __forceinline__ int lds_pos(int rb, int e, bool rowfast) {
-    return rowfast ? e * G::RB + rb : rb * G::PITCH + lds_pad<G::ELEM>(e);
+    return rowfast ? e * G::RB + rb : rb * G::PITCH + e + (e >> G::LOGPAD);
+}
+// Offset of element e0 + d relative to element e0 when the low bits of e0 that d touches are zero
+// (true for every scatter / gather of the Stockham schedule): a compile-time constant.
+template <class G>
+constexpr int lds_delta(int d, bool rowfast) {
+    return rowfast ? d * G::RB : d + (d >> G::LOGPAD);
 }
 
 // Apply inter-phase twiddles w^r = exp(-2 pi i * kidx * r / N) to the
@@ -239,34 +242,62 @@ __device__ __forceinline__ void phase_scatter(const cx<R> (&x)[G::P], int t, F&&
 }
 
 // Exchange through LDS: scatter phase output, then gather x[v] = buf[t + v*T].
+// Addresses are one runtime base per butterfly (scatter) / per thread (gather)
+// plus compile-time offsets, so each LDS access is a single instruction with
+// an immediate offset (the padded index e + (e >> LOGPAD) is affine in the
+// radix digit because the digit only fills bits that are zero in the base).
+template <class G, typename R, int LOGNS, int LOGR, class T_, class Pick>
+__device__ __forceinline__ void exchange_pass(cx<R> (&x)[G::P], int t, int rb, bool rowfast, T_* buf, Pick&& pick,
+                                              bool write_x_component) {
+    constexpr int RAD = 1 << LOGR, NB = G::P / RAD;
+    (void)write_x_component;
+    static_for<0, NB>([&](auto uI) {
+        constexpr int u = decltype(uI)::value;
+        const int j = t + u * G::T;
+        const int k = j & ((1 << LOGNS) - 1);
+        const int e0 = ((j - k) << LOGR) + k;
+        const int p0 = lds_pos<G>(rb, e0, rowfast);
+        static_for<0, RAD>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            const int off = rowfast ? lds_delta<G>(r << LOGNS, true) : lds_delta<G>(r << LOGNS, false);
+            buf[p0 + off] = pick(x[u + bitrev(r, LOGR) * NB]);
+        });
+    });
+}
+
+template <class G, typename R, class T_, class Put>
+__device__ __forceinline__ void gather_pass(int t, int rb, bool rowfast, const T_* buf, Put&& put) {
+    const int p0 = lds_pos<G>(rb, t, rowfast);
+    static_for<0, G::P>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        if constexpr (G::T % (1 << G::LOGPAD) == 0) {
+            const int off = rowfast ? lds_delta<G>(v * G::T, true) : lds_delta<G>(v * G::T, false);
+            put(vI, buf[p0 + off]);
+        } else {
+            put(vI, buf[lds_pos<G>(rb, t + v * G::T, rowfast)]);
+        }
+    });
+}
+
 template <class G, typename R, int LOGNS, int LOGR>
 __device__ __forceinline__ void phase_exchange(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds) {
     if constexpr (!G::SPLIT) {
         cx<R>* buf = reinterpret_cast<cx<R>*>(lds);
-        phase_scatter<G, R, LOGNS, LOGR>(x, t, [&](int e, cx<R> v) { buf[lds_pos<G>(rb, e, rowfast)] = v; });
+        exchange_pass<G, R, LOGNS, LOGR>(x, t, rb, rowfast, buf, [](cx<R> v) { return v; }, true);
         __syncthreads();
-        static_for<0, G::P>([&](auto vI) {
-            constexpr int v = decltype(vI)::value;
-            x[v] = buf[lds_pos<G>(rb, t + v * G::T, rowfast)];
-        });
+        gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, cx<R> val) { x[decltype(vI)::value] = val; });
         __syncthreads();
     } else {
-        // re and im separately: halves the LDS footprint (N*8 B > 160 KiB case)
+        // re and im separately: halves the LDS footprint
         R* buf = reinterpret_cast<R*>(lds);
-        phase_scatter<G, R, LOGNS, LOGR>(x, t, [&](int e, cx<R> v) { buf[lds_pos<G>(rb, e, rowfast)] = v.x; });
+        exchange_pass<G, R, LOGNS, LOGR>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.x; }, true);
         __syncthreads();
         // every old real part is in LDS now, so x[].x can take the new ones
-        static_for<0, G::P>([&](auto vI) {
-            constexpr int v = decltype(vI)::value;
-            x[v].x = buf[lds_pos<G>(rb, t + v * G::T, rowfast)];
-        });
+        gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, R val) { x[decltype(vI)::value].x = val; });
         __syncthreads();
-        phase_scatter<G, R, LOGNS, LOGR>(x, t, [&](int e, cx<R> v) { buf[lds_pos<G>(rb, e, rowfast)] = v.y; });
+        exchange_pass<G, R, LOGNS, LOGR>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.y; }, false);
         __syncthreads();
-        static_for<0, G::P>([&](auto vI) {
-            constexpr int v = decltype(vI)::value;
-            x[v].y = buf[lds_pos<G>(rb, t + v * G::T, rowfast)];
-        });
+        gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, R val) { x[decltype(vI)::value].y = val; });
         __syncthreads();
     }
 }

@@ -40,7 +40,8 @@ struct RGeo {
     static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P, NT = T;
     static constexpr int RB = 1;
     static constexpr int ELEM = SPLIT ? 4 : 8;
-    static constexpr int PITCH = lds_pitch<ELEM>(N);
+    static constexpr int LOGPAD = eff_logpad(ELEM, LOGP);
+    static constexpr int PITCH = N + (N >> LOGPAD);
     static constexpr size_t LDS_BYTES = (size_t)PITCH * ELEM;
 };
 

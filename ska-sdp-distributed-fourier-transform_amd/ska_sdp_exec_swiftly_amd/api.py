@@ -227,19 +227,34 @@ def _torch():
     return torch
 
 
+_MASK_CACHE = {}
+_MASK_CACHE_MAX = 512
+
+
 def _mask_table(core, configs, which, size, cdtype):
     """[len(configs), size] real device table of the masks (ones where a config
-    has no mask), or None when no config has one."""
+    has no mask), or None when no config has one.  Tables are cached per
+    (device, precision, mask contents): an upload from pageable host memory is
+    ordered behind everything already queued on the stream, i.e. it would stall
+    the host once per wave."""
     torch = _torch()
     masks = [getattr(c, which) for c in configs]
     if all(m is None for m in masks):
         return None
-    rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
     tab = numpy.ones((len(configs), size))
     for i, m in enumerate(masks):
         if m is not None:
             tab[i] = numpy.asarray(m, dtype=float)
-    return torch.from_numpy(tab).to(device=core.device, dtype=rdtype).contiguous()
+    key = (str(core.device), str(cdtype), tab.shape, tab.tobytes())
+    hit = _MASK_CACHE.get(key)
+    if hit is not None:
+        return hit
+    rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
+    dev_tab = torch.from_numpy(tab).to(device=core.device, dtype=rdtype).contiguous()
+    if len(_MASK_CACHE) >= _MASK_CACHE_MAX:
+        _MASK_CACHE.pop(next(iter(_MASK_CACHE)))
+    _MASK_CACHE[key] = dev_tab
+    return dev_tab
 
 
 class SwiftlyForward:
