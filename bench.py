@@ -296,14 +296,18 @@ def main():
         k1 = stages["K1_prepare_facet_axis0"]
         k1_bytes = parts["K1"] / F  # per facet = per launch group
         achieved = k1_bytes / (k1["avg_ms"] * 1e-3) / 1e9
+        # HBM bytes per K1 launch group from rocprofv3 PMC passes of the same kernels (tools/run_k1_plan.py,
+        # profiles/r1d_pmc_k1_traffic.txt): FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request) + WRITE_SIZE
+        k1_traffic = {"64k-sparse": 2 * (1994492 + 2885678) * 1024 + (5767168 + 2019072) * 1024}.get(args.workload)
         roofline = dict(
-            kernel="K1 prepare_facet(axis=0) per facet = fft_rows<128> (pass A) + fft_rows<256> (pass B)",
+            kernel="K1 prepare_facet(axis=0) per facet = col_pass<n1=128, mapped load> + col_pass<n2=256, mapped store>",
             bound="hbm",
             achieved=round(achieved, 1),
             peak=HBM_PEAK_GBS,
             unit="GB/s",
             frac=round(achieved / HBM_PEAK_GBS, 4),
-            traffic=None,
+            traffic=k1_traffic,
+            traffic_note="bytes per launch group measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)",
             algorithmic_bytes_per_launch=k1_bytes,
             avg_launch_ms=k1["avg_ms"],
         )

@@ -959,9 +959,10 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
     c.in_bs_hi = in_facet_stride;
     c.in_bs = 0;
     c.out_bs = out_batch_stride;
-    // batch item z = f*nb + b  (f: facet / group index, b: subgrid of this chunk)
-    const int per = (int)std::max<int64_t>(1, 64 / nfacets);
-    if (nfacets > 64) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: at most 64 facets per call");
+    // batch item z = f*nb + b  (f: facet / group index, b: subgrid of this chunk); item (f, b) reads facet f's
+    // column buffer and adds into out + (f*nsub + b0 + b) * out_batch_stride
+    if (nfacets > kColGatherMax) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: too many facets per call");
+    const int per = (int)std::max<int64_t>(1, kColGatherMax / nfacets);
     for (int64_t b0 = 0; b0 < nsub; b0 += per) {
         const int nb = (int)std::min<int64_t>(per, nsub - b0);
         ColGather cg;
@@ -973,27 +974,11 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
             }
         c.in = (const cx<float>*)in;
         c.in_bdiv = nb;
-        // out item (f, b) lives at out + (f*nsub + b0 + b) * out_batch_stride: not linear in z unless nb == nsub,
-        // so launch per facet when the chunk does not cover all subgrids
-        if (nb == nsub) {
-            c.out = (cx<float>*)out;
-            int e = launch_col_pass(h->log_m, 2, c, cg, 1, (int)nfacets * nb, (hipStream_t)stream);
-            if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-        } else {
-            for (int f = 0; f < nfacets; f++) {
-                ColGather cg1;
-                for (int b = 0; b < nb; b++) {
-                    cg1.rot[b] = cg.rot[f * nb + b];
-                    cg1.base[b] = cg.base[f * nb + b];
-                }
-                c.in = (const cx<float>*)in + f * in_facet_stride;
-                c.in_bdiv = 0;
-                c.in_bs = 0;
-                c.out = (cx<float>*)out + (f * nsub + b0) * out_batch_stride;
-                int e = launch_col_pass(h->log_m, 2, c, cg1, 1, nb, (hipStream_t)stream);
-                if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-            }
-        }
+        c.out = (cx<float>*)out + b0 * out_batch_stride;
+        c.out_bdiv = nb;
+        c.out_bs_hi = nsub * out_batch_stride;
+        int e = launch_col_pass(h->log_m, 2, c, cg, 1, (int)nfacets * nb, (hipStream_t)stream);
+        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     return 0;
 }

@@ -23,6 +23,9 @@ struct ColPassArgs {
     // two-level batch on the input side: item z reads in + (z / in_bdiv)*in_bs_hi + (z % in_bdiv)*in_bs (in_bdiv > 0)
     long long in_bs_hi;
     int in_bdiv;
+    // same on the output side: item z writes out + (z / out_bdiv)*out_bs_hi + (z % out_bdiv)*out_bs (out_bdiv > 0)
+    long long out_bs_hi;
+    int out_bdiv;
     // optional column gather on load (fuses extract_from_facet along the contiguous axis, core.py:243-253):
     //   source column = (cg.base[z] + ((col + cg.rot[z]) mod cg_mod)) mod cg_full
     int cg_mod, cg_full;
@@ -50,8 +53,9 @@ struct ColPassArgs {
 };
 
 // per-batch-item column gather parameters (by value)
+constexpr int kColGatherMax = 192;
 struct ColGather {
-    int rot[64], base[64];
+    int rot[kColGatherMax], base[kColGatherMax];
 };
 
 template <int LOGN_, int LOGP_, bool SPLIT_>
@@ -111,7 +115,9 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     const long long in_off =
         A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs : (long long)z * A.in_bs;
     const cx<float>* __restrict__ in = gin + in_off + scol;
-    cx<float>* __restrict__ out = gout + (long long)z * A.out_bs + col;
+    const long long out_off =
+        A.out_bdiv > 0 ? (long long)(z / A.out_bdiv) * A.out_bs_hi + (long long)(z % A.out_bdiv) * A.out_bs : (long long)z * A.out_bs;
+    cx<float>* __restrict__ out = gout + out_off + col;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
     const int slot = lane & (P - 1);
