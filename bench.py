@@ -258,10 +258,15 @@ def main():
         def one_pass(timer=None):  # pylint: disable=unused-argument
             dfw = DistributedForward(cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs)
             dfw.local._get_BF_Fs()  # pylint: disable=protected-access
+            # software pipeline: the all-to-all of wave w runs while wave w+1's column/extract kernels do
             n = 0
+            pending = None
             for wave in waves:
-                mine, _ = dfw.get_subgrid_wave(wave)
-                n += len(mine)
+                handle = dfw.start_wave(wave)
+                if pending is not None:
+                    n += len(dfw.finish_wave(pending)[0])
+                pending = handle
+            n += len(dfw.finish_wave(pending)[0])
             return n
 
     def fence():

@@ -14,7 +14,7 @@ product wires in the HIP kernels (:class:`DistributedForward`).
 """
 import numpy
 
-__all__ = ["FacetSharding", "exchange_contributions", "DistributedForward"]
+__all__ = ["FacetSharding", "exchange_contributions", "start_exchange", "DistributedForward"]
 
 
 def _torch():
@@ -41,22 +41,45 @@ class FacetSharding:
         return list(range(rank, n_subgrids, self.world))
 
 
-def exchange_contributions(contrib_local, sharding, group=None):
-    """All-to-all of one wave.
+class _Exchange:
+    """In-flight all-to-all of one wave (``wait()`` returns the re-ordered contributions)."""
 
-    :param contrib_local: ``[F_local, S, m, m]`` contributions of this rank's
-        facets to all ``S`` subgrids of the wave
-    :return: ``[F, S_local, m, m]`` contributions of ALL facets (global facet
-        order) to the subgrids this rank owns (``sharding.subgrids_of(S)``)
+    def __init__(self, work, recv, send, sharding, n_mine, blk):
+        self.work, self.recv, self.send = work, recv, send  # send is kept alive until the collective is done
+        self.sharding, self.n_mine, self.blk = sharding, n_mine, blk
+
+    def wait(self):
+        torch = _torch()
+        if self.work is not None:
+            self.work.wait()
+        arrived = self.recv.reshape(self.sharding.n_facets, self.n_mine, *self.blk)  # source-rank (arrival) order
+        return arrived[torch.as_tensor(self.sharding.to_global, device=arrived.device)]
+
+
+class _Done:
+    def __init__(self, value):
+        self.value = value
+
+    def wait(self):
+        return self.value
+
+
+def start_exchange(contrib_local, sharding, group=None, async_op=True):
+    """Issue the all-to-all of one wave and return a handle whose ``wait()`` gives
+    ``[F, S_local, m, m]`` (all facets in global order, the subgrids this rank owns).
+
+    With ``async_op`` the collective runs on RCCL's own stream: kernels launched
+    afterwards on the compute stream (the next wave's column / extract kernels)
+    overlap with it, and only ``wait()`` orders the compute stream behind it.
     """
     torch = _torch()
     dist = torch.distributed
-    world, rank = sharding.world, sharding.rank
-    F_local, S = contrib_local.shape[0], contrib_local.shape[1]
-    blk = contrib_local.shape[2:]
+    world = sharding.world
+    S = contrib_local.shape[1]
+    blk = tuple(contrib_local.shape[2:])
     mine = sharding.subgrids_of(S)
     if world == 1:
-        return contrib_local
+        return _Done(contrib_local)
     # send buffer: for every destination rank the blocks [F_local, S_dest, m, m]
     pieces = [contrib_local[:, sharding.subgrids_of(S, r)].reshape(-1) for r in range(world)]
     send = torch.cat(pieces)
@@ -66,17 +89,28 @@ def exchange_contributions(contrib_local, sharding, group=None):
     recv = torch.empty(sum(out_split), dtype=contrib_local.dtype, device=contrib_local.device)
     if contrib_local.is_complex():
         # RCCL has no complex type: ship as interleaved reals
-        dist.all_to_all_single(
+        work = dist.all_to_all_single(
             torch.view_as_real(recv).reshape(-1),
             torch.view_as_real(send).reshape(-1),
             [2 * n for n in out_split],
             [2 * n for n in in_split],
             group=group,
+            async_op=async_op,
         )
     else:
-        dist.all_to_all_single(recv, send, out_split, in_split, group=group)
-    arrived = recv.reshape(sharding.n_facets, len(mine), *blk)  # source-rank (arrival) order
-    return arrived[torch.as_tensor(sharding.to_global, device=arrived.device)]
+        work = dist.all_to_all_single(recv, send, out_split, in_split, group=group, async_op=async_op)
+    return _Exchange(work if async_op else None, recv, send, sharding, len(mine), blk)
+
+
+def exchange_contributions(contrib_local, sharding, group=None):
+    """Blocking all-to-all of one wave.
+
+    :param contrib_local: ``[F_local, S, m, m]`` contributions of this rank's
+        facets to all ``S`` subgrids of the wave
+    :return: ``[F, S_local, m, m]`` contributions of ALL facets (global facet
+        order) to the subgrids this rank owns (``sharding.subgrids_of(S)``)
+    """
+    return start_exchange(contrib_local, sharding, group, async_op=False).wait()
 
 
 class DistributedForward:
@@ -104,21 +138,33 @@ class DistributedForward:
             subgrid_configs=subgrid_configs,
         )
 
-    def get_subgrid_wave(self, sgs):
-        """Finish the subgrids of ``sgs`` (same ``off0`` / ``size``) this rank
-        owns: returns ``(indices within sgs, tensor [S_local, xA, xA])``."""
-        from .api import sum_and_finish_wave  # pylint: disable=import-outside-toplevel
-
+    def start_wave(self, sgs):
+        """Compute this rank's contributions to the subgrids ``sgs`` (same
+        ``off0`` / ``size``) and start their all-to-all; returns a handle for
+        :py:meth:`finish_wave`.  Starting wave w+1 before finishing wave w
+        overlaps the exchange with the column and extract kernels."""
         torch = _torch()
-        mine = self.sharding.subgrids_of(len(sgs))
         if self.sharding.local_facets:
             contrib = self.local.wave_contributions(sgs)
         else:
             core = self.config.core
             m = core.xM_yN_size
             contrib = torch.empty((0, len(sgs), m, m), dtype=self.local.dtype, device=core.device)
-        allc = exchange_contributions(contrib, self.sharding, self.group)
+        return sgs, start_exchange(contrib, self.sharding, self.group)
+
+    def finish_wave(self, handle):
+        """Finish the subgrids of a started wave that this rank owns: returns
+        ``(indices within sgs, tensor [S_local, xA, xA] or None)``."""
+        from .api import sum_and_finish_wave  # pylint: disable=import-outside-toplevel
+
+        sgs, exch = handle
+        mine = self.sharding.subgrids_of(len(sgs))
+        allc = exch.wait()
         if not mine:
             return mine, None
         res = sum_and_finish_wave(self.config.core, allc, self.facet_configs, [sgs[i] for i in mine])
         return mine, res
+
+    def get_subgrid_wave(self, sgs):
+        """start_wave + finish_wave"""
+        return self.finish_wave(self.start_wave(sgs))

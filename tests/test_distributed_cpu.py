@@ -15,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import swiftly_oracle as orc
-from ska_sdp_exec_swiftly_amd.distributed import FacetSharding, exchange_contributions
+from ska_sdp_exec_swiftly_amd.distributed import FacetSharding, exchange_contributions, start_exchange
 
 P = dict(W=11.0, N=512, yB_size=176, yN_size=256, xA_size=96, xM_size=128)
 
@@ -58,7 +58,11 @@ def _worker(rank, world, port, q):
         core, facet_items, sg_items, facets = _problem()
         sh = FacetSharding(len(facet_items), rank, world)
         local = torch.from_numpy(_contribs(core, facet_items, facets, sg_items, sh.local_facets))
+        # blocking and pipelined (async) forms must agree
         allc = exchange_contributions(local, sh).numpy()
+        h1 = start_exchange(local, sh)
+        h2 = start_exchange(2 * local, sh)
+        assert numpy.array_equal(h1.wait().numpy(), allc) and numpy.array_equal(h2.wait().numpy(), 2 * allc)
         mine = sh.subgrids_of(len(sg_items))
         res = [orc.sum_and_finish_subgrid(core, list(allc[:, k]), facet_items, sg_items[i]) for k, i in enumerate(mine)]
         q.put((rank, mine, res, allc.shape))
