@@ -121,13 +121,16 @@ def run_forward(sw, torch, cfg, fwd_factory, waves, timer=None):
             count += len(res)
         return count
     # instrumented pass: same launches, events around each stage
+    # K1 exactly as SwiftlyForward._get_BF_Fs issues it, one event pair per facet
+    pre = fwd.dtype == torch.complex64
+    fwd._prewindowed = pre  # pylint: disable=protected-access
+    n_rows = fwd._n_rows if fwd._rowmap is not None else core.yN_size  # pylint: disable=protected-access
     bfs = []
     for c, data in zip(fwd.facet_configs, fwd._facets):  # pylint: disable=protected-access
         t0 = timer.start()
-        if fwd._rowmap is None:  # pylint: disable=protected-access
-            bfs.append(core.prepare_facet(data, c.off0, axis=0))
-        else:
-            bfs.append(core.prepare_facet_rows(data, c.off0, fwd._rowmap, fwd._n_rows))  # pylint: disable=protected-access
+        bfs.append(
+            core.prepare_facet_rows(data, c.off0, fwd._rowmap, n_rows, fold_axis1_window=pre)  # pylint: disable=protected-access
+        )
         timer.stop("K1_prepare_facet_axis0", t0)
     fwd.BF_Fs_persist = bfs
     for wave in waves:

@@ -150,14 +150,19 @@ int swiftly_hip_extract_column(swiftly_hip_t* h, int dtype, const void* in, int6
 /* Row-compacted BF_F (sparse subgrid sets): `rowmap` is a DEVICE int32 array of length yN; entry k is the
  * physical row of BF_F that holds logical row k, or negative when no requested subgrid column reads row k.
  * prepare_facet_rows = prepare_facet whose output index along the transform axis goes through the map
- * (unmapped rows are never written); extract_column_rows = extract_column reading such a compacted BF_F. */
+ * (unmapped rows are never written; rowmap may be NULL); extract_column_rows = extract_column reading such a
+ * compacted BF_F.  fold_other_axis_window != 0 makes prepare_facet_rows also multiply row r of the call (= index r
+ * along the OTHER axis, facet size `rows`) by 1/pswf -- the window the axis-1 prepare_facet of extract_column
+ * applies; windows commute with transforms along the orthogonal axis, so extract_column_rows(prewindowed != 0)
+ * then skips its window loads. */
 int swiftly_hip_prepare_facet_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                    int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
-                                   int64_t out_col_stride, int64_t facet_off, const int32_t* rowmap, void* stream);
+                                   int64_t out_col_stride, int64_t facet_off, const int32_t* rowmap,
+                                   int fold_other_axis_window, void* stream);
 int swiftly_hip_extract_column_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t facet_size,
                                     int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
                                     int64_t out_col_stride, int64_t subgrid_off0, int64_t facet_off1,
-                                    const int32_t* rowmap, void* stream);
+                                    const int32_t* rowmap, int prewindowed, void* stream);
 
 int swiftly_hip_extract_from_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
                                          int64_t in_row_stride, int64_t in_col_stride, void* out,

@@ -362,6 +362,7 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     c.st_a = a.st.a; c.st_len = a.st.len; c.st_c = a.st.c; c.st_mod = a.st.mod;
     c.st_win = a.st.win; c.st_win2 = a.st.win2; c.st_win_bs = a.st_win_bs;
     c.st_rowmap = a.st_rowmap;
+    c.col_win = a.row_win;
     c.scale = a.scale;
     c.conj_ld = a.conj_ld; c.conj_st = a.conj_st; c.accumulate = a.accumulate;
     c.ld_mul = c.st_mul = 1;
@@ -437,7 +438,7 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     r.nrows = a.nrows;
     r.rm_mod = a.rm_mod; r.rm_inner = a.rm_inner; r.rm_outer = a.rm_outer; r.rm_full = a.rm_full;
     r.in_rowmap = a.in_rowmap;
-    if (a.st_rowmap) return false;
+    if (a.st_rowmap || a.row_win) return false;
     r.ld_a = a.ld.a; r.ld_len = a.ld.len; r.ld_c = a.ld.c; r.ld_mod = a.ld.mod; r.ld_win = a.ld.win;
     r.st_a = a.st.a; r.st_len = a.st.len; r.st_c = a.st.c; r.st_mod = a.st.mod; r.st_win = a.st.win; r.st_win2 = a.st.win2;
     r.tw = twiddles<float>(h, logn);
@@ -605,7 +606,8 @@ static const auto kNoFill = [](int64_t, int, OffTab&) {};
 template <typename R>
 static int do_prepare_facet(swiftly_hip* h, const void* in, int64_t rows, int64_t yB, int64_t in_rs, int64_t in_cs,
                             void* out, int64_t out_rs, int64_t out_cs, int64_t off, int64_t row_gather_off,
-                            const int32_t* out_rowmap, const int32_t* in_rowmap, hipStream_t st) {
+                            const int32_t* out_rowmap, const int32_t* in_rowmap, int fold_other, int no_window,
+                            hipStream_t st) {
     const int yN = (int)h->yN, m = (int)h->m;
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
@@ -616,6 +618,8 @@ static int do_prepare_facet(swiftly_hip* h, const void* in, int64_t rows, int64_
     a.scale = (R)(1.0 / yN);
     a.st_rowmap = out_rowmap;
     a.in_rowmap = in_rowmap;
+    if (no_window) a.ld.win = nullptr;
+    if (fold_other) a.row_win = invp<R>(h) + (yN / 2 - (int)(rows / 2));  // the rows of this call are the other axis
     if (row_gather_off != INT64_MIN) {
         const int64_t s = floordiv(row_gather_off * h->yN, h->N);
         a.rm_mod = m;
@@ -729,16 +733,19 @@ int swiftly_hip_prepare_facet(swiftly_hip_t* h, int dtype, const void* in, int64
     CHECK_COMMON();
     CHECK_FACET_SIZE();
     return DISPATCH(do_prepare_facet, h, in, rows, facet_size, in_rs, in_cs, out, out_rs, out_cs, facet_off, INT64_MIN,
-                    nullptr, nullptr, (hipStream_t)stream);
+                    nullptr, nullptr, 0, 0, (hipStream_t)stream);
 }
 
 int swiftly_hip_prepare_facet_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                    int64_t in_rs, int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs,
-                                   int64_t facet_off, const int32_t* out_rowmap, void* stream) {
+                                   int64_t facet_off, const int32_t* out_rowmap, int fold_other_axis_window,
+                                   void* stream) {
     CHECK_COMMON();
     CHECK_FACET_SIZE();
+    if (fold_other_axis_window && (rows <= 0 || rows >= h->yN))
+        return fail(SWIFTLY_ERR_PARAM, "other-axis facet size %lld must be in [1, yN_size - 1]", (long long)rows);
     return DISPATCH(do_prepare_facet, h, in, rows, facet_size, in_rs, in_cs, out, out_rs, out_cs, facet_off, INT64_MIN,
-                    out_rowmap, nullptr, (hipStream_t)stream);
+                    out_rowmap, nullptr, fold_other_axis_window, 0, (hipStream_t)stream);
 }
 
 int swiftly_hip_extract_column(swiftly_hip_t* h, int dtype, const void* in, int64_t facet_size, int64_t in_rs,
@@ -748,17 +755,17 @@ int swiftly_hip_extract_column(swiftly_hip_t* h, int dtype, const void* in, int6
     CHECK_COMMON();
     CHECK_FACET_SIZE();
     return DISPATCH(do_prepare_facet, h, in, rows, facet_size, in_rs, in_cs, out, out_rs, out_cs, facet_off1,
-                    subgrid_off0, nullptr, nullptr, (hipStream_t)stream);
+                    subgrid_off0, nullptr, nullptr, 0, 0, (hipStream_t)stream);
 }
 
 int swiftly_hip_extract_column_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t facet_size, int64_t in_rs,
                                     int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs, int64_t subgrid_off0,
-                                    int64_t facet_off1, const int32_t* in_rowmap, void* stream) {
+                                    int64_t facet_off1, const int32_t* in_rowmap, int prewindowed, void* stream) {
     const int64_t rows = h ? h->m : 0;
     CHECK_COMMON();
     CHECK_FACET_SIZE();
     return DISPATCH(do_prepare_facet, h, in, rows, facet_size, in_rs, in_cs, out, out_rs, out_cs, facet_off1,
-                    subgrid_off0, nullptr, in_rowmap, (hipStream_t)stream);
+                    subgrid_off0, nullptr, in_rowmap, 0, prewindowed, (hipStream_t)stream);
 }
 
 int swiftly_hip_extract_from_facet_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,

@@ -45,6 +45,7 @@ struct ColPassArgs {
     const float* st_win2;
     long long st_win_bs;   // per-batch-item stride of st_win (masks), 0 = shared
     const int* st_rowmap;  // optional: physical output row of logical row idx (negative = not stored)
+    const float* col_win;  // optional real factor per column applied on store (see RowsArgs::row_win)
     const cx<float>* tw;       // exp(-2 pi i k / n), this pass's length
     const cx<float>* tw_full;  // exp(-2 pi i k / 2^full_logn)
     int tw_on_store;
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     cx<float>* __restrict__ out = gout + out_off + col;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
+    const float col_w = (A.col_win && live) ? A.col_win[col] : 1.f;
     const int slot = lane & (P - 1);
 
     // ---- input rows: lane `slot` describes row i = t + slot*T
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             v.y *= sg_st;
             if (live) out[(unsigned)row * A.out_pitch] = v;
         } else {
-            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_w), s));
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_w), s)) * col_w;
             v.x *= w;
             v.y *= w * sg_st;
             cx<float>* p = out + (unsigned)row * A.out_pitch;

@@ -66,6 +66,10 @@ struct RowsArgs {
     // in_rowmap: physical input row of logical input row.
     const int* st_rowmap;
     const int* in_rowmap;
+    // Optional real factor per ROW of the primitive applied on store (lets K1 pre-apply the window that
+    // the next primitive would apply along the other axis: windows commute with transforms along the
+    // orthogonal axis).
+    const R* row_win;
 };
 
 // Per-batch-item overrides of the map offsets (passed by value as a kernel
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
             R w = (R)1;
             if (st_win) w = st_win[d];
             if (A.st.win2) w *= A.st.win2[d];
+            if (A.row_win) w *= A.row_win[row];
             v.x *= w;
             v.y *= w;
             cx<R>* p = out + (size_t)((unsigned)idx * A.out_cs);

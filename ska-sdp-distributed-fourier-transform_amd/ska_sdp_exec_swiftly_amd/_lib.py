@@ -56,8 +56,8 @@ def _declare(lib):
     batch = [i64, i64, i64, pi64]  # nbatch, in_bs, out_bs, offs
     for name, args in [
         ("extract_column", [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, vp]),
-        ("extract_column_rows", [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, vp, vp]),
-        ("prepare_facet_rows", sized_in[:-1] + [vp, vp]),
+        ("extract_column_rows", [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, vp, c_int, vp]),
+        ("prepare_facet_rows", sized_in[:-1] + [vp, c_int, vp]),
         ("extract_from_facet_batch", plain[:-1] + batch + [vp]),
         ("add_to_subgrid_batch", plain[:-1] + batch + [vp]),
         ("finish_subgrid_batch", finish[:-1] + batch + [i64, vp]),

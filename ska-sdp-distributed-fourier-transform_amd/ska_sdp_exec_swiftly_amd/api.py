@@ -301,14 +301,22 @@ class SwiftlyForward:
     # -- stage 1: BF_F = prepare_facet(axis 0), once per facet (api.py:281-298)
     def _get_BF_Fs(self):
         if self.BF_Fs_persist is None:
-            if self._rowmap is None:
+            # BF_F as the streaming classes keep it: (optionally) row-compacted and with the axis-1 window of
+            # extract_column already applied (it commutes with the axis-0 transform), so the column kernel
+            # has no window loads; complex128 and unsupported sizes use the plain primitive
+            torch = _torch()
+            self._prewindowed = self.dtype == torch.complex64
+            n_rows = self._n_rows if self._rowmap is not None else self.core.yN_size
+            if self._prewindowed or self._rowmap is not None:
                 self.BF_Fs_persist = [
-                    self.core.prepare_facet(data, cfg.off0, axis=0)
+                    self.core.prepare_facet_rows(
+                        data, cfg.off0, self._rowmap, n_rows, fold_axis1_window=self._prewindowed
+                    )
                     for cfg, data in zip(self.facet_configs, self._facets)
                 ]
             else:
                 self.BF_Fs_persist = [
-                    self.core.prepare_facet_rows(data, cfg.off0, self._rowmap, self._n_rows)
+                    self.core.prepare_facet(data, cfg.off0, axis=0)
                     for cfg, data in zip(self.facet_configs, self._facets)
                 ]
         return self.BF_Fs_persist
@@ -328,7 +336,9 @@ class SwiftlyForward:
                 (len(BF_Fs), core.xM_yN_size, core.yN_size), dtype=self.dtype, device=core.device
             )
             for j, (cfg, BF_F) in enumerate(zip(self.facet_configs, BF_Fs)):
-                core.extract_column(BF_F, off0, cfg.off1, out=cols[j], rowmap=self._rowmap)
+                core.extract_column(
+                    BF_F, off0, cfg.off1, out=cols[j], rowmap=self._rowmap, prewindowed=getattr(self, "_prewindowed", False)
+                )
             self.lru.set(off0, cols)
         return cols
 

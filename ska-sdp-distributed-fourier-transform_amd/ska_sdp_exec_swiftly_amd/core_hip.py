@@ -323,7 +323,7 @@ class SwiftlyCoreHip:
         )
         return out
 
-    def extract_column(self, BF_F, subgrid_off0, facet_off1, out=None, rowmap=None):
+    def extract_column(self, BF_F, subgrid_off0, facet_off1, out=None, rowmap=None, prewindowed=False):
         """``prepare_facet(extract_from_facet(BF_F, subgrid_off0, axis=0),
         facet_off1, axis=1)`` (reference api_helper.py:200-210) as one kernel on
         a device tensor ``BF_F[yN_size, facet_size]`` -> ``[xM_yN_size,
@@ -333,7 +333,7 @@ class SwiftlyCoreHip:
         if not isinstance(BF_F, torch.Tensor):
             res = self.extract_column(self._as_device(BF_F)[0], subgrid_off0, facet_off1)
             return res.cpu().numpy()
-        if BF_F.dim() != 2 or (rowmap is None and BF_F.shape[0] != self.yN_size):
+        if BF_F.dim() != 2 or (rowmap is None and BF_F.shape[0] != self.yN_size):  # compacted when rowmap is given
             raise ValueError(f"BF_F must have shape [{self.yN_size}, facet_size], got {tuple(BF_F.shape)}")
         if out is None:
             out = torch.empty((self.xM_yN_size, self.yN_size), dtype=BF_F.dtype, device=self._device)
@@ -344,11 +344,14 @@ class SwiftlyCoreHip:
             BF_F.stride(0), BF_F.stride(1), ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1),
             int(subgrid_off0), int(facet_off1),
         ]
-        if rowmap is None:
+        if rowmap is None and not prewindowed:
             _lib.check(self._lib.swiftly_hip_extract_column(*args, self._stream()))
         else:
             _lib.check(
-                self._lib.swiftly_hip_extract_column_rows(*args, ctypes.c_void_p(rowmap.data_ptr()), self._stream())
+                self._lib.swiftly_hip_extract_column_rows(
+                    *args, ctypes.c_void_p(rowmap.data_ptr()) if rowmap is not None else None, int(bool(prewindowed)),
+                    self._stream(),
+                )
             )
         return out
 
@@ -368,11 +371,15 @@ class SwiftlyCoreHip:
         rowmap[keep] = numpy.arange(int(keep.sum()), dtype=numpy.int32)
         return torch.from_numpy(rowmap).to(self._device), int(keep.sum())
 
-    def prepare_facet_rows(self, facet, facet_off, rowmap, n_rows, out=None):
+    def prepare_facet_rows(self, facet, facet_off, rowmap, n_rows, out=None, fold_axis1_window=False):
         """``prepare_facet(facet, facet_off, axis=0)`` keeping only the rows
         ``rowmap`` selects (device tensors only): output ``[n_rows,
         facet.shape[1]]``; rows no requested subgrid column reads are never
-        written, which removes their share of the HBM traffic and footprint."""
+        written, which removes their share of the HBM traffic and footprint.
+        ``rowmap=None`` keeps all ``yN_size`` rows.  ``fold_axis1_window`` also
+        multiplies column c by the 1/PSWF window of ``prepare_facet(., axis=1)``
+        (windows commute with the transform along the other axis), to be paired
+        with ``extract_column(..., prewindowed=True)``."""
         torch = _torch()
         if facet.dim() != 2:
             raise ValueError("prepare_facet_rows needs a 2-D device tensor")
@@ -382,7 +389,9 @@ class SwiftlyCoreHip:
             self._lib.swiftly_hip_prepare_facet_rows(
                 self._handle, self._code(facet), ctypes.c_void_p(facet.data_ptr()), int(facet.shape[1]),
                 int(facet.shape[0]), facet.stride(1), facet.stride(0), ctypes.c_void_p(out.data_ptr()),
-                out.stride(1), out.stride(0), int(facet_off), ctypes.c_void_p(rowmap.data_ptr()), self._stream(),
+                out.stride(1), out.stride(0), int(facet_off),
+                ctypes.c_void_p(rowmap.data_ptr()) if rowmap is not None else None, int(bool(fold_axis1_window)),
+                self._stream(),
             )
         )
         return out
