@@ -385,30 +385,42 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     const cx<float>* tw2 = twiddles<float>(h, l2);
     const cx<float>* twf = twiddles<float>(h, logn);
     if (!tw1 || !tw2 || !twf) return false;
+    // Column slabs (tuning knob SWIFTLY_SLAB_COLS, 0 = off): both passes of a slab run back to back so that the
+    // four-step intermediate of the slab is re-read while it may still sit in the 256 MiB Infinity Cache.
+    static const long long slab_env = getenv("SWIFTLY_SLAB_COLS") ? atoll(getenv("SWIFTLY_SLAB_COLS")) : 0;
+    const long long slab = (slab_env >= 64 && nb == 1) ? (slab_env / 64) * 64 : (long long)W;
+    const long long Ws = std::min<long long>(slab, (long long)W);  // scratch row width
     void* scratch = nullptr;
-    hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * W * sizeof(cx<float>), st);
+    hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
     if (he != hipSuccess) {
         *rc_out = fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
         return true;
     }
-    // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
-    ColPassArgs A = c;
-    A.in = a.in; A.in_pitch = a.in_cs;
-    A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)W; A.out_bs = (long long)(n * W);
-    A.ld_mul = n2;
-    A.out_i_rows = n2; A.out_o_rows = 1;
-    A.tw = tw1; A.tw_full = twf;
-    A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
-    int rc = launch(l1, 0, A, n2);
-    if (!rc) {
+    int rc = 0;
+    for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
+        const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
+        // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
+        ColPassArgs A = c;
+        A.ncols = wc;
+        A.in = a.in + c0; A.in_pitch = a.in_cs;
+        A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)Ws; A.out_bs = (long long)(n * Ws);
+        A.ld_mul = n2;
+        A.out_i_rows = n2; A.out_o_rows = 1;
+        A.tw = tw1; A.tw_full = twf;
+        A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
+        A.col_win = nullptr;
+        rc = launch(l1, 0, A, n2);
+        if (rc) break;
         // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
         ColPassArgs B = c;
-        B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)W; B.in_bs = (long long)(n * W);
+        B.ncols = wc;
+        B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)Ws; B.in_bs = (long long)(n * Ws);
         B.in_i_rows = 1; B.in_o_rows = n2;
-        B.out = a.out; B.out_pitch = a.out_cs;
+        B.out = a.out + c0; B.out_pitch = a.out_cs;
         B.st_mul = n1;
         B.tw = tw2; B.tw_full = twf;
         B.conj_ld = 0;
+        if (B.col_win) B.col_win += c0;
         rc = launch(l2, 1, B, n1);
     }
     he = hipFreeAsync(scratch, st);
