@@ -47,27 +47,48 @@ int launch_row_pass(int logn, int mode, const RowPassArgs& a, hipStream_t s) {
         default: return -1;
     }
 }
-template <class G>
-static int launch_half(const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s) {
-    const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
-    hipLaunchKernelGGL((row_pass_half_kernel<G>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
-                       tw_half, tw_full);
+template <class G, int LOGS>
+static int launch_split(const RowPassArgs& a, const cx<float>* tw_part, const cx<float>* tw_full, hipStream_t s) {
+    const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * (8 << LOGS));
+    if (a.ld_win)
+        hipLaunchKernelGGL((row_pass_split_kernel<G, LOGS, true>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in,
+                           a.out, a.ld_win, tw_part, tw_full);
+    else
+        hipLaunchKernelGGL((row_pass_split_kernel<G, LOGS, false>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a,
+                           a.in, a.out, a.ld_win, tw_part, tw_full);
     return (int)hipGetLastError();
 }
-using HalfGeoA = RGeo<14, 4, true>;  // 1024 threads x 16 points, 2 workgroups / CU
-using HalfGeoB = RGeo<14, 5, true>;  // 512 threads x 32 points (tuning alternative)
-int launch_row_pass_half(const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s) {
+using SplitGeo2 = RGeo<14, 4, true>;   // 2 x 16384 points, 1024 threads x 16 (one workgroup per CU)
+using SplitGeo4 = RGeo<13, 4, true>;   // 4 x  8192 points,  512 threads x 16, 34 KB LDS (split exchange): 4 per CU
+using SplitGeo4N = RGeo<13, 4, false>; // same, interleaved exchange (68 KB): 2 per CU, half the LDS instructions
+int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw13, const cx<float>* tw_full,
+                          hipStream_t s) {
     if (a.nrows <= 0) return 0;
-    static const bool alt = getenv("SWIFTLY_K2_P32") != nullptr;
-    return alt ? launch_half<HalfGeoB>(a, tw_half, tw_full, s) : launch_half<HalfGeoA>(a, tw_half, tw_full, s);
+    static const int variant = getenv("SWIFTLY_K2_SPLIT") ? atoi(getenv("SWIFTLY_K2_SPLIT")) : 2;  // tuning knob: 2 (default, fastest measured), 4, 41
+    if (variant == 2) return launch_split<SplitGeo2, 1>(a, tw14, tw_full, s);
+    if (variant == 41) return launch_split<SplitGeo4N, 2>(a, tw13, tw_full, s);
+    return launch_split<SplitGeo4, 2>(a, tw13, tw_full, s);
+}
+// occupancy query (blocks per CU) for tuning / DESIGN.md
+int row_pass_half_occupancy(int lds_bytes) {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_split_kernel<SplitGeo4, 2, false>, SplitGeo4::NT,
+                                                       lds_bytes < 0 ? SplitGeo4::LDS_BYTES : (size_t)lds_bytes);
+    return n;
+}
+template <class G, int LOGS>
+static int init_split() {
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_split_kernel<G, LOGS, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_split_kernel<G, LOGS, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 int init_row_pass() {
     {
-        int rc0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_half_kernel<HalfGeoA>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HalfGeoA::LDS_BYTES);
-        if (!rc0)
-            rc0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_half_kernel<HalfGeoB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HalfGeoB::LDS_BYTES);
+        int rc0 = init_split<SplitGeo2, 1>();
+        if (!rc0) rc0 = init_split<SplitGeo4, 2>();
+        if (!rc0) rc0 = init_split<SplitGeo4N, 2>();
         if (rc0) return rc0;
     }
     int rc = init_one<13>();

@@ -224,7 +224,8 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             rc = make_twiddles(h, l);
             if (!rc && l >= kTwoPassMinLog) rc = make_twiddles(h, l / 2);
             if (!rc && l >= kTwoPassMinLog) rc = make_twiddles(h, l - l / 2);
-            if (!rc && l == 15) rc = make_twiddles(h, 14);  // two-workgroup row kernel
+            if (!rc && l == 15) rc = make_twiddles(h, 14);  // multi-workgroup row kernels
+            if (!rc && l == 15) rc = make_twiddles(h, 13);
         }
     if (rc) {
         swiftly_hip_destroy(h);
@@ -459,9 +460,10 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     const int mode = ident_st ? 0 : (ident_ld ? 1 : 2);
     static const bool no_half = getenv("SWIFTLY_NO_HALF") != nullptr;
     if (logn == 15 && mode == 0 && !a.accumulate && !no_half) {
-        const cx<float>* twh = twiddles<float>(h, 14);
-        if (twh) {
-            int e2 = launch_row_pass_half(r, twh, r.tw, st);
+        const cx<float>* tw14 = twiddles<float>(h, 14);
+        const cx<float>* tw13 = twiddles<float>(h, 13);
+        if (tw14 && tw13) {
+            int e2 = launch_row_pass_split(r, tw14, tw13, r.tw, st);
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
             return true;
         }
@@ -1001,6 +1003,8 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
     }
     return 0;
 }
+
+int swiftly_hip_debug_occupancy(int lds_bytes) { return swf::row_pass_half_occupancy(lds_bytes); }
 
 int swiftly_hip_malloc(void** ptr, size_t bytes) {
     if (!ptr) return fail(SWIFTLY_ERR_PARAM, "null argument");

@@ -33,14 +33,16 @@ struct RowPassArgs {
     int conj_ld, conj_st, accumulate;
 };
 
-template <int LOGN_, int LOGP_, bool SPLIT_>
+template <int LOGN_, int LOGP_, bool SPLIT_, bool PAD_ = true>
 struct RGeo {
     static constexpr int LOGN = LOGN_, LOGP = LOGP_;
     static constexpr bool SPLIT = SPLIT_;
     static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P, NT = T;
     static constexpr int RB = 1;
     static constexpr int ELEM = SPLIT ? 4 : 8;
-    static constexpr int LOGPAD = eff_logpad(ELEM, LOGP);
+    // PAD_ = false: exactly N elements (64 KiB for the 16384-point split exchange) so that TWO workgroups fit
+    // the 128 KiB the dispatcher hands out per CU for co-resident workgroups (measured: 68 KiB -> 1 block/CU)
+    static constexpr int LOGPAD = PAD_ ? eff_logpad(ELEM, LOGP) : 30;
     static constexpr int PITCH = N + (N >> LOGPAD);
     static constexpr size_t LDS_BYTES = (size_t)PITCH * ELEM;
 };
@@ -157,28 +159,32 @@ __global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, co
     });
 }
 
-// N = 2*G::N transform of one row by TWO workgroups (radix-2 decimation in
-// frequency on load): half h computes the outputs of parity h,
-//   X[2k'+h] = FFT_{N/2}( (x[j] + (-1)^h x[j+N/2]) * W_N^{h j} )[k'] .
-// Each half is an N/2-point problem (64 KB of LDS, < 128 VGPRs, no spills), so
-// two workgroups are resident per CU and one's HBM phase overlaps the other's
-// butterflies -- the single 32768-point workgroup (1 per CU, spilling) cannot.
-// Blocks 8i..8i+7 / 8i+8..8i+15 are the two halves of rows 8i..8i+7, so both
-// halves of a row run on the same XCD (block b -> XCD b mod 8): the second read
-// of the input row and the interleaved (stride-2) output lines meet in one L2.
-// MODE 0 only (mapped load, identity store): K2.
-template <class G>
-__global__ __launch_bounds__(G::NT) void row_pass_half_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
-                                                              cx<float>* __restrict__ gout,
-                                                              const float* __restrict__ ld_win,
-                                                              const cx<float>* __restrict__ tw,
-                                                              const cx<float>* __restrict__ tw_full) {
+// N = S*G::N transform of one row by S = 2^LOGS workgroups (radix-S decimation in
+// frequency on load): part h computes the outputs k = S*k' + h,
+//   X[S k'+h] = FFT_{N/S}( W_N^{h j} * sum_q x[j + q N/S] W_S^{q h} )[k'] .
+// Each part is an N/S-point problem that fits comfortably (512 threads x 16
+// points, 32-64 KB of LDS, ~45 VGPRs), so several workgroups are resident per
+// CU and one's HBM phase overlaps another's butterflies.  (Measured on MI355X:
+// a 1024-thread workgroup is never co-resident with a second one, whatever its
+// LDS/VGPR footprint -- kernel time is exactly linear in ceil(workgroups/256) --
+// so the single 32768-point workgroup and the 2 x 16384-point form run one
+// workgroup per CU with all of its waves in the same phase.)
+// The S parts of rows 8i..8i+7 are blocks 8S*i .. 8S*i+8S-1 with part = (b/8) mod S,
+// so all parts of a row run on the same XCD (block b -> XCD b mod 8): the
+// repeated reads of the input row and the interleaved (stride-S) output lines
+// meet in one L2.  MODE 0 only (mapped load, identity store): K2.
+template <class G, int LOGS, bool HAS_WIN>
+__global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
+                                                               cx<float>* __restrict__ gout,
+                                                               const float* __restrict__ ld_win,
+                                                               const cx<float>* __restrict__ tw,
+                                                               const cx<float>* __restrict__ tw_full) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int P = G::P, T = G::T, H = G::N, N = 2 * G::N;
+    constexpr int P = G::P, T = G::T, H = G::N, S = 1 << LOGS, N = S * G::N;
     const int t = threadIdx.x;
     const int b = blockIdx.x;
-    const int h = (b >> 3) & 1;
-    const int row = ((b >> 4) << 3) + (b & 7);  // uniform
+    const int h = (b >> 3) & (S - 1);
+    const int row = ((b >> (3 + LOGS)) << 3) + (b & 7);  // uniform
     if (row >= A.nrows) return;
     int in_row = row;
     if (A.rm_mod > 0) {
@@ -189,36 +195,50 @@ __global__ __launch_bounds__(G::NT) void row_pass_half_kernel(const RowPassArgs 
         in_row = r1;
     }
     if (A.in_rowmap) in_row = A.in_rowmap[in_row];
-    const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;
-    cx<float>* __restrict__ out = gout + (long long)row * A.out_pitch;
+    // row base pointers are wave-uniform: pin them to SGPRs so that every access is SGPR base + 32-bit lane offset
+    const unsigned long long in_addr = (unsigned long long)(gin + (long long)in_row * A.in_pitch);
+    const unsigned long long out_addr = (unsigned long long)(gout + (long long)row * A.out_pitch);
+    const cx<float>* __restrict__ in = (const cx<float>*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(in_addr >> 32)) << 32) |
+                                                          (unsigned)__builtin_amdgcn_readfirstlane((int)in_addr));
+    cx<float>* __restrict__ out = (cx<float>*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(out_addr >> 32)) << 32) |
+                                               (unsigned)__builtin_amdgcn_readfirstlane((int)out_addr));
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
-    const float* __restrict__ lw = ld_win ? ld_win : &kRowOne;
-    const int lws = ld_win ? 1 : 0;
-    const float hs = h ? -1.f : 1.f;
+    // W_S^{q h} = (-i)^{(q h) mod 4 * (4/S)}: real/imag parts in {0, +-1}, uniform per workgroup
+    float cr[S], ci[S];
+    static_for<0, S>([&](auto qI) {
+        constexpr int q = decltype(qI)::value;
+        const int rot = ((q * h) * (4 / S)) & 3;
+        cr[q] = rot == 0 ? 1.f : (rot == 2 ? -1.f : 0.f);
+        ci[q] = rot == 1 ? -1.f : (rot == 3 ? 1.f : 0.f);
+    });
 
     cx<float> x[P];
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         const int j = t + v * T;
-        // plain index j -> centred j + N/2 ; plain j + N/2 -> centred j
-        const int qa = (j + H + A.ld_a) & (N - 1);
-        const int qb = (j + A.ld_a) & (N - 1);
-        const bool oka = qa < A.ld_len, okb = qb < A.ld_len;
-        const int qas = oka ? qa : 0, qbs = okb ? qb : 0;
-        unsigned ia = (unsigned)(qas + A.ld_c), ib = (unsigned)(qbs + A.ld_c);
-        if (ia >= (unsigned)A.ld_mod) ia -= (unsigned)A.ld_mod;
-        if (ib >= (unsigned)A.ld_mod) ib -= (unsigned)A.ld_mod;
-        const cx<float> a = in[ia], c = in[ib];
-        const float wa = oka ? lw[qas * lws] : 0.f;
-        const float wb = (okb ? lw[qbs * lws] : 0.f) * hs;
-        cx<float> y = {a.x * wa + c.x * wb, (a.y * wa + c.y * wb) * sg_ld};
-        if (h) y = cmul(y, tw_full[j]);
+        cx<float> y = {0.f, 0.f};
+        static_for<0, S>([&](auto qI) {
+            constexpr int q = decltype(qI)::value;
+            // plain index j + q*H -> centred index (j + q*H) ^ (N/2)
+            const int qq = ((((j + q * H) ^ (N >> 1)) + A.ld_a) & (N - 1));
+            const bool ok = qq < A.ld_len;
+            const int qs = ok ? qq : 0;
+            unsigned idx = (unsigned)(qs + A.ld_c);
+            if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
+            const cx<float> a = in[idx];
+            float w = ok ? 1.f : 0.f;
+            if constexpr (HAS_WIN) w *= ld_win[qs];
+            const float ax = a.x * w, ay = a.y * w * sg_ld;
+            y.x += ax * cr[q] - ay * ci[q];
+            y.y += ax * ci[q] + ay * cr[q];
+        });
+        if (h) y = cmul(y, tw_full[(h * j) & (N - 1)]);
         x[v] = y;
     });
 
     fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
-        const int ck = (2 * e + h) ^ H;
+        const int ck = (S * e + h) ^ (N >> 1);
         v.x *= A.scale;
         v.y *= A.scale * sg_st;
         out[ck] = v;
@@ -229,7 +249,9 @@ constexpr int kRowPassMinLog = 13;
 constexpr int kRowPassMaxLog = 15;
 int launch_row_pass(int logn, int mode, const RowPassArgs& a, hipStream_t s);
 int init_row_pass();
-// two-workgroup form for N = 32768 (MODE 0 only); tw_half = table of length N/2, tw_full of length N
-int launch_row_pass_half(const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s);
+int row_pass_half_occupancy(int lds_bytes);
+// multi-workgroup form for N = 32768 (MODE 0 only); tw14 / tw13 = tables of length 16384 / 8192, tw_full of length N
+int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw13, const cx<float>* tw_full,
+                          hipStream_t s);
 
 }  // namespace swf
