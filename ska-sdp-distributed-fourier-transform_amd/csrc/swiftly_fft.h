@@ -39,6 +39,23 @@ template <typename R>
 __device__ __forceinline__ cx<R> cmul(cx<R> a, cx<R> b) {
     return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
+// complex64 products written on 2-vectors so that they lower to v_pk_mul_f32 + v_pk_fma_f32 (2 packed
+// instructions instead of 4 scalar ones): (a.x, a.x)*(b.x, b.y) + (-a.y, a.y)*(b.y, b.x)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Measured on MI355X (same-box A/B, bench.py): the packed forms make the column passes ~18 % SLOWER
+// (K1 32.5 -> 38.5 ms) and leave the row kernels unchanged, so they are compiled out by default.
+#ifndef SWF_PACKED_CMUL
+#define SWF_PACKED_CMUL 0
+#endif
+#if SWF_PACKED_CMUL
+template <>
+__device__ __forceinline__ cx<float> cmul<float>(cx<float> a, cx<float> b) {
+    const f32x2 bv = {b.x, b.y}, bs = {b.y, b.x};
+    const f32x2 ax = {a.x, a.x}, ay = {-a.y, a.y};
+    const f32x2 r = __builtin_elementwise_fma(ay, bs, ax * bv);
+    return {r.x, r.y};
+}
+#endif
 
 // compile-time loop: f(std::integral_constant<int, i>) for i in [I0, I1)
 template <int I0, int I1, class F>
@@ -102,7 +119,15 @@ __device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
         return {(d.y - d.x) * c, -(d.x + d.y) * c};
     } else {
         constexpr R c = (R)cos64(n), s = (R)(-sin64(n));
-        return {d.x * c - d.y * s, d.x * s + d.y * c};
+        if constexpr (std::is_same<R, float>::value && SWF_PACKED_CMUL) {
+            // (d.x, d.x)*(c, s) + (d.y, d.y)*(-s, c) as two packed instructions
+            const f32x2 dx = {d.x, d.x}, dy = {d.y, d.y};
+            const f32x2 k0 = {c, s}, k1 = {-s, c};
+            const f32x2 r = __builtin_elementwise_fma(dy, k1, dx * k0);
+            return {r.x, r.y};
+        } else {
+            return {d.x * c - d.y * s, d.x * s + d.y * c};
+        }
     }
 }
 

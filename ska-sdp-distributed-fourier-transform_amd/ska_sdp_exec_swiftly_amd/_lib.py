@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswiftly_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("SWIFTLY_HIP_LIB", "libswiftly_hip.so"))  # env: A/B builds
 
 C64, C128 = 0, 1
 ERR_PARAM, ERR_UNSUPPORTED, ERR_HIP = 1, 2, 3
