@@ -320,6 +320,29 @@ def main():
             avg_launch_ms=k1["avg_ms"],
         )
 
+    if roofline is None and local:
+        # multi-GPU: time K1 of one local facet on this rank (outside the timed region) for the roofline object
+        core = cfg.core
+        rowmap, n_rows = core.subgrid_column_rows([sg.off0 for sg in sg_cfgs])
+        j0 = local[0]
+        buf = core.prepare_facet_rows(facet_data[j0], facet_cfgs[j0].off0, rowmap, n_rows, fold_axis1_window=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            core.prepare_facet_rows(facet_data[j0], facet_cfgs[j0].off0, rowmap, n_rows, out=buf, fold_axis1_window=True)
+        e1.record()
+        torch.cuda.synchronize()
+        k1_ms = e0.elapsed_time(e1) / 3
+        k1_bytes = parts["K1"] / F
+        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+        roofline = dict(
+            kernel="K1 prepare_facet(axis=0) per facet (rank 0) = col_pass<n1> + col_pass<n2>",
+            bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+            algorithmic_bytes_per_launch=k1_bytes, avg_launch_ms=round(k1_ms, 4),
+        )
+        del buf
+
     line = dict(
         metric="facet_to_subgrid_contributions_per_s",
         value=round(F * S / (ms_per_step * 1e-3), 1),
