@@ -294,3 +294,30 @@ def test_long_rows_yN32768_c64():
         want = orc.extract_column(ref, bf.astype(complex), so0, fo1)
         rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
         assert rel < 2e-6, rel
+
+
+def test_backward_long_rows_yN32768_c64():
+    """Backward-pass primitives at the N=65536 sizes: finish_facet along the contiguous axis (long-row kernel,
+    mapped store with the 1/pswf window and a mask) and along the strided axis (column passes, four-step) plus
+    add_to_facet, against the oracle."""
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    W, N, xM, yN, yB = 10.875, 65536, 1024, 32768, 22528
+    core = SwiftlyCoreHip(W, N, xM, yN)
+    ref = orc.OracleCore(W, N, xM, yN)
+    rng = numpy.random.default_rng(12)
+    acc = (rng.standard_normal((4, yN)) + 1j * rng.standard_normal((4, yN))).astype(numpy.complex64)
+    mask = (rng.random(yB) > 0.3).astype(float)
+    for off in (0, 22528, -20480):
+        got = core.finish_facet(acc, off, yB, axis=1, mask=mask)
+        want = ref.finish_facet(acc.astype(complex), off, yB, 1) * mask[None, :]
+        rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+        assert got.shape == (4, yB) and rel < 3e-6, rel
+    accT = numpy.ascontiguousarray(acc[:, :].T[:, :3])  # [yN, 3]: strided axis
+    got = core.finish_facet(accT, 22528, yB, axis=0)
+    want = ref.finish_facet(accT.astype(complex), 22528, yB, 0)
+    rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+    assert got.shape == (yB, 3) and rel < 3e-6, rel
+    m = core.xM_yN_size
+    c = (rng.standard_normal((5, m)) + 1j * rng.standard_normal((5, m))).astype(numpy.complex64)
+    assert numpy.array_equal(core.add_to_facet(c, 928 * 7, axis=1), ref.add_to_facet(c, 928 * 7, 1))
