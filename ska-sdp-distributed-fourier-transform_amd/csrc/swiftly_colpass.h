@@ -15,6 +15,28 @@
 
 namespace swf {
 
+// streaming (non-temporal) global accesses for the column passes: every byte is touched once per pass
+// (same-box A/B on MI355X: whole pass 74.0 -> 70.6-72.0 ms)
+#ifndef SWF_NT
+#define SWF_NT 1
+#endif
+__device__ __forceinline__ cx<float> cp_load(const cx<float>* p) {
+#if SWF_NT
+    const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+    return {v.x, v.y};
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void cp_store(cx<float>* p, cx<float> v) {
+#if SWF_NT
+    const f32x2 w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
+#else
+    *p = v;
+#endif
+}
+
 struct ColPassArgs {
     const cx<float>* in;
     cx<float>* out;
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         const int row = __builtin_amdgcn_readlane(in_row, v);
         cx<float> val = {0.f, 0.f};
         if (row >= 0) {  // uniform
-            if (live) val = in[(unsigned)row * A.in_pitch];
+            if (live) val = cp_load(in + (unsigned)row * A.in_pitch);
         }
         x[v] = val;
     });
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             w.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_tw.y), s));
             v = cmul(v, w);
             v.y *= sg_st;
-            if (live) out[(unsigned)row * A.out_pitch] = v;
+            if (live) cp_store(out + (unsigned)row * A.out_pitch, v);
         } else {
             const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_w), s)) * col_w;
             v.x *= w;
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
                     v.y += old.y;
                 }
             }
-            if (live) *p = v;
+            if (live) cp_store(p, v);
         }
     });
 }

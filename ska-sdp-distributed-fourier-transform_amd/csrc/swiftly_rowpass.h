@@ -49,6 +49,26 @@ struct RGeo {
 
 __device__ const float kRowOne = 1.f;
 
+#ifndef SWF_NT_ROW
+#define SWF_NT_ROW 0
+#endif
+__device__ __forceinline__ cx<float> rp_load(const cx<float>* p) {
+#if SWF_NT_ROW
+    const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+    return {v.x, v.y};
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void rp_store(cx<float>* p, cx<float> v) {
+#if SWF_NT_ROW
+    const f32x2 w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
+#else
+    *p = v;
+#endif
+}
+
 // MODE 0: mapped load (window, pad, shift), identity store   -- prepare_facet / prepare_subgrid style
 // MODE 1: identity load, mapped store (shift, crop, windows)  -- finish_facet / finish_subgrid style
 // MODE 2: both mapped
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
             const int qs = ok ? qq : 0;
             unsigned idx = (unsigned)(qs + A.ld_c);
             if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
-            const cx<float> a = in[idx];
+            const cx<float> a = rp_load(in + idx);
             float w = ok ? 1.f : 0.f;
             if constexpr (HAS_WIN) w *= ld_win[qs];
             const float ax = a.x * w, ay = a.y * w * sg_ld;
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
         const int ck = (S * e + h) ^ (N >> 1);
         v.x *= A.scale;
         v.y *= A.scale * sg_st;
-        out[ck] = v;
+        rp_store(out + ck, v);
     });
 }
 
