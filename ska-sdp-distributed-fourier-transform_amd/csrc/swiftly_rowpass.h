@@ -49,8 +49,13 @@ struct RGeo {
 
 __device__ const float kRowOne = 1.f;
 
+// non-temporal accesses in the long-row kernel: loads measured much slower (the input row is read by two
+// workgroups: K2 25 -> 37.5 ms); stores are a separate switch
 #ifndef SWF_NT_ROW
 #define SWF_NT_ROW 0
+#endif
+#ifndef SWF_NT_ROW_ST
+#define SWF_NT_ROW_ST 0
 #endif
 __device__ __forceinline__ cx<float> rp_load(const cx<float>* p) {
 #if SWF_NT_ROW
@@ -61,7 +66,7 @@ __device__ __forceinline__ cx<float> rp_load(const cx<float>* p) {
 #endif
 }
 __device__ __forceinline__ void rp_store(cx<float>* p, cx<float> v) {
-#if SWF_NT_ROW
+#if SWF_NT_ROW || SWF_NT_ROW_ST
     const f32x2 w = {v.x, v.y};
     __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
 #else
