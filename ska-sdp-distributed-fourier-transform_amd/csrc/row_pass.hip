@@ -59,6 +59,7 @@ static int launch_split(const RowPassArgs& a, const cx<float>* tw_part, const cx
     return (int)hipGetLastError();
 }
 using SplitGeo2 = RGeo<14, 4, true>;   // 2 x 16384 points, 1024 threads x 16 (one workgroup per CU)
+using SplitGeo2N = RGeo<14, 4, false>; // same with interleaved (re,im) exchange: 136 KB LDS, half the LDS instructions and barriers
 using SplitGeo4 = RGeo<13, 4, true>;   // 4 x  8192 points,  512 threads x 16, 34 KB LDS (split exchange): 4 per CU
 using SplitGeo4N = RGeo<13, 4, false>; // same, interleaved exchange (68 KB): 2 per CU, half the LDS instructions
 int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw13, const cx<float>* tw_full,
@@ -66,6 +67,7 @@ int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<
     if (a.nrows <= 0) return 0;
     static const int variant = getenv("SWIFTLY_K2_SPLIT") ? atoi(getenv("SWIFTLY_K2_SPLIT")) : 2;  // tuning knob: 2 (default, fastest measured), 4, 41
     if (variant == 2) return launch_split<SplitGeo2, 1>(a, tw14, tw_full, s);
+    if (variant == 21) return launch_split<SplitGeo2N, 1>(a, tw14, tw_full, s);
     if (variant == 41) return launch_split<SplitGeo4N, 2>(a, tw13, tw_full, s);
     return launch_split<SplitGeo4, 2>(a, tw13, tw_full, s);
 }
@@ -87,6 +89,7 @@ static int init_split() {
 int init_row_pass() {
     {
         int rc0 = init_split<SplitGeo2, 1>();
+        if (!rc0) rc0 = init_split<SplitGeo2N, 1>();
         if (!rc0) rc0 = init_split<SplitGeo4, 2>();
         if (!rc0) rc0 = init_split<SplitGeo4N, 2>();
         if (rc0) return rc0;
