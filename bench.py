@@ -2,11 +2,11 @@
 """
 bench.py -- facet -> subgrid throughput of the MI355X SwiFTly path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-verify] [--no-cpu-baseline]
 
 One "step" = one complete forward pass of the workload with the facets already
-resident in HBM: prepare_facet(axis 0) of every facet (K1), then for every
-subgrid column the column kernel (K2), the window extraction (K3), the
+resident in HBM: the full-facet transform of every facet (K1), then for every
+subgrid wave the per-wave facet transform (K2), the window extraction (K3), the
 per-subgrid accumulation (K4) and finish (K5).  Nothing is cached across
 steps.  Prints ONE JSON line (rank 0).
 
@@ -14,17 +14,27 @@ Workloads (BASELINE.json configs):
   64k-sparse  (default) catalogue "64k[1]-n32k-1k": N=65536, 3x3 facets of
               22528^2, sparse subgrid set (505 of 71^2 = 10.02 %, 25 columns),
               complex64 -- the configuration BASELINE.json's metric is quoted on
-              (fits one 288 GB GPU: 36.5 GB facets + 53 GB BF_F).
+              (fits one 288 GB GPU: 36.5 GB facets + intermediates).
   8k          BASELINE configs[1] parameters (N=8192, 6x6 facets, 8x8 subgrids).
   1k          reference TEST_PARAMS (N=1024), plumbing.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) facets are
-sharded over ranks and the contributions go through an RCCL all-to-all per
-wave; total work is fixed ("strong" scaling).
+Synthetic data.  Facet j = sum_{r<2} a_{j,r} (x) b_{j,r} times the cover masks,
+with seeded random vectors on the 1/8 grid (oracle/separable.py): DENSE
+random-looking complex64 arrays whose exact forward result the CPU oracle can
+evaluate per subgrid in O(1 s) even at N = 65536.  After the timed region the
+subgrids the TIMED objects produce are compared with the oracle ("parity" in
+the JSON line) -- the benchmarked code path is the verified code path.
+
+--gpus N > 1: if not already running under torch.distributed.run, bench.py
+re-launches itself with N ranks (one per GPU, RCCL); facets are sharded over
+ranks and the contributions go through an RCCL all-to-all per wave; total work
+is fixed ("strong" scaling).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +46,7 @@ for _p in (ROOT, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd")
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PARITY_TOL = 2e-5  # complex64 relative RMSE bound vs the complex128 oracle
 
 WORKLOADS = {
     "64k-sparse": dict(
@@ -86,6 +97,56 @@ def algorithmic_bytes(p, F, S, C):
     return sum(parts.values()), parts
 
 
+# --------------------------------------------------------------------------- synthetic facets
+def separable_facet(torch, vec, cfg, pixels=None, device="cuda"):
+    """Device facet ``sum_r a_r (x) b_r`` (times the cover masks, plus optional
+    point-source pixels) as complex64 -- exactly the numbers the separable
+    oracle uses (components on the 1/8 grid: products and sums are exact in
+    float32)."""
+    yB = cfg.size
+    out = torch.zeros((yB, yB), dtype=torch.complex64, device=device)
+    if vec is not None:
+        a, b = vec
+        m0 = cfg.mask0 if cfg.mask0 is not None else numpy.ones(yB)
+        m1 = cfg.mask1 if cfg.mask1 is not None else numpy.ones(yB)
+        for r in range(a.shape[0]):
+            ta = torch.from_numpy((a[r] * m0).astype(numpy.complex64)).to(device)
+            tb = torch.from_numpy((b[r] * m1).astype(numpy.complex64)).to(device)
+            out.add_(torch.outer(ta, tb))
+    for p0, p1, val in pixels or []:
+        out[p0, p1] += complex(val)
+    return out
+
+
+def verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got_by_index, pixels=None):
+    """Compare finished subgrids (dict: index into sg_cfgs -> numpy array) with the separable oracle.
+    Returns the "parity" object of the JSON line."""
+    from oracle import separable as sep  # checker only
+    from oracle import swiftly_oracle as orc
+
+    core = orc.OracleCore(p["W"], p["N"], p["xM_size"], p["yN_size"])
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    so = sep.SeparableOracle(core, items, vectors, pixels)
+    rels, maxs = [], []
+    for i, got in sorted(got_by_index.items()):
+        c = sg_cfgs[i]
+        want = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1))
+        rms = float(numpy.sqrt(numpy.mean(numpy.abs(want) ** 2)))
+        err = numpy.abs(got - want)
+        rels.append(float(numpy.sqrt(numpy.mean(err**2))) / rms)
+        maxs.append(float(err.max()) / rms)
+    return dict(
+        checker="oracle/separable.py (numpy, complex128) on the subgrids produced by the timed objects",
+        subgrids=len(rels),
+        subgrid_offsets=[[int(sg_cfgs[i].off0), int(sg_cfgs[i].off1)] for i in sorted(got_by_index)],
+        rel_rmse=max(rels),
+        rel_rmse_each=[float(f"{r:.3e}") for r in rels],
+        max_abs_over_rms=max(maxs),
+        tol_rel_rmse=PARITY_TOL,
+        ok=bool(max(rels) < PARITY_TOL),
+    )
+
+
 class StageTimer:
     """HIP-event timing of launch groups on the stream the kernels run on
     (torch's current stream == the stream handed to the C ABI)."""
@@ -109,64 +170,27 @@ class StageTimer:
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.pairs.items()}
 
 
-def run_forward(sw, torch, cfg, fwd_factory, waves, timer=None):
-    """One full forward pass.  Returns the number of finished subgrids."""
-    fwd = fwd_factory()
-    core = cfg.core
-    count = 0
-    if timer is None:
-        fwd._get_BF_Fs()  # pylint: disable=protected-access
-        for wave in waves:
-            res = fwd.get_subgrid_tasks(wave)
-            count += len(res)
-        return count
-    # instrumented pass: same launches, events around each stage
-    # K1 exactly as SwiftlyForward._get_BF_Fs issues it, one event pair per facet
-    pre = fwd.dtype == torch.complex64
-    fwd._prewindowed = pre  # pylint: disable=protected-access
-    n_rows = fwd._n_rows if fwd._rowmap is not None else core.yN_size  # pylint: disable=protected-access
-    bfs = []
-    for c, data in zip(fwd.facet_configs, fwd._facets):  # pylint: disable=protected-access
-        t0 = timer.start()
-        bfs.append(
-            core.prepare_facet_rows(data, c.off0, fwd._rowmap, n_rows, fold_axis1_window=pre)  # pylint: disable=protected-access
-        )
-        timer.stop("K1_prepare_facet_axis0", t0)
-    fwd.BF_Fs_persist = bfs
-    for wave in waves:
-        t0 = timer.start()
-        fwd.get_NMBF_BFs_off0(wave[0].off0)
-        timer.stop("K2_extract_column", t0)
-        t0 = timer.start()
-        res = fwd._wave(wave)  # pylint: disable=protected-access
-        timer.stop("K345_extract_sum_finish", t0)
-        count += res.shape[0]
-    return count
-
-
-def cpu_baseline(p, F, S, C, budget_s=25.0):
-    """Oracle (numpy restatement of the reference, complex128 like the
-    reference's numpy path) timed on ONE host core on a bounded sample of the
-    same workload, extrapolated linearly by unit counts."""
+# --------------------------------------------------------------------------- CPU baseline
+def _cpu_sample(args):
+    """One worker's share of the CPU sample (runs in a separate process)."""
+    p, F, seed = args
     from oracle import swiftly_oracle as orc  # checker / baseline only
 
     yB, yN, xA, xM, N = p["yB_size"], p["yN_size"], p["xA_size"], p["xM_size"], p["N"]
     core = orc.OracleCore(p["W"], N, xM, yN)
     m = core.xM_yN_size
-    rng = numpy.random.default_rng(0)
-    ncol = max(1, min(yB, int(8.0e6 // yN)))  # K1 slab: column-independent
+    rng = numpy.random.default_rng(seed)
+    ncol = max(1, min(yB, int(4.0e6 // yN)))  # K1 slab: column-independent
     slab = (rng.standard_normal((yB, ncol)) + 1j * rng.standard_normal((yB, ncol))).astype(numpy.complex64)
     t0 = time.perf_counter()
     bf = core.prepare_facet(slab, 0, axis=0)
     t_k1 = (time.perf_counter() - t0) * (yB / ncol)
-    # K2 on a row slab of one (facet, column)
-    nrow = max(1, min(m, int(1.6e7 // yN)))
+    del bf
+    nrow = max(1, min(m, int(8.0e6 // yN)))
     rows = (rng.standard_normal((nrow, yB)) + 1j * rng.standard_normal((nrow, yB))).astype(numpy.complex64)
     t0 = time.perf_counter()
     col = core.prepare_facet(rows, 0, axis=1)
     t_k2 = (time.perf_counter() - t0) * (m / nrow)
-    del bf
-    # K3..K5 for one subgrid with all F contributions
     colfull = numpy.zeros((m, yN), dtype=complex)
     colfull[:nrow] = col
     items = orc.make_full_cover(N, yB)[:F]
@@ -175,20 +199,69 @@ def cpu_baseline(p, F, S, C, budget_s=25.0):
     contribs = [core.extract_from_facet(colfull, 0, axis=1) for _ in range(F)]
     orc.sum_and_finish_subgrid(core, contribs, items, sg)
     t_sg = time.perf_counter() - t0
-    total = F * t_k1 + F * C * t_k2 + S * t_sg
+    return t_k1, t_k2, t_sg, ncol, nrow
+
+
+def cpu_baseline(p, F, S, C):
+    """Oracle (numpy restatement of the reference, complex128 like the
+    reference's numpy path) timed on ALL host cores: what Dask would
+    parallelise -- independent facet column slabs, (facet, column) row slabs and
+    subgrids -- runs as one process per core (numpy's pocketfft is single
+    threaded), every process working on its own bounded sample concurrently (so
+    memory-bandwidth contention between cores is in the numbers), extrapolated
+    linearly by unit counts."""
+    from concurrent.futures import ProcessPoolExecutor
+
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(cores) as pool:
+        res = list(pool.map(_cpu_sample, [(p, F, 1000 + i) for i in range(cores)]))
+    wall = time.perf_counter() - t0
+    t_k1 = float(numpy.mean([r[0] for r in res]))
+    t_k2 = float(numpy.mean([r[1] for r in res]))
+    t_sg = float(numpy.mean([r[2] for r in res]))
+    ncol, nrow = res[0][3], res[0][4]
+    # per-unit times measured with all cores busy; units are independent, so `cores` of them run at a time
+    total = (F * t_k1 + F * C * t_k2 + S * t_sg) / cores
+    m = p["xM_size"] * p["yN_size"] // p["N"]
     return dict(
         value=F * S / total,
         unit="contributions/s",
-        cores=1,
+        cores=cores,
         kind="port",
         sample=(
-            f"oracle (numpy, complex128) on 1 core: K1 on a {yB}x{ncol} column slab of one facet, "
-            f"K2 on {nrow} of {m} rows of one (facet, column), K3-K5 for one subgrid with {F} contributions; "
-            f"extrapolated linearly to {F} facets x {C} columns x {S} subgrids "
-            f"(K1 {F * t_k1:.1f} s + K2 {F * C * t_k2:.1f} s + K3-5 {S * t_sg:.1f} s)"
+            f"oracle (numpy, complex128), {cores} processes concurrently, each: K1 on a {p['yB_size']}x{ncol} "
+            f"column slab of one facet, K2 on {nrow} of {m} rows of one (facet, column), K3-K5 for one subgrid "
+            f"with {F} contributions; per-unit times averaged over processes and extrapolated linearly to {F} facets "
+            f"x {C} columns x {S} subgrids spread over {cores} cores "
+            f"(K1 {F * t_k1 / cores:.1f} s + K2 {F * C * t_k2 / cores:.1f} s + K3-5 {S * t_sg / cores:.1f} s); "
+            f"sample wall time {wall:.1f} s"
         ),
         extrapolated_seconds=total,
     )
+
+
+# --------------------------------------------------------------------------- measured traffic (PMC passes)
+def measured_traffic(workload):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc summary of THIS round's build
+    (profiles/r2_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes),
+    or None when no such measurement is recorded for the workload."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    try:
+        with open(path, encoding="utf-8") as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    entry = rec.get(workload)
+    if not entry:
+        return None, None
+    return entry.get("bytes_per_launch"), entry.get("note")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def main():
@@ -198,7 +271,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="64k-sparse", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle parity check of the timed objects")
+    ap.add_argument("--verify", action="store_true", help="(default) kept for explicitness")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one rank per GPU ourselves (one process per GPU over RCCL)
+        cmd = [
+            sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__),
+        ] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
 
@@ -212,64 +297,92 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a mislabelled number")
+    if torch.cuda.device_count() < world and os.environ.get("SWIFTLY_BENCH_OVERSUBSCRIBE") != "1":
+        raise SystemExit(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} GPU(s) visible")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
-    if args.gpus != world:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     wl = WORKLOADS[args.workload]
     p = wl["params"]
     cfg = sw.SwiftlyConfig(backend="hip", **p)
     facet_cfgs = sw.make_full_facet_cover(cfg)
     sg_cfgs = select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
+    force_dist = os.environ.get("SWIFTLY_BENCH_FORCE_DIST") == "1"  # exercise the multi-GPU code path on 1 GPU
+    single = world == 1 and not force_dist
+    wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64) if single else 0
+    key = (lambda c: c.off1) if wave_axis == 1 else (lambda c: c.off0)
     waves = {}
-    for c in sg_cfgs:
-        waves.setdefault(c.off0, []).append(c)
-    waves = list(waves.values())
+    for i, c in enumerate(sg_cfgs):
+        waves.setdefault(key(c), []).append(i)
+    wave_idx = list(waves.values())
+    waves = [[sg_cfgs[i] for i in w] for w in wave_idx]
     F, S, C = len(facet_cfgs), len(sg_cfgs), len(waves)
 
-    # synthetic dense facets N(0,1)+iN(0,1), complex64, generated on the device
-    # (seed 1234 + facet index), times the cover masks
-    yB = p["yB_size"]
+    # synthetic dense facets: separable (rank 2) random vectors on the 1/8 grid, seed 1234 + facet index,
+    # times the cover masks; built on the device
+    from oracle import separable as sep  # data recipe shared with the checker
+
     local = [j for j in range(F) if j % world == rank]
+    vectors = [sep.facet_vectors(1234 + j, p["yB_size"], rank=2) for j in range(F)]
     facet_data = [None] * F
     for j in local:
-        gen = torch.Generator(device="cuda")
-        gen.manual_seed(1234 + j)
-        re = torch.randn((yB, yB), generator=gen, device="cuda", dtype=torch.float32)
-        im = torch.randn((yB, yB), generator=gen, device="cuda", dtype=torch.float32)
-        m0 = torch.from_numpy(facet_cfgs[j].mask0).to("cuda", torch.float32)
-        m1 = torch.from_numpy(facet_cfgs[j].mask1).to("cuda", torch.float32)
-        facet_data[j] = torch.complex(re, im) * m0[:, None] * m1[None, :]
-        del re, im
+        facet_data[j] = separable_facet(torch, vectors[j], facet_cfgs[j])
 
-    force_dist = os.environ.get("SWIFTLY_BENCH_FORCE_DIST") == "1"  # exercise the multi-GPU code path on 1 GPU
-    if world == 1 and not force_dist:
+    picks = sep.pick_subgrids(sg_cfgs, 6) if not args.no_verify else []
+    kept = {}
+
+    if single:
 
         def factory():
             return sw.SwiftlyForward(
-                cfg, [(facet_cfgs[j], facet_data[j]) for j in range(F)], lru_forward=1, subgrid_configs=sg_cfgs
+                cfg, [(facet_cfgs[j], facet_data[j]) for j in range(F)], lru_forward=1, subgrid_configs=sg_cfgs,
+                wave_axis=wave_axis,
             )
 
-        def one_pass(timer=None):
-            return run_forward(sw, torch, cfg, factory, waves, timer)
+        def one_pass(timer=None, keep=None):
+            fwd = factory()
+            if timer is not None:
+                t0 = timer.start()
+            fwd.prepare_all_facets(timer)
+            if timer is not None:
+                timer.stop("K1_total", t0)
+            count = 0
+            for widx, wave in zip(wave_idx, waves):
+                res = fwd.get_wave(wave, timer)
+                count += len(wave)
+                if keep is not None:
+                    for k, i in enumerate(widx):
+                        if i in picks:
+                            keep[i] = res[k].cpu().numpy()
+            return count
 
     else:
 
-        def one_pass(timer=None):  # pylint: disable=unused-argument
+        def one_pass(timer=None, keep=None):  # pylint: disable=unused-argument
             dfw = DistributedForward(cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs)
             dfw.local._get_BF_Fs()  # pylint: disable=protected-access
             # software pipeline: the all-to-all of wave w runs while wave w+1's column/extract kernels do
             n = 0
             pending = None
-            for wave in waves:
+
+            def finish(h, widx):
+                mine, res = dfw.finish_wave(h)
+                if keep is not None and res is not None:
+                    for k, pos in enumerate(mine):
+                        if widx[pos] in picks:
+                            keep[widx[pos]] = res[k].cpu().numpy()
+                return len(mine)
+
+            for widx, wave in zip(wave_idx, waves):
                 handle = dfw.start_wave(wave)
                 if pending is not None:
-                    n += len(dfw.finish_wave(pending)[0])
-                pending = handle
-            n += len(dfw.finish_wave(pending)[0])
+                    n += finish(*pending)
+                pending = (handle, widx)
+            n += finish(*pending)
             return n
 
     def fence():
@@ -291,31 +404,42 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
 
+    # parity of the timed objects (same factory, same facets, same waves), outside the timed region
+    parity = None
+    if picks:
+        one_pass(keep=kept)
+        fence()
+        if world > 1:
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, kept)
+            kept = {k: v for d in gathered for k, v in d.items()}
+        if rank == 0:
+            parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept)
+
     # per-stage HIP-event timing (separate instrumented pass, 1 GPU only)
     stages = {}
     roofline = None
     total_bytes, parts = algorithmic_bytes(p, F, S, C)
-    if world == 1 and not force_dist:
+    if single:
         timer = StageTimer(torch)
         one_pass(timer)
         torch.cuda.synchronize()
         for name, (cnt, ms) in timer.totals().items():
             stages[name] = dict(launch_groups=cnt, total_ms=round(ms, 3), avg_ms=round(ms / cnt, 4))
-        k1 = stages["K1_prepare_facet_axis0"]
+        k1 = stages["K1_full_facet_transform"]
         k1_bytes = parts["K1"] / F  # per facet = per launch group
         achieved = k1_bytes / (k1["avg_ms"] * 1e-3) / 1e9
-        # HBM bytes per K1 launch group from rocprofv3 PMC passes of the same kernels (tools/run_k1_plan.py,
-        # profiles/r1d_pmc_k1_traffic.txt): FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request) + WRITE_SIZE
-        k1_traffic = {"64k-sparse": 2 * (1994492 + 2885678) * 1024 + (5767168 + 2019072) * 1024}.get(args.workload)
+        traffic, traffic_note = measured_traffic(args.workload)
         roofline = dict(
-            kernel="K1 prepare_facet(axis=0) per facet = col_pass<n1=128, mapped load> + col_pass<n2=256, mapped store>",
+            kernel=sw_api.K1_DESCRIPTION[wave_axis],
             bound="hbm",
             achieved=round(achieved, 1),
             peak=HBM_PEAK_GBS,
             unit="GB/s",
             frac=round(achieved / HBM_PEAK_GBS, 4),
-            traffic=k1_traffic,
-            traffic_note="bytes per launch group measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)",
+            traffic=traffic,
+            traffic_note=traffic_note
+            or "null: no rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE summary of this build is committed for this workload",
             algorithmic_bytes_per_launch=k1_bytes,
             avg_launch_ms=k1["avg_ms"],
         )
@@ -348,6 +472,7 @@ def main():
         value=round(F * S / (ms_per_step * 1e-3), 1),
         unit="contributions/s",
         n_gpus=world,
+        rccl_ranks=world if world > 1 else 0,
         steps=args.steps,
         warmup=args.warmup,
         ms_per_step=round(ms_per_step, 3),
@@ -358,6 +483,8 @@ def main():
         data="synthetic",
         config=dict(
             workload=wl["name"], facets=F, subgrids=S, subgrid_columns=C, contributions=F * S, params=p,
+            wave_axis=wave_axis,
+            facet_data="separable rank-2 dense random (1/8 grid), seed 1234+j, times cover masks",
             parallelism=f"facets sharded over {world} rank(s), contribution all-to-all" if world > 1 else "1 GPU",
         ),
         hbm_algorithmic_gbs=round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
@@ -365,15 +492,18 @@ def main():
         algorithmic_bytes=dict(total=total_bytes, **parts),
         stages=stages,
         roofline=roofline,
+        parity=parity,
     )
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p, F, S, C)
             line["cpu_baseline"]["value"] = round(line["cpu_baseline"]["value"], 3)
-            line["speedup_vs_cpu_core"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+            line["speedup_vs_cpu_host"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {PARITY_TOL}")
 
 
 if __name__ == "__main__":

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -147,7 +148,24 @@ static int make_twiddles(swiftly_hip* h, int logn) {
     return 0;
 }
 
-static bool g_inited = false;
+// Kernel attributes (max dynamic LDS) and the memory-pool release threshold are per DEVICE state: they are set
+// once for every device a handle is created on, under a lock (handles may be created from several host threads).
+static std::mutex g_init_mutex;
+static std::vector<char> g_device_inited;
+
+// RAII: make `device` current for the duration of one ABI call and restore the caller's (torch's) current
+// device afterwards.  Streams handed in by the caller belong to the handle's device.
+struct DeviceGuard {
+    int prev = -1, rc = 0;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) rc = (int)hipSetDevice(device);
+        else prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 // Transforms of length >= 2^kTwoPassMinLog along a STRIDED axis (rows contiguous) are decomposed into
 // two passes of short transforms so that every access is >= 128 B contiguous.
 static const int kTwoPassMinLog = 9;
@@ -179,8 +197,11 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
     int ndev = swiftly_hip_device_count();
     if (ndev <= 0) return fail(SWIFTLY_ERR_HIP, "no HIP device visible: the SwiFTly HIP backend has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(SWIFTLY_ERR_PARAM, "invalid device %d", device);
-    HIP_TRY(hipSetDevice(device));
-    if (!g_inited) {
+    DeviceGuard guard(device);
+    if (guard.rc) return fail(SWIFTLY_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString((hipError_t)guard.rc));
+    std::lock_guard<std::mutex> init_lock(g_init_mutex);
+    if ((int)g_device_inited.size() < ndev) g_device_inited.resize(ndev, 0);
+    if (!g_device_inited[device]) {
         if (int rc = init_fft_rows_f32()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (f32): %d", rc);
         if (int rc = init_fft_rows_f64()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (f64): %d", rc);
         if (int rc = init_col_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (col pass): %d", rc);
@@ -194,7 +215,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
         }
         (void)hipGetLastError();
-        g_inited = true;
+        g_device_inited[device] = 1;
     }
     swiftly_hip* h = new (std::nothrow) swiftly_hip();
     if (!h) return fail(SWIFTLY_ERR_HIP, "out of host memory");
@@ -245,6 +266,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
 
 void swiftly_hip_destroy(swiftly_hip_t* h) {
     if (!h) return;
+    DeviceGuard guard(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -535,6 +557,8 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     A.conj_st = 0;
     A.scale = (R)1;
     A.accumulate = 0;
+    A.st_rowmap = nullptr;  // output-side maps / windows belong to pass B
+    A.row_win = nullptr;
     int rc = launch_checked(l1, A, tab, st);
     if (!rc) {
         RowsArgs<R> B = a;
@@ -546,6 +570,7 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
         B.in_os = (long long)n2 * W;
         B.in_bs = (long long)(n * W);
         B.rm_mod = 0;
+        B.in_rowmap = nullptr;  // the scratch is indexed by plain (k1, y2), never through the compaction map
         B.outer = n1;
         B.st_mul = n1;
         B.st_addmul = 1;
@@ -596,6 +621,8 @@ static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, const Batch& bt, i
 
 #define CHECK_COMMON()                                                                       \
     if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");                  \
+    DeviceGuard device_guard_(h->device);                                                    \
+    if (device_guard_.rc) return fail(SWIFTLY_ERR_HIP, "hipSetDevice(%d) failed", h->device); \
     if (rows < 0) return fail(SWIFTLY_ERR_PARAM, "negative row count");                      \
     if (dtype != SWIFTLY_C64 && dtype != SWIFTLY_C128) return fail(SWIFTLY_ERR_PARAM, "bad dtype %d", dtype); \
     if (in_cs < 0 || out_cs < 0 || in_cs >= (int64_t(1) << 32) || out_cs >= (int64_t(1) << 32)) \
@@ -603,6 +630,11 @@ static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, const Batch& bt, i
     if (rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "too many rows");
 #define CHECK_BATCH()                                                                        \
     if (nbatch < 0 || in_bs < 0 || out_bs < 0) return fail(SWIFTLY_ERR_PARAM, "bad batch description");
+// The accumulating entry points read-modify-write their output non-atomically and run the batch items
+// concurrently: items that share output elements would lose updates.
+#define CHECK_ACCUMULATE_BATCH()                                                             \
+    if (nbatch > 1 && out_bs == 0)                                                           \
+        return fail(SWIFTLY_ERR_PARAM, "accumulating batch items must not share output elements (out_batch_stride = 0)");
 
 template <typename R>
 static void fill_io(RowsArgs<R>& a, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
@@ -814,6 +846,7 @@ int swiftly_hip_add_to_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in
                                      void* stream) {
     CHECK_COMMON();
     CHECK_BATCH();
+    CHECK_ACCUMULATE_BATCH();
     Batch bt{nbatch, in_bs, out_bs, facet_offs, 0};
     return DISPATCH(do_add_to_subgrid, h, in, rows, in_rs, in_cs, out, out_rs, out_cs, facet_off, bt, (hipStream_t)stream);
 }
@@ -883,6 +916,7 @@ int swiftly_hip_add_to_facet_batch(swiftly_hip_t* h, int dtype, const void* in, 
                                    void* stream) {
     CHECK_COMMON();
     CHECK_BATCH();
+    CHECK_ACCUMULATE_BATCH();
     Batch bt{nbatch, in_bs, out_bs, subgrid_offs, 0};
     if (dtype == SWIFTLY_C64)
         return run_modcopy<float, true>(h, in, rows, in_rs, in_cs, out, out_rs, out_cs, subgrid_off, bt, (hipStream_t)stream);
@@ -918,6 +952,7 @@ int swiftly_hip_sum_finish_rows(swiftly_hip_t* h, int dtype, const void* in, int
                                 const int64_t* subgrid_offs, int64_t subgrid_size, const void* mask,
                                 int64_t mask_batch_stride, int64_t nbatch, void* stream) {
     if (!h || !in || !out || !group_facet_offs || !subgrid_offs) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
     CHECK_SUBGRID_SIZE();
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_rows: complex64 only");
     if (ngroups <= 0 || ngroups > kSumFinishMaxGroups)
@@ -960,6 +995,7 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
                                             int64_t out_col_stride, int64_t out_batch_stride, int64_t facet_off0,
                                             int64_t nsub, const int64_t* subgrid_off1s, void* stream) {
     if (!h || !in || !out || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: complex64 only");
     const int m = (int)h->m, xM = (int)h->xM, yN = (int)h->yN;
     if (h->log_m < kColPassMinLog || h->log_m > kColPassMaxLog || h->log_yN < 0)

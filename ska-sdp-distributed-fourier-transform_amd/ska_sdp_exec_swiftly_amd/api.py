@@ -12,14 +12,20 @@ What changes relative to the reference, and why:
   (``dask_client`` / ``client`` are accepted and ignored).
 * "Tasks" are device tensors: work is enqueued asynchronously on the current
   HIP stream, so ``get_subgrid_task`` returns immediately with a tensor whose
-  contents are ready in stream order (the counterpart of a Dask future);
-  ``queue_size`` bounds how many finished subgrids stay referenced.
+  contents are ready in stream order (the counterpart of a Dask future).
+  ``queue_size`` keeps the meaning it has in the reference's ``TaskQueue``
+  (api.py:466-522): at most that many submitted tasks may be unfinished; the
+  submitting host thread blocks on the oldest one beyond that
+  (:class:`TaskQueue`, HIP events instead of ``distributed.wait``).
 * facets and all intermediates (``BF_F`` per facet, the per-``off0`` column
   cache of ``lru_forward`` / ``lru_backward`` entries) live in HBM for the
   whole run.
 * ``get_subgrid_tasks`` / ``add_new_subgrid_tasks`` (extensions) process a
   whole subgrid column ("wave") per launch sequence; the single-subgrid
   methods are the same code with a wave of one.
+* ``backend="numpy"`` (the reference default) is not available here -- this
+  package has no CPU path by design -- and raises a ``ValueError`` that says
+  so; pass ``backend="hip"`` (the default of THIS package).
 """
 import logging
 
@@ -34,6 +40,8 @@ __all__ = [
     "SwiftlyForward",
     "SwiftlyBackward",
     "LRUCache",
+    "TaskQueue",
+    "preferred_wave_axis",
     "make_full_facet_cover",
     "make_full_subgrid_cover",
     "make_full_cover_config",
@@ -137,6 +145,12 @@ class SwiftlyConfig:
         self.dask_client = dask_client  # unused: there is no Dask in this backend
         if backend == "hip":
             self._core = SwiftlyCoreHip(W, N, xM_size, yN_size)
+        elif backend in ("numpy", "ska_sdp_func"):
+            # reference api.py:137-141 -- those cores live in the reference package; this one is GPU only
+            raise ValueError(
+                f"SwiFTly backend {backend!r} is provided by ska_sdp_exec_swiftly itself; "
+                "ska_sdp_exec_swiftly_amd only implements backend='hip' (no CPU fallback)"
+            )
         else:
             raise ValueError(f"Unknown SwiFTly backend: {backend}")
         # the reference wraps a scattered core in dask.delayed (api.py:145-147)
@@ -221,14 +235,85 @@ class LRUCache:
             yield old_key, self._items.pop(old_key)
 
 
+class TaskQueue:
+    """Bounded queue of in-flight tasks (reference api.py:466-522).
+
+    The reference submits Dask tasks and, once ``max_task`` of them are
+    unfinished, blocks in ``distributed.wait(..., FIRST_COMPLETED)``.  Here a
+    task is a device tensor whose producing kernels have been enqueued on a HIP
+    stream; "finished" means a HIP event recorded right after them has
+    completed.  ``process`` records such an event per task and, while
+    ``max_task`` or more are unfinished, blocks the submitting host thread on
+    the OLDEST one (stream order makes the oldest the first to complete), so
+    the host never runs more than ``max_task`` tasks ahead of the GPU and the
+    scratch memory those tasks pin stays bounded.
+
+    :param max_task: queue size
+    :param event_factory: callable returning an object with ``record()``,
+        ``query() -> bool`` and ``synchronize()`` (default: ``torch.cuda.Event``)
+    """
+
+    def __init__(self, max_task, event_factory=None):
+        self.max_task = max(1, int(max_task))
+        self.task_queue = []  # [(event, task)], oldest first
+        self._event_factory = event_factory
+
+    def _new_event(self):
+        if self._event_factory is not None:
+            return self._event_factory()
+        return _torch().cuda.Event()
+
+    def empty_done(self):
+        """drop finished tasks from the queue (reference api.py:497-509)"""
+        self.task_queue = [(ev, task) for ev, task in self.task_queue if not ev.query()]
+
+    def process(self, task_list):
+        """submit tasks; blocks while the queue is full (reference api.py:478-495)"""
+        for task in task_list:
+            while len(self.task_queue) >= self.max_task:
+                self.task_queue[0][0].synchronize()
+                self.empty_done()
+            ev = self._new_event()
+            ev.record()
+            self.task_queue.append((ev, task))
+        return task_list
+
+    def wait_all_done(self):
+        """block until every submitted task has finished (reference api.py:511-522)"""
+        for ev, _ in self.task_queue:
+            ev.synchronize()
+        self.empty_done()
+        if self.task_queue:
+            raise RuntimeError("Some tasks did not finish")
+
+
 def _torch():
     import torch  # pylint: disable=import-outside-toplevel
 
     return torch
 
 
+def preferred_wave_axis(swiftly_config, dtype=None):  # pylint: disable=unused-argument
+    """Which subgrid offset the forward engine groups "waves" by for row-major
+    facets: 0 = ``off0`` (the reference's column cache key, api.py:300-324),
+    1 = ``off1`` (full-facet transform along the contiguous axis first; the
+    axis order is free, the transforms are separable)."""
+    return 0
+
+
+K1_DESCRIPTION = {
+    0: "K1 prepare_facet(axis=0) per facet = col_pass<n1=128, mapped load> + col_pass<n2=256, mapped store>",
+}
+
+
 _MASK_CACHE = {}
-_MASK_CACHE_MAX = 512
+_MASK_CACHE_MAX = 4096
+
+
+def _mask_cache_put(key, value):
+    if len(_MASK_CACHE) >= _MASK_CACHE_MAX:
+        _MASK_CACHE.pop(next(iter(_MASK_CACHE)))
+    _MASK_CACHE[key] = value
 
 
 def _mask_table(core, configs, which, size, cdtype):
@@ -238,8 +323,15 @@ def _mask_table(core, configs, which, size, cdtype):
     ordered behind everything already queued on the stream, i.e. it would stall
     the host once per wave."""
     torch = _torch()
+    # fast path: the same config objects as last time (waves are re-requested every pass); the cache entry
+    # keeps the configs alive, so their ids cannot be recycled while it exists
+    idkey = (str(core.device), str(cdtype), which, size, tuple(id(c) for c in configs))
+    hit = _MASK_CACHE.get(idkey)
+    if hit is not None:
+        return hit[1]
     masks = [getattr(c, which) for c in configs]
     if all(m is None for m in masks):
+        _mask_cache_put(idkey, (tuple(configs), None))
         return None
     tab = numpy.ones((len(configs), size))
     for i, m in enumerate(masks):
@@ -247,14 +339,12 @@ def _mask_table(core, configs, which, size, cdtype):
             tab[i] = numpy.asarray(m, dtype=float)
     key = (str(core.device), str(cdtype), tab.shape, tab.tobytes())
     hit = _MASK_CACHE.get(key)
-    if hit is not None:
-        return hit
-    rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
-    dev_tab = torch.from_numpy(tab).to(device=core.device, dtype=rdtype).contiguous()
-    if len(_MASK_CACHE) >= _MASK_CACHE_MAX:
-        _MASK_CACHE.pop(next(iter(_MASK_CACHE)))
-    _MASK_CACHE[key] = dev_tab
-    return dev_tab
+    if hit is None:
+        rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
+        hit = (None, torch.from_numpy(tab).to(device=core.device, dtype=rdtype).contiguous())
+        _mask_cache_put(key, hit)
+    _mask_cache_put(idkey, (tuple(configs), hit[1]))
+    return hit[1]
 
 
 class SwiftlyForward:
@@ -266,17 +356,25 @@ class SwiftlyForward:
         once and stays in HBM)
     :param lru_forward: number of subgrid columns (distinct ``off0``) whose
         prepared facet columns ``NMBF_BF`` are kept
-    :param queue_size: kept for signature compatibility (bounds in-flight
-        subgrid tasks in the reference; here the HIP stream is the queue)
+    :param queue_size: bound on unfinished subgrid tasks (reference
+        ``TaskQueue``, api.py:466-522): ``get_subgrid_task`` blocks the host
+        while that many earlier results are still being computed
     :param subgrid_configs: optional (extension) list of all subgrids that will
         be requested; enables row-compacted ``BF_F`` for sparse subgrid sets
     """
 
     # pylint: disable=too-many-arguments,too-many-instance-attributes
-    def __init__(self, swiftly_config, facet_tasks, lru_forward=1, queue_size=20, client=None, subgrid_configs=None):
+    def __init__(
+        self, swiftly_config, facet_tasks, lru_forward=1, queue_size=20, client=None, subgrid_configs=None,
+        wave_axis=None,
+    ):
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facet_tasks = facet_tasks
+        self.wave_axis = 0 if wave_axis is None else int(wave_axis)
+        if self.wave_axis not in (0, 1):
+            raise ValueError("wave_axis must be 0 or 1")
+        self.task_queue = TaskQueue(queue_size)
         # optional plan (extension): when the caller knows up front which subgrids it will ask for (sparse
         # covers, scripts/demo_sparse_facet.py style), BF_F only keeps the rows those columns read
         self._rowmap, self._n_rows = None, None
@@ -288,6 +386,7 @@ class SwiftlyForward:
         self._client = client
         self.lru = LRUCache(lru_forward)
         self.BF_Fs_persist = None
+        self._prewindowed = False
         torch = _torch()
         self._facets = []
         for _, data in facet_tasks:
@@ -299,33 +398,44 @@ class SwiftlyForward:
         self.dtype = dtypes.pop() if dtypes else torch.complex64
 
     # -- stage 1: BF_F = prepare_facet(axis 0), once per facet (api.py:281-298)
-    def _get_BF_Fs(self):
+    def _prepare_one_facet(self, j):
+        """BF_F of facet ``j`` as the streaming classes keep it: (optionally) row-compacted and with the
+        axis-1 window of extract_column already applied (it commutes with the axis-0 transform), so the
+        column kernel has no window loads; complex128 and unsupported sizes use the plain primitive."""
+        cfg, data = self.facet_configs[j], self._facets[j]
+        n_rows = self._n_rows if self._rowmap is not None else self.core.yN_size
+        if self._prewindowed or self._rowmap is not None:
+            return self.core.prepare_facet_rows(
+                data, cfg.off0, self._rowmap, n_rows, fold_axis1_window=self._prewindowed
+            )
+        return self.core.prepare_facet(data, cfg.off0, axis=0)
+
+    def prepare_all_facets(self, timer=None):
+        """Stage 1 for every facet (idempotent).  ``timer`` (optional, bench.py's
+        StageTimer) brackets each facet's launch group with HIP events."""
         if self.BF_Fs_persist is None:
-            # BF_F as the streaming classes keep it: (optionally) row-compacted and with the axis-1 window of
-            # extract_column already applied (it commutes with the axis-0 transform), so the column kernel
-            # has no window loads; complex128 and unsupported sizes use the plain primitive
-            torch = _torch()
-            self._prewindowed = self.dtype == torch.complex64
-            n_rows = self._n_rows if self._rowmap is not None else self.core.yN_size
-            if self._prewindowed or self._rowmap is not None:
-                self.BF_Fs_persist = [
-                    self.core.prepare_facet_rows(
-                        data, cfg.off0, self._rowmap, n_rows, fold_axis1_window=self._prewindowed
-                    )
-                    for cfg, data in zip(self.facet_configs, self._facets)
-                ]
-            else:
-                self.BF_Fs_persist = [
-                    self.core.prepare_facet(data, cfg.off0, axis=0)
-                    for cfg, data in zip(self.facet_configs, self._facets)
-                ]
+            self._prewindowed = self.dtype == _torch().complex64
+            out = []
+            for j in range(len(self.facet_configs)):
+                t0 = timer.start() if timer is not None else None
+                out.append(self._prepare_one_facet(j))
+                if timer is not None:
+                    timer.stop("K1_full_facet_transform", t0)
+            self.BF_Fs_persist = out
         return self.BF_Fs_persist
+
+    def _get_BF_Fs(self):
+        return self.prepare_all_facets()
 
     # -- stage 2: per subgrid column (api.py:300-324)
     def get_NMBF_BFs_off0(self, off0, BF_Fs=None):
         """prepared facet columns for subgrid column ``off0`` (LRU cached)"""
         if BF_Fs is None:
             BF_Fs = self._get_BF_Fs()
+        elif BF_Fs is not self.BF_Fs_persist:
+            # BF_Fs_persist holds pre-windowed / row-compacted data (see _prepare_one_facet); a plain
+            # prepare_facet(axis=0) result would silently miss the axis-1 window
+            raise ValueError("get_NMBF_BFs_off0 only accepts the BF_Fs this object prepared itself")
         cols = self.lru.get(off0)
         if cols is None:
             if self._rowmap is not None and int(off0) not in self._planned_off0:
@@ -336,9 +446,7 @@ class SwiftlyForward:
                 (len(BF_Fs), core.xM_yN_size, core.yN_size), dtype=self.dtype, device=core.device
             )
             for j, (cfg, BF_F) in enumerate(zip(self.facet_configs, BF_Fs)):
-                core.extract_column(
-                    BF_F, off0, cfg.off1, out=cols[j], rowmap=self._rowmap, prewindowed=getattr(self, "_prewindowed", False)
-                )
+                core.extract_column(BF_F, off0, cfg.off1, out=cols[j], rowmap=self._rowmap, prewindowed=self._prewindowed)
             self.lru.set(off0, cols)
         return cols
 
@@ -348,23 +456,44 @@ class SwiftlyForward:
         (reference api.py:238-253)."""
         return self.get_subgrid_tasks([subgrid_config])[0]
 
+    def _key(self, sg):
+        return sg.off1 if self.wave_axis == 1 else sg.off0
+
     def get_subgrid_tasks(self, subgrid_configs):
         """Finished subgrids for a list of configs; consecutive configs with the
-        same ``off0`` and ``size`` are processed as one wave."""
+        same wave key (``off0``, or ``off1`` when ``wave_axis == 1``) and
+        ``size`` are processed as one wave.  Each result is registered with the
+        task queue (``queue_size``)."""
         out = []
         i = 0
         while i < len(subgrid_configs):
             j = i + 1
             while (
                 j < len(subgrid_configs)
-                and subgrid_configs[j].off0 == subgrid_configs[i].off0
+                and self._key(subgrid_configs[j]) == self._key(subgrid_configs[i])
                 and subgrid_configs[j].size == subgrid_configs[i].size
             ):
                 j += 1
-            res = self._wave(subgrid_configs[i:j])
-            out.extend(res[k] for k in range(j - i))
+            res = self.get_wave(subgrid_configs[i:j])
+            tasks = [res[k] for k in range(j - i)]
+            self.task_queue.process(tasks)
+            out.extend(tasks)
             i = j
         return out
+
+    def get_wave(self, sgs, timer=None):
+        """Finished, masked subgrids ``[S, xA, xA]`` of one wave (configs sharing
+        the wave key and size).  ``timer`` brackets the stages with HIP events."""
+        self.prepare_all_facets()
+        t0 = timer.start() if timer is not None else None
+        self.get_NMBF_BFs_off0(sgs[0].off0)
+        if timer is not None:
+            timer.stop("K2_wave_facet_transform", t0)
+            t0 = timer.start()
+        res = self._wave(sgs)
+        if timer is not None:
+            timer.stop("K345_extract_sum_finish", t0)
+        return res
 
     def wave_contributions(self, sgs):
         """Contributions of every (local) facet to the subgrids ``sgs`` (same

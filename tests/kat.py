@@ -7,7 +7,7 @@ Every function takes ``make_core(params) -> core`` and the absolute tolerances
 to use; the reference's own tolerances are the defaults (complex128).
 Truth is the direct DFT of point sources (``make_subgrid_from_sources`` /
 ``make_facet_from_sources`` restated in oracle/swiftly_oracle.py and pinned by
-tests/test_oracle_truth.py).
+tests/test_oracle_known_answers.py and tests/test_oracle_golden.py).
 """
 import itertools
 

@@ -147,6 +147,13 @@ def test_sparse_plan_is_bit_identical():
     assert plan.BF_Fs_persist[0].shape[0] == plan._n_rows
     for x, y in zip(a, b):
         assert numpy.array_equal(x, y)
+    # ... and the planned path agrees with the ORACLE (not only with the other HIP path)
+    ref = orc.OracleCore(SMALL11_PARAMS["W"], SMALL11_PARAMS["N"], SMALL11_PARAMS["xM_size"], SMALL11_PARAMS["yN_size"])
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    sitems = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in wanted]
+    want = orc.forward_all(ref, items, [f.astype(complex) for f in facets], sitems)
+    for y, w in zip(b, want):
+        assert relrms(y, w) < 2e-5
     with pytest.raises(ValueError):
         plan.get_subgrid_task([c for c in sg_cfgs if c.off0 == 96][0])
 

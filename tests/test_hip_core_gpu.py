@@ -185,12 +185,12 @@ P = TEST_PARAMS
 @pytest.mark.parametrize("xA", [P["xA_size"], P["xA_size"] - 1])
 @pytest.mark.parametrize("yB", [P["yB_size"], P["yB_size"] - 1])
 def test_kat_facet_to_subgrid_basic(xA, yB):
-    kat.facet_to_subgrid_basic(hip_core, xA, yB, thin=3)
+    kat.facet_to_subgrid_basic(hip_core, xA, yB)
 
 
 @pytest.mark.parametrize("xA,yB", [(P["xA_size"], P["yB_size"]), (P["xA_size"] - 1, P["yB_size"] - 1)])
 def test_kat_facet_to_subgrid_dft_1d(xA, yB):
-    kat.facet_to_subgrid_dft_1d(hip_core, xA, yB, thin=4)
+    kat.facet_to_subgrid_dft_1d(hip_core, xA, yB)
 
 
 def test_kat_facet_to_subgrid_dft_2d():
@@ -199,12 +199,12 @@ def test_kat_facet_to_subgrid_dft_2d():
 
 @pytest.mark.parametrize("xA,yB", [(P["xA_size"], P["yB_size"]), (P["xA_size"] - 1, P["yB_size"] - 1)])
 def test_kat_subgrid_to_facet_basic(xA, yB):
-    kat.subgrid_to_facet_basic(hip_core, xA, yB, thin=4)
+    kat.subgrid_to_facet_basic(hip_core, xA, yB)
 
 
 @pytest.mark.parametrize("xA,yB", [(P["xA_size"], P["yB_size"]), (P["xA_size"] - 1, P["yB_size"] - 1)])
 def test_kat_subgrid_to_facet_dft(xA, yB):
-    kat.subgrid_to_facet_dft(hip_core, xA, yB, thin=4)
+    kat.subgrid_to_facet_dft(hip_core, xA, yB)
 
 
 def test_kat_subgrid_to_facet_dft_2d():
@@ -214,9 +214,9 @@ def test_kat_subgrid_to_facet_dft_2d():
 def test_kat_complex64():
     """Same known answers in complex64 with float32-appropriate bounds
     (values are O(1/N) ~ 1e-3 forward, O(1) backward)."""
-    kat.facet_to_subgrid_basic(hip_core, P["xA_size"], P["yB_size"], tol=3e-9, dtype=numpy.complex64, thin=5)
+    kat.facet_to_subgrid_basic(hip_core, P["xA_size"], P["yB_size"], tol=3e-9, dtype=numpy.complex64)
     kat.facet_to_subgrid_dft_2d(hip_core, tol=5e-8, dtype=numpy.complex64)
-    kat.subgrid_to_facet_basic(hip_core, P["xA_size"], P["yB_size"], tol=2e-5, dtype=numpy.complex64, thin=6)
+    kat.subgrid_to_facet_basic(hip_core, P["xA_size"], P["yB_size"], tol=2e-5, dtype=numpy.complex64)
 
 
 @pytest.mark.parametrize("logn", range(3, 16))

@@ -1,0 +1,150 @@
+"""
+GPU tests of the robustness contract of the drop-in boundary:
+  * pickling like SwiftlyCoreFunc (reference core.py:512-525): only the four parameters travel;
+  * one core shared by many host threads (the reference scatters ONE core object to every Dask worker
+    thread, api.py:145-147; 38 threads/worker in slurm_scripts/run_distr_single_csd3.slurm:71);
+  * the accumulate entry points refuse batch items that share output elements;
+  * extract_column with a row map on a BF_F whose transform axis is strided (the generic
+    four-step path used to index its scratch through the row map).
+"""
+import pickle
+import threading
+
+import numpy
+import pytest
+
+from oracle import swiftly_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+P = dict(W=11.0, N=512, yB_size=176, yN_size=256, xA_size=96, xM_size=128)
+
+
+def _core():
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    return SwiftlyCoreHip(P["W"], P["N"], P["xM_size"], P["yN_size"])
+
+
+def _chain(core, facet, fo, so, xA):
+    bf = core.prepare_facet(facet, fo, axis=0)
+    c = core.extract_from_facet(bf, so, axis=0)
+    acc = core.add_to_subgrid(c, fo, axis=0)
+    return core.finish_subgrid(acc, so, xA)
+
+
+def test_pickle_roundtrip():
+    core = _core()
+    clone = pickle.loads(pickle.dumps(core))
+    assert (clone.W, clone.N, clone.xM_size, clone.yN_size) == (core.W, core.N, core.xM_size, core.yN_size)
+    assert clone._handle and clone._handle.value != core._handle.value  # a fresh native handle
+    rng = numpy.random.default_rng(1)
+    facet = rng.standard_normal(P["yB_size"]) + 1j * rng.standard_normal(P["yB_size"])
+    a = _chain(core, facet, 8, 6, P["xA_size"])
+    b = _chain(clone, facet, 8, 6, P["xA_size"])
+    assert numpy.array_equal(a, b)
+    # the state carries no device pointers
+    assert set(core.__getstate__()) == {"W", "N", "xM_size", "yN_size"}
+
+
+def test_eight_threads_share_one_core():
+    core = _core()
+    ref = orc.OracleCore(P["W"], P["N"], P["xM_size"], P["yN_size"])
+    nthreads, reps = 8, 25
+    rng = numpy.random.default_rng(2)
+    facets = rng.standard_normal((nthreads, P["yB_size"])) + 1j * rng.standard_normal((nthreads, P["yB_size"]))
+    offs = [(4 * (3 * i - 7), 2 * (5 * i - 11)) for i in range(nthreads)]
+    want = [_chain(ref, facets[i], offs[i][0], offs[i][1], P["xA_size"]) for i in range(nthreads)]
+    errors = []
+    barrier = threading.Barrier(nthreads)
+
+    def work(i):
+        try:
+            barrier.wait()
+            for _ in range(reps):
+                got = _chain(core, facets[i], offs[i][0], offs[i][1], P["xA_size"])
+                err = numpy.abs(got - want[i]).max()
+                if not err <= 1e-11 * numpy.abs(want[i]).max():
+                    errors.append((i, float(err)))
+                    return
+        except Exception as exc:  # pylint: disable=broad-except
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_handles_created_concurrently():
+    """swiftly_hip_create from several threads at once (per-device one-time setup is locked)."""
+    made, errors = [], []
+
+    def work():
+        try:
+            made.append(_core())
+        except Exception as exc:  # pylint: disable=broad-except
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(made) == 6
+    x = numpy.ones(P["yB_size"], dtype=complex)
+    outs = [c.prepare_facet(x, 0, axis=0) for c in made]
+    assert all(numpy.array_equal(outs[0], o) for o in outs[1:])
+
+
+def test_accumulating_batches_must_not_overlap():
+    import torch
+
+    core = _core()
+    m, xM = core.xM_yN_size, core.xM_size
+    src = torch.zeros((2, 4, m), dtype=torch.complex128, device="cuda")
+    dst = torch.zeros((4, xM), dtype=torch.complex128, device="cuda")
+    with pytest.raises(ValueError):
+        core.launch("add_to_subgrid", src, 4, m, 1, dst, xM, 1, 0, nbatch=2, in_bs=4 * m, out_bs=0)
+    dstf = torch.zeros((4, core.yN_size), dtype=torch.complex128, device="cuda")
+    with pytest.raises(ValueError):
+        core.launch("add_to_facet", src, 4, m, 1, dstf, core.yN_size, 1, 0, nbatch=2, in_bs=4 * m, out_bs=0)
+    # distinct outputs are fine
+    dst2 = torch.zeros((2, 4, xM), dtype=torch.complex128, device="cuda")
+    core.launch("add_to_subgrid", src, 4, m, 1, dst2, xM, 1, 0, nbatch=2, in_bs=4 * m, out_bs=4 * xM)
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128])
+def test_extract_column_rowmap_on_strided_bf(dtype):
+    """Row-compacted BF_F stored TRANSPOSED (transform axis strided): goes through the generic two-pass
+    route for long transforms; result must equal the contiguous-layout call and the oracle."""
+    import torch
+
+    W, N, xM, yN, yB = 11.0, 4096, 512, 2048, 1408  # yN >= 512 on a strided axis -> four-step
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    core = SwiftlyCoreHip(W, N, xM, yN)
+    ref = orc.OracleCore(W, N, xM, yN)
+    m = core.xM_yN_size
+    off0s = [0, 3 * 448, -5 * 448]
+    rowmap, n_rows = core.subgrid_column_rows(off0s)
+    rng = numpy.random.default_rng(3)
+    ncol = 40  # "facet size" along the other axis of this slab
+    full = (rng.standard_normal((yN, ncol)) + 1j * rng.standard_normal((yN, ncol))).astype(dtype)
+    rm = rowmap.cpu().numpy()
+    compact = numpy.zeros((n_rows, ncol), dtype=dtype)
+    compact[rm[rm >= 0]] = full[rm >= 0]
+    bf_c = torch.from_numpy(compact).cuda()                      # [n_rows, ncol], transform axis (1) contiguous
+    bf_t = torch.from_numpy(numpy.ascontiguousarray(compact.T)).cuda().T  # same values, axis 1 strided
+    assert bf_t.stride() == (1, n_rows)
+    for off0 in off0s:
+        a = core.extract_column(bf_c, off0, 1408, rowmap=rowmap).cpu().numpy()
+        b = core.extract_column(bf_t, off0, 1408, rowmap=rowmap).cpu().numpy()
+        want = orc.extract_column(ref, full.astype(complex), off0, 1408)
+        tol = 2e-6 if dtype == numpy.complex64 else 1e-12
+        for got in (a, b):
+            assert got.shape == (m, yN)
+            rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+            assert rel < tol, rel
