@@ -273,6 +273,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle parity check of the timed objects")
     ap.add_argument("--verify", action="store_true", help="(default) kept for explicitness")
+    ap.add_argument("--wave-axis", type=int, default=None, choices=[0, 1],
+                    help="force the forward pipeline: 0 = strided axis first (waves by off0), 1 = contiguous axis first")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -314,6 +316,8 @@ def main():
     force_dist = os.environ.get("SWIFTLY_BENCH_FORCE_DIST") == "1"  # exercise the multi-GPU code path on 1 GPU
     single = world == 1 and not force_dist
     wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64) if single else 0
+    if args.wave_axis is not None and single:
+        wave_axis = args.wave_axis
     key = (lambda c: c.off1) if wave_axis == 1 else (lambda c: c.off0)
     waves = {}
     for i, c in enumerate(sg_cfgs):

@@ -32,7 +32,11 @@
  *    a power of two in [8, 32768] (complex64) / [8, 8192] (complex128).
  *  - a handle is immutable after creation and may be used concurrently from
  *    several host threads / streams (the reference scatters one core object
- *    to all Dask worker threads, api.py:145-147).
+ *    to all Dask worker threads, api.py:145-147).  Handles may be created
+ *    concurrently and on several devices of one process; every entry point
+ *    makes the handle's device current for the duration of the call and
+ *    restores the caller's current device afterwards (`stream` must belong to
+ *    the handle's device).
  */
 #ifndef SWIFTLY_HIP_H
 #define SWIFTLY_HIP_H
@@ -134,7 +138,10 @@ int swiftly_hip_finish_facet(swiftly_hip_t* h, int dtype, const void* in, int64_
  *
  * *_batch: `nbatch` independent problems of identical shape; item b reads
  * in + b*in_batch_stride and writes out + b*out_batch_stride (strides in
- * complex elements; in_batch_stride = 0 shares one input).  `offs` is a HOST
+ * complex elements; in_batch_stride = 0 shares one input; the ACCUMULATING
+ * entry points add_to_subgrid_batch / add_to_facet_batch run the items
+ * concurrently with plain read-modify-write, so items must not share output
+ * elements: out_batch_stride = 0 with nbatch > 1 is SWIFTLY_ERR_PARAM).  `offs` is a HOST
  * array of nbatch per-item offsets, or NULL to use the scalar offset for all
  * items.  `mask` (finish_*): item b uses mask + b*mask_batch_stride (real
  * elements; 0 = one shared mask).  One launch covers up to 64 items. */
@@ -223,6 +230,74 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
                                             int64_t in_facet_stride, int64_t nfacets, void* out,
                                             int64_t out_col_stride, int64_t out_batch_stride, int64_t facet_off0,
                                             int64_t nsub, const int64_t* subgrid_off1s, void* stream);
+
+/* -- contiguous-axis-first forward pipeline ----------------------------------------------------------------
+ *
+ * The 2-D transforms of the reference are separable, so the order in which api_helper.extract_column
+ * (api_helper.py:200-210) visits the axes is free (it does axis 0 on the whole facet, then axis 1 per subgrid
+ * column).  On a row-major facet the cheap order is the other one: the full-facet pass runs along the CONTIGUOUS
+ * axis in ONE kernel (no four-step scratch), keeps only the output columns some planned subgrid reads, and the
+ * strided-axis transform moves to the per-wave stage where it acts on m columns only.  complex64.
+ *
+ *   P_f   = prepare_facet_band(facet_f)                      once per facet       [yB, band]      K1
+ *   Q_f   = prepare_facet_columns(P_f, wave off1)            per subgrid wave     [rows kept, m]  K2
+ *   G_f,b = transform_contributions(Q_f, subgrid b)          per (facet, subgrid) [m, m]          K3+K4a
+ *   T_b   = sum_finish_facets(G_.,b)                         per subgrid          [xM, xA]        K4b+K5a
+ *   S_b   = finish_subgrid_batch(T_b, axis 0)                per subgrid          [xA, xA]        K5b
+ */
+
+/* Number of physical columns of a band buffer holding `band_len` logical columns (parity-split layout: the
+ * logical column with cyclic distance d from band_start lives at (d & 1) * ((band_len + 1) / 2) + (d >> 1)). */
+int64_t swiftly_hip_band_columns(int64_t band_len);
+
+/* K1: Swiftly.prepare_facet(in[rows, facet_size], ., facet_off) (core.py:686; numpy form core.py:212-222) along
+ * the contiguous axis for every row of a facet, keeping only the centred output indices in the cyclic range
+ * [band_start, band_start + band_len) of [0, yN) (band_len = yN keeps everything), parity-split (see above);
+ * out[rows, band_columns(band_len)], row stride out_row_stride.  fold_other_axis_window != 0 also multiplies row r
+ * by 1/pswf of the OTHER axis (facet size `rows`) -- the window prepare_facet applies along that axis later;
+ * windows commute with transforms along the orthogonal axis.  yN = 32768 only (SWIFTLY_ERR_UNSUPPORTED else). */
+int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
+                                   int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
+                                   int64_t band_start, int64_t band_len, int fold_other_axis_window, void* stream);
+
+/* K2: for every facet f < nfacets: extract_from_facet(P_f, subgrid_off1, axis=1) (core.py:715) folded into the load
+ * of prepare_facet(., facet_off0s[f], axis=0) WITHOUT its window (pre-applied by prepare_facet_band).
+ * in + f*in_facet_stride = band buffer P_f[rows, band], out + f*out_facet_stride = Q_f[., m] with row stride
+ * out_row_stride; out_rowmap (device int32[yN], optional): physical output row of logical row k, negative = not
+ * stored (the rows no subgrid of the plan reads).  facet_off0s is a HOST array. */
+int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+                                      int64_t in_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
+                                      int64_t band_start, int64_t band_len, int64_t subgrid_off1, void* out,
+                                      int64_t out_row_stride, int64_t out_facet_stride, const int32_t* out_rowmap,
+                                      void* stream);
+
+/* K3 + K4a: out[f][b][k, j] = Fn[k] * cfft_m(C_{f,b}[:, j])[(k + s'0_f) mod m]  --  add_to_subgrid(axis 0)
+ * (core.py:744, numpy form core.py:274-285) of the [m, m] contribution C_{f,b} WITHOUT its placement into the
+ * padded subgrid (row k belongs to padded row (k + xM/2 - m/2 + s'0_f) mod xM; sum_finish_facets resolves that).
+ * The contribution is gathered on load (extract_from_facet, core.py:243-253, never materialised):
+ *   layout 0: in + f*in_facet_stride = NMBF_BF[m, yN or band] (output of extract_column[_rows]); window of
+ *             subgrid_offs[b] (an off1) along the contiguous axis; band_len > 0: parity-split band columns.
+ *   layout 1: in + f*in_facet_stride = Q_f[rows kept, m] (output of prepare_facet_columns); window of
+ *             subgrid_offs[b] (an off0) along the strided axis through in_rowmap (device int32[yN] or NULL).
+ *   layout 2: in + f*in_facet_stride + b*in_sub_stride = C_{f,b}[m, m] materialised (multi-GPU path).
+ * out[f][b] at out + f*out_facet_stride + b*out_sub_stride, [m, m] row-major.  Overwrites.  Host offset arrays. */
+int swiftly_hip_transform_contributions(swiftly_hip_t* h, int dtype, const void* in, int layout, int64_t in_row_stride,
+                                        int64_t in_facet_stride, int64_t in_sub_stride, const int32_t* in_rowmap,
+                                        int64_t band_start, int64_t band_len, int64_t nfacets,
+                                        const int64_t* facet_off0s, int64_t nsub, const int64_t* subgrid_offs,
+                                        void* out, int64_t out_facet_stride, int64_t out_sub_stride, void* stream);
+
+/* K4b + K5a: for every padded row r < xM of every subgrid b:
+ *   out[b][r, :] = mask_b * finish_subgrid_axis1( sum_f add_to_subgrid_axis1( G[f][b][k_f(r), :], facet_off1s[f] ) )
+ * over the facets whose axis-0 band covers r (k_f(r) = (r - (xM/2 - m/2 + s'0_f)) mod xM < m): the facet sums of
+ * api_helper.sum_and_finish_subgrid (api_helper.py:81-99) re-associated so that no accumulator reaches HBM, plus
+ * finish_subgrid along axis 1 and the mask (api_helper.py:101-111).  in = G from transform_contributions,
+ * out[b] = [xM, subgrid_size].  Up to 64 facets. */
+int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t nfacets, int64_t in_facet_stride,
+                                  int64_t in_sub_stride, int64_t in_row_stride, const int64_t* facet_off0s,
+                                  const int64_t* facet_off1s, void* out, int64_t out_sub_stride, int64_t out_row_stride,
+                                  const int64_t* subgrid_off1s, int64_t subgrid_size, const void* mask,
+                                  int64_t mask_batch_stride, int64_t nsub, void* stream);
 
 /* -- device memory helpers for callers that do not bring their own allocator
  *    (the Python mirror uses torch for device memory and never calls these) -- */

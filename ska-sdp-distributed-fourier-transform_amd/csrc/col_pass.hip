@@ -13,18 +13,18 @@ struct CGeoFor {
 };
 
 template <int LOGN, int MODE>
-static int launch_mode(const ColPassArgs& a, const ColGather& cg, int outer, int nbatch, hipStream_t s) {
+static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     using G = typename CGeoFor<LOGN>::type;
     dim3 grid((unsigned)((a.ncols + 63) / 64), (unsigned)outer, (unsigned)nbatch);
     hipLaunchKernelGGL((col_pass_kernel<G, MODE>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
-                       a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cg);
+                       a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
     return (int)hipGetLastError();
 }
 template <int LOGN>
-static int launch_one(int mode, const ColPassArgs& a, const ColGather& cg, int outer, int nbatch, hipStream_t s) {
-    if (mode == 0) return launch_mode<LOGN, 0>(a, cg, outer, nbatch, s);
-    if (mode == 1) return launch_mode<LOGN, 1>(a, cg, outer, nbatch, s);
-    return launch_mode<LOGN, 2>(a, cg, outer, nbatch, s);
+static int launch_one(int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
+    if (mode == 0) return launch_mode<LOGN, 0>(a, cz, outer, nbatch, s);
+    if (mode == 1) return launch_mode<LOGN, 1>(a, cz, outer, nbatch, s);
+    return launch_mode<LOGN, 2>(a, cz, outer, nbatch, s);
 }
 template <int LOGN, int MODE>
 static int init_mode() {
@@ -43,9 +43,9 @@ static int init_one() {
 
 template <int LO, int HI>
 struct CDispatch {
-    static int launch(int logn, int mode, const ColPassArgs& a, const ColGather& cg, int outer, int nbatch, hipStream_t s) {
-        if (logn == LO) return launch_one<LO>(mode, a, cg, outer, nbatch, s);
-        if constexpr (LO < HI) return CDispatch<LO + 1, HI>::launch(logn, mode, a, cg, outer, nbatch, s);
+    static int launch(int logn, int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
+        if (logn == LO) return launch_one<LO>(mode, a, cz, outer, nbatch, s);
+        if constexpr (LO < HI) return CDispatch<LO + 1, HI>::launch(logn, mode, a, cz, outer, nbatch, s);
         return -1;
     }
     static int init() {
@@ -56,8 +56,8 @@ struct CDispatch {
     }
 };
 
-int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColGather& cg, int outer, int nbatch, hipStream_t s) {
-    return CDispatch<kColPassMinLog, kColPassMaxLog>::launch(logn, mode, a, cg, outer, nbatch, s);
+int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
+    return CDispatch<kColPassMinLog, kColPassMaxLog>::launch(logn, mode, a, cz, outer, nbatch, s);
 }
 int init_col_pass() { return CDispatch<kColPassMinLog, kColPassMaxLog>::init(); }
 

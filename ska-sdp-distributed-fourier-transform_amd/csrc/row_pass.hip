@@ -71,6 +71,53 @@ int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<
     if (variant == 41) return launch_split<SplitGeo4N, 2>(a, tw13, tw_full, s);
     return launch_split<SplitGeo4, 2>(a, tw13, tw_full, s);
 }
+using BandGeo5 = RGeo<14, 5, true>;  // 2 x 16384 points, 512 threads x 32, 66 KB LDS: two workgroups per CU
+using BandGeo4 = RGeo<14, 4, true>;  // 2 x 16384 points, 1024 threads x 16, one workgroup per CU
+template <class G>
+static int launch_band_geo(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
+    const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
+    const bool band = a.band_len > 0;
+#define SWF_LAUNCH_BAND(WIN, BAND)                                                                                  \
+    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, BAND>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, \
+                       a.out, a.ld_win, tw14, tw_full)
+    if (a.ld_win) {
+        if (band) SWF_LAUNCH_BAND(true, true);
+        else SWF_LAUNCH_BAND(true, false);
+    } else {
+        if (band) SWF_LAUNCH_BAND(false, true);
+        else SWF_LAUNCH_BAND(false, false);
+    }
+#undef SWF_LAUNCH_BAND
+    return (int)hipGetLastError();
+}
+int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
+    if (a.nrows <= 0) return 0;
+    // tuning knob SWIFTLY_ROW_GEO: 5 (512 threads x 32 points, two workgroups per CU) | 4 (1024 x 16, one per CU);
+    // default: 5 for the band store (1 spilled VGPR), 4 for the plain store (the 512-thread form spills ~49 there)
+    static const int geo_env = getenv("SWIFTLY_ROW_GEO") ? atoi(getenv("SWIFTLY_ROW_GEO")) : 0;
+    const int geo = geo_env ? geo_env : (a.band_len > 0 ? 5 : 4);
+    if (geo == 4) return launch_band_geo<BandGeo4>(a, tw14, tw_full, s);
+    return launch_band_geo<BandGeo5>(a, tw14, tw_full, s);
+}
+int row_pass_band_occupancy() {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_band_kernel<BandGeo5, true, true>, BandGeo5::NT,
+                                                       BandGeo5::LDS_BYTES);
+    return n;
+}
+template <class G, bool WIN, bool BAND>
+static int init_band() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, BAND>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+}
+template <class G>
+static int init_band_geo() {
+    int rc = init_band<G, true, true>();
+    if (!rc) rc = init_band<G, true, false>();
+    if (!rc) rc = init_band<G, false, true>();
+    if (!rc) rc = init_band<G, false, false>();
+    return rc;
+}
 // occupancy query (blocks per CU) for tuning / DESIGN.md
 int row_pass_half_occupancy(int lds_bytes) {
     int n = -1;
@@ -87,6 +134,11 @@ static int init_split() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 int init_row_pass() {
+    {
+        int rcb = init_band_geo<BandGeo5>();
+        if (!rcb) rcb = init_band_geo<BandGeo4>();
+        if (rcb) return rcb;
+    }
     {
         int rc0 = init_split<SplitGeo2, 1>();
         if (!rc0) rc0 = init_split<SplitGeo2N, 1>();

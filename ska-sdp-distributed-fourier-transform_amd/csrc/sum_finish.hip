@@ -17,6 +17,20 @@ static int init_one() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
 }
 
+template <int LOGM, int LOGX>
+static int launch_one_f(const SumFinishFacetArgs& a, int nbatch, hipStream_t s) {
+    using S = SFGeo<LOGM, LOGX>;
+    dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
+    hipLaunchKernelGGL((sum_finish_facets_kernel<LOGM, LOGX>), grid, dim3(256), S::LDS_BYTES, s, a);
+    return (int)hipGetLastError();
+}
+template <int LOGM, int LOGX>
+static int init_one_f() {
+    using S = SFGeo<LOGM, LOGX>;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&sum_finish_facets_kernel<LOGM, LOGX>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+}
+
 #define SF_PAIRS(X) X(7, 8) X(7, 10) X(8, 9) X(8, 10) X(9, 10) X(9, 11) X(10, 11)
 
 int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s) {
@@ -26,10 +40,18 @@ int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatc
 #undef SF_CASE
     return -1;
 }
+int launch_sum_finish_facets(int logm, int logx, const SumFinishFacetArgs& a, int nbatch, hipStream_t s) {
+#define SF_CASE_F(M, XX) \
+    if (logm == M && logx == XX) return launch_one_f<M, XX>(a, nbatch, s);
+    SF_PAIRS(SF_CASE_F)
+#undef SF_CASE_F
+    return -1;
+}
 int init_sum_finish_rows() {
     int rc = 0;
-#define SF_INIT(M, XX) \
-    if (!rc) rc = init_one<M, XX>();
+#define SF_INIT(M, XX)               \
+    if (!rc) rc = init_one<M, XX>(); \
+    if (!rc) rc = init_one_f<M, XX>();
     SF_PAIRS(SF_INIT)
 #undef SF_INIT
     return rc;

@@ -367,16 +367,97 @@ static int launch_checked(int logn, const RowsArgs<R>& a, const OffTab& tab, hip
     return 0;
 }
 
+static ColZ plain_colz() {
+    ColZ z;
+    std::memset(&z, 0, sizeof z);
+    z.nb = 1;
+    return z;
+}
+
+static int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz, int outer, int nb, hipStream_t st) {
+    int e = launch_col_pass(lg, mode, args, cz, outer, nb, st);
+    if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return 0;
+}
+
+// Strided-axis transform of length 2^logn over `W` adjacent columns and `nb` batch items with the column-tile
+// passes: one pass up to 512 points, otherwise four-step (N = n1*n2, input index y = y1*n2 + y2, output index
+// k = k1 + n1*k2) through a stream-ordered scratch [nb][N][W]:
+//   pass A (length n1 over y1, one per y2): scratch[k1*n2 + y2] = W_N^(y2 k1) * sum_y1 x[y1 n2 + y2] W_n1^(y1 k1)
+//   pass B (length n2 over y2, one per k1): X[k1 + n1 k2]       = sum_y2 scratch[k1*n2 + y2] W_n2^(y2 k2)
+// `c` carries the load / store maps, windows, conjugation flags, scale, batch strides, column gather and row
+// maps of the whole transform; in/out pitches and pointers are given separately.  Returns -1 when the length
+// is outside the column-pass range (caller falls back), else a status code.
+static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st) {
+    const bool two = logn > kColPassMaxLog;  // single pass up to 512 points (1024 threads x 32 points)
+    static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
+    const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
+    if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return -1;
+    const uint64_t n = uint64_t(1) << logn;
+    if (!two) {
+        ColPassArgs one = c;
+        one.tw = twiddles<float>(h, logn);
+        if (!one.tw) return -1;
+        return launch_col_checked(logn, 2, one, cz, 1, nb, st);
+    }
+    const int n1 = 1 << l1, n2 = 1 << l2;
+    const cx<float>* tw1 = twiddles<float>(h, l1);
+    const cx<float>* tw2 = twiddles<float>(h, l2);
+    const cx<float>* twf = twiddles<float>(h, logn);
+    if (!tw1 || !tw2 || !twf) return -1;
+    if (n * (uint64_t)W >= (uint64_t(1) << 32)) return -1;
+    // Column slabs (tuning knob SWIFTLY_SLAB_COLS, 0 = off): both passes of a slab run back to back so that the
+    // four-step intermediate of the slab is re-read while it may still sit in the 256 MiB Infinity Cache.
+    static const long long slab_env = getenv("SWIFTLY_SLAB_COLS") ? atoll(getenv("SWIFTLY_SLAB_COLS")) : 0;
+    const bool gathered = (cz.flags & kZColGather) != 0;
+    const long long slab = (slab_env >= 64 && nb == 1 && !gathered) ? (slab_env / 64) * 64 : (long long)W;
+    const long long Ws = std::min<long long>(slab, (long long)W);  // scratch row width
+    void* scratch = nullptr;
+    hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
+    if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
+    int rc = 0;
+    for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
+        const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
+        // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
+        ColPassArgs A = c;
+        A.ncols = wc;
+        A.in = c.in + c0;
+        A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)Ws; A.out_bs = (long long)(n * Ws);
+        A.out_bdiv = 0; A.out_bs_hi = 0;
+        A.ld_mul = n2;
+        A.out_i_rows = n2; A.out_o_rows = 1;
+        A.tw = tw1; A.tw_full = twf;
+        A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
+        A.col_win = nullptr; A.st_rowmap = nullptr; A.st_win = nullptr; A.st_win2 = nullptr;
+        rc = launch_col_checked(l1, 0, A, cz, n2, nb, st);
+        if (rc) break;
+        // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
+        ColPassArgs B = c;
+        ColZ zb = cz;
+        zb.flags &= ~(kZColGather | kZLoadB | kZLoadAF);  // the scratch is read plainly
+        B.ncols = wc;
+        B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)Ws; B.in_bs = (long long)(n * Ws);
+        B.in_bdiv = 0; B.in_bs_hi = 0;
+        B.in_i_rows = 1; B.in_o_rows = n2;
+        B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr;
+        B.out = c.out + c0;
+        B.st_mul = n1;
+        B.tw = tw2; B.tw_full = twf;
+        B.conj_ld = 0;
+        if (B.col_win) B.col_win += c0;
+        rc = launch_col_checked(l2, 1, B, zb, n1, nb, st);
+    }
+    he = hipFreeAsync(scratch, st);
+    if (!rc && he != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(he));
+    return rc;
+}
+
 // Lean path for complex64 transforms along the strided axis of row-major
 // arrays (columns contiguous): swiftly_colpass.h.  Returns false when the call
 // does not fit its constraints (the generic kernel handles it then).
 static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, const OffTab& tab, hipStream_t st,
                          int* rc_out) {
-    if (!a.rowfast || a.in_rs != 1 || a.out_rs != 1 || tab.use != 0 || a.rm_mod > 0 || a.in_rowmap) return false;
-    const bool two = logn > kColPassMaxLog;  // single pass up to 512 points (1024 threads x 32 points)
-    static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
-    const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
-    if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return false;
+    if (!a.rowfast || a.in_rs != 1 || a.out_rs != 1 || (tab.use & 8) || a.rm_mod > 0 || a.in_rowmap) return false;
     const uint64_t n = uint64_t(1) << logn, lim = uint64_t(1) << 32;
     const uint64_t W = (uint64_t)a.nrows;
     // all element offsets inside one batch item are 32 bit
@@ -386,6 +467,8 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     std::memset(&c, 0, sizeof c);
     c.ncols = a.nrows;
     c.full_logn = logn;
+    c.in = a.in; c.out = a.out;
+    c.in_pitch = a.in_cs; c.out_pitch = a.out_cs;
     c.in_bs = a.in_bs;
     c.out_bs = a.out_bs;
     c.ld_a = a.ld.a; c.ld_len = a.ld.len; c.ld_c = a.ld.c; c.ld_mod = a.ld.mod;
@@ -397,65 +480,25 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     c.scale = a.scale;
     c.conj_ld = a.conj_ld; c.conj_st = a.conj_st; c.accumulate = a.accumulate;
     c.ld_mul = c.st_mul = 1;
-    auto launch = [&](int lg, int mode, const ColPassArgs& args, int outer) -> int {
-        static const ColGather no_gather{};
-        int e = launch_col_pass(lg, mode, args, no_gather, outer, nb, st);
-        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-        return 0;
-    };
-    if (!two) {
-        c.in = a.in; c.out = a.out;
-        c.in_pitch = a.in_cs; c.out_pitch = a.out_cs;
-        c.tw = twiddles<float>(h, logn);
-        if (!c.tw) return false;
-        *rc_out = launch(logn, 2, c, 1);
-        return true;
+    // per-item map offsets (OffTab) -> per-subgrid tables of the column pass (batch item z = b)
+    ColZ cz = plain_colz();
+    if (tab.use) {
+        static_assert(kMaxBatch <= kColZB, "per-item tables");
+        cz.nb = nb;
+        if (tab.use & 3) {
+            cz.flags |= kZLoadB;
+            for (int b = 0; b < nb; b++) {
+                cz.b_lda[b] = (tab.use & 1) ? tab.ld_a[b] : a.ld.a;
+                cz.b_ldc[b] = (tab.use & 2) ? tab.ld_c[b] : a.ld.c;
+            }
+        }
+        if (tab.use & 4) {
+            cz.flags |= kZStoreAB;
+            for (int b = 0; b < nb; b++) cz.b_sta[b] = tab.st_a[b];
+        }
     }
-    const int n1 = 1 << l1, n2 = 1 << l2;
-    const cx<float>* tw1 = twiddles<float>(h, l1);
-    const cx<float>* tw2 = twiddles<float>(h, l2);
-    const cx<float>* twf = twiddles<float>(h, logn);
-    if (!tw1 || !tw2 || !twf) return false;
-    // Column slabs (tuning knob SWIFTLY_SLAB_COLS, 0 = off): both passes of a slab run back to back so that the
-    // four-step intermediate of the slab is re-read while it may still sit in the 256 MiB Infinity Cache.
-    static const long long slab_env = getenv("SWIFTLY_SLAB_COLS") ? atoll(getenv("SWIFTLY_SLAB_COLS")) : 0;
-    const long long slab = (slab_env >= 64 && nb == 1) ? (slab_env / 64) * 64 : (long long)W;
-    const long long Ws = std::min<long long>(slab, (long long)W);  // scratch row width
-    void* scratch = nullptr;
-    hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
-    if (he != hipSuccess) {
-        *rc_out = fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
-        return true;
-    }
-    int rc = 0;
-    for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
-        const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
-        // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
-        ColPassArgs A = c;
-        A.ncols = wc;
-        A.in = a.in + c0; A.in_pitch = a.in_cs;
-        A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)Ws; A.out_bs = (long long)(n * Ws);
-        A.ld_mul = n2;
-        A.out_i_rows = n2; A.out_o_rows = 1;
-        A.tw = tw1; A.tw_full = twf;
-        A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
-        A.col_win = nullptr;
-        rc = launch(l1, 0, A, n2);
-        if (rc) break;
-        // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
-        ColPassArgs B = c;
-        B.ncols = wc;
-        B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)Ws; B.in_bs = (long long)(n * Ws);
-        B.in_i_rows = 1; B.in_o_rows = n2;
-        B.out = a.out + c0; B.out_pitch = a.out_cs;
-        B.st_mul = n1;
-        B.tw = tw2; B.tw_full = twf;
-        B.conj_ld = 0;
-        if (B.col_win) B.col_win += c0;
-        rc = launch(l2, 1, B, n1);
-    }
-    he = hipFreeAsync(scratch, st);
-    if (!rc && he != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(he));
+    const int rc = col_transform(h, logn, c, cz, (int)W, nb, st);
+    if (rc == -1) return false;
     *rc_out = rc;
     return true;
 }
@@ -492,6 +535,14 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     if (logn == 15 && mode == 0 && !a.accumulate && !no_half) {
         const cx<float>* tw14 = twiddles<float>(h, 14);
         const cx<float>* tw13 = twiddles<float>(h, 13);
+        // default: the r2 kernel (all loads of a lane in flight, global-address-space accesses); SWIFTLY_K2_SPLIT
+        // selects the r1 multi-workgroup kernels for A/B runs
+        static const bool legacy = getenv("SWIFTLY_K2_SPLIT") != nullptr;
+        if (tw14 && !legacy) {
+            int e2 = launch_row_pass_band(r, tw14, r.tw, st);
+            *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
+            return true;
+        }
         if (tw14 && tw13) {
             int e2 = launch_row_pass_split(r, tw14, tw13, r.tw, st);
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
@@ -1026,27 +1077,232 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
     c.out_bs = out_batch_stride;
     // batch item z = f*nb + b  (f: facet / group index, b: subgrid of this chunk); item (f, b) reads facet f's
     // column buffer and adds into out + (f*nsub + b0 + b) * out_batch_stride
-    if (nfacets > kColGatherMax) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: too many facets per call");
-    const int per = (int)std::max<int64_t>(1, kColGatherMax / nfacets);
-    for (int64_t b0 = 0; b0 < nsub; b0 += per) {
-        const int nb = (int)std::min<int64_t>(per, nsub - b0);
-        ColGather cg;
-        for (int f = 0; f < nfacets; f++)
-            for (int b = 0; b < nb; b++) {
-                const int64_t s = floordiv(subgrid_off1s[b0 + b] * h->yN, h->N);
-                cg.rot[f * nb + b] = pmod(-s, m);
-                cg.base[f * nb + b] = pmod(yN / 2 - m / 2 + s, yN);
-            }
+    if (nfacets > kColZF) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: too many facets per call");
+    for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
+        const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
+        ColZ cz = plain_colz();
+        cz.flags = kZColGather;
+        cz.nb = nb;
+        for (int b = 0; b < nb; b++) {
+            const int64_t s = floordiv(subgrid_off1s[b0 + b] * h->yN, h->N);
+            cz.b_rot[b] = pmod(-s, m);
+            cz.b_base[b] = pmod(yN / 2 - m / 2 + s, yN);
+        }
         c.in = (const cx<float>*)in;
         c.in_bdiv = nb;
         c.out = (cx<float>*)out + b0 * out_batch_stride;
         c.out_bdiv = nb;
         c.out_bs_hi = nsub * out_batch_stride;
-        int e = launch_col_pass(h->log_m, 2, c, cg, 1, (int)nfacets * nb, (hipStream_t)stream);
+        if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, (int)nfacets * nb, (hipStream_t)stream)) return rc;
+    }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Contiguous-axis-first pipeline
+
+int64_t swiftly_hip_band_columns(int64_t band_len) { return 2 * ((band_len + 1) / 2); }
+
+int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
+                                   int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
+                                   int64_t band_start, int64_t band_len, int fold_other_axis_window, void* stream) {
+    if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: complex64 only");
+    CHECK_FACET_SIZE();
+    const int yN = (int)h->yN;
+    if (h->log_yN != 15) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: padded facet size %d not supported (32768)", yN);
+    if (rows < 0 || rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "bad row count");
+    if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN)
+        return fail(SWIFTLY_ERR_PARAM, "band [%lld, +%lld) is not a cyclic range of [0, %d)", (long long)band_start, (long long)band_len, yN);
+    if (fold_other_axis_window && (rows <= 0 || rows >= h->yN))
+        return fail(SWIFTLY_ERR_PARAM, "other-axis facet size %lld must be in [1, yN_size - 1]", (long long)rows);
+    if (rows == 0) return 0;
+    const int lo = yN / 2 - (int)(facet_size / 2);
+    RowPassArgs r;
+    std::memset(&r, 0, sizeof r);
+    r.in = (const cx<float>*)in; r.out = (cx<float>*)out;
+    r.in_pitch = in_row_stride; r.out_pitch = out_row_stride;
+    r.nrows = (int)rows;
+    r.ld_a = pmod(-(facet_off + lo), yN); r.ld_len = (int)facet_size; r.ld_c = 0; r.ld_mod = (int)facet_size;
+    r.ld_win = h->invp_f + lo;
+    r.st_len = yN; r.st_mod = yN;
+    r.scale = (float)(1.0 / yN);
+    r.conj_ld = r.conj_st = 1;
+    r.row_win = fold_other_axis_window ? h->invp_f + (yN / 2 - (int)(rows / 2)) : nullptr;
+    r.band_start = (int)band_start; r.band_len = (int)band_len; r.band_half = (int)((band_len + 1) / 2);
+    const cx<float>* tw14 = twiddles<float>(h, 14);
+    const cx<float>* twf = twiddles<float>(h, 15);
+    if (!tw14 || !twf) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
+    int e = launch_row_pass_band(r, tw14, twf, (hipStream_t)stream);
+    if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return 0;
+}
+
+int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+                                      int64_t in_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
+                                      int64_t band_start, int64_t band_len, int64_t subgrid_off1, void* out,
+                                      int64_t out_row_stride, int64_t out_facet_stride, const int32_t* out_rowmap,
+                                      void* stream) {
+    if (!h || !in || !out || !facet_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: complex64 only");
+    const int yN = (int)h->yN, m = (int)h->m;
+    if (h->log_yN < 0 || h->log_m < 6) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: sizes not supported");
+    if (rows <= 0 || rows >= yN) return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1]", (long long)rows);
+    if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
+    if (nfacets <= 0) return 0;
+    if ((uint64_t)yN * (uint64_t)in_row_stride >= (uint64_t(1) << 32) || (uint64_t)yN * (uint64_t)out_row_stride >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
+    const int lo = yN / 2 - (int)(rows / 2);
+    const int64_t s = floordiv(subgrid_off1 * h->yN, h->N);
+    ColPassArgs c;
+    std::memset(&c, 0, sizeof c);
+    c.ncols = m;
+    c.full_logn = h->log_yN;
+    c.in_pitch = (unsigned)in_row_stride;
+    c.out_pitch = (unsigned)out_row_stride;
+    c.ld_mul = c.st_mul = 1;
+    c.ld_a = 0; c.ld_len = (int)rows; c.ld_c = 0; c.ld_mod = (int)rows;  // window already applied by prepare_facet_band
+    c.st_a = 0; c.st_len = yN; c.st_c = 0; c.st_mod = yN;
+    c.st_rowmap = out_rowmap;
+    c.scale = (float)(1.0 / yN);
+    c.conj_ld = c.conj_st = 1;
+    c.cg_mod = m; c.cg_full = yN;
+    c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = (int)((band_len + 1) / 2);
+    c.in_bs = in_facet_stride;
+    c.out_bs = out_facet_stride;
+    for (int64_t f0 = 0; f0 < nfacets; f0 += kColZF) {
+        const int nf = (int)std::min<int64_t>(kColZF, nfacets - f0);
+        ColZ cz = plain_colz();
+        cz.flags = kZColGather | kZLoadAF;
+        cz.nb = 1;
+        cz.b_rot[0] = pmod(-s, m);
+        cz.b_base[0] = pmod(yN / 2 - m / 2 + s, yN);
+        for (int f = 0; f < nf; f++) cz.f_lda[f] = pmod(-(facet_off0s[f0 + f] + lo), yN);
+        c.in = (const cx<float>*)in + f0 * in_facet_stride;
+        c.out = (cx<float>*)out + f0 * out_facet_stride;
+        const int rc = col_transform(h, h->log_yN, c, cz, m, nf, (hipStream_t)stream);
+        if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: padded facet size %d not supported", yN);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int swiftly_hip_transform_contributions(swiftly_hip_t* h, int dtype, const void* in, int layout, int64_t in_row_stride,
+                                        int64_t in_facet_stride, int64_t in_sub_stride, const int32_t* in_rowmap,
+                                        int64_t band_start, int64_t band_len, int64_t nfacets,
+                                        const int64_t* facet_off0s, int64_t nsub, const int64_t* subgrid_offs,
+                                        void* out, int64_t out_facet_stride, int64_t out_sub_stride, void* stream) {
+    if (!h || !in || !out || !facet_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "transform_contributions: complex64 only");
+    if (layout < 0 || layout > 2) return fail(SWIFTLY_ERR_PARAM, "bad layout %d", layout);
+    if (layout != 2 && !subgrid_offs) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    const int m = (int)h->m, yN = (int)h->yN;
+    if (h->log_m < kColPassMinLog || h->log_m > kColPassMaxLog || h->log_yN < 0)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "transform_contributions: contribution size %d not supported", m);
+    if (nfacets <= 0 || nsub <= 0) return 0;
+    if ((uint64_t)yN * (uint64_t)in_row_stride + (uint64_t)yN >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
+    ColPassArgs c;
+    std::memset(&c, 0, sizeof c);
+    c.ncols = m;
+    c.full_logn = h->log_m;
+    c.in_pitch = (unsigned)in_row_stride;
+    c.out_pitch = (unsigned)m;
+    c.ld_mul = c.st_mul = 1;
+    c.ld_a = 0; c.ld_len = m; c.ld_c = 0; c.ld_mod = m;
+    c.st_a = 0; c.st_len = m; c.st_c = 0; c.st_mod = m;   // no placement: out[k] = Fn[k] * F[(k + s') mod m]
+    c.st_win = h->fn_f;
+    c.scale = 1.f;
+    c.tw = twiddles<float>(h, h->log_m);
+    if (!c.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table");
+    if (layout == 0) {  // in[f] = [m, yN] column buffers: window gather along the contiguous axis
+        c.cg_mod = m; c.cg_full = yN;
+        c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = (int)((band_len + 1) / 2);
+    } else if (layout == 1) {  // in[f] = [kept rows of yN, m]: window gather along the strided axis
+        c.ld_mod = yN;
+        c.ld_rowmap = in_rowmap;
+    }
+    for (int64_t f0 = 0; f0 < nfacets; f0 += kColZF) {
+        const int nf = (int)std::min<int64_t>(kColZF, nfacets - f0);
+        for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
+            const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
+            ColZ cz = plain_colz();
+            cz.nb = nb;
+            cz.flags = kZStoreAF;
+            for (int f = 0; f < nf; f++) cz.f_sta[f] = pmod(-floordiv(facet_off0s[f0 + f] * h->xM, h->N), m);
+            for (int b = 0; b < nb && layout != 2; b++) {
+                const int64_t s = floordiv(subgrid_offs[b0 + b] * h->yN, h->N);
+                if (layout == 0) {
+                    cz.b_rot[b] = pmod(-s, m);
+                    cz.b_base[b] = pmod(yN / 2 - m / 2 + s, yN);
+                } else {
+                    cz.b_lda[b] = pmod(-s, m);
+                    cz.b_ldc[b] = pmod(yN / 2 - m / 2 + s, yN);
+                }
+            }
+            if (layout == 0) cz.flags |= kZColGather;
+            if (layout == 1) cz.flags |= kZLoadB;
+            // item z = f*nb + b reads in + f*in_facet_stride (+ b*in_sub_stride for layout 2), writes out[f][b]
+            c.in = (const cx<float>*)in + f0 * in_facet_stride + (layout == 2 ? b0 * in_sub_stride : 0);
+            c.in_bdiv = nb; c.in_bs_hi = in_facet_stride; c.in_bs = layout == 2 ? in_sub_stride : 0;
+            c.out = (cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
+            c.out_bdiv = nb; c.out_bs_hi = out_facet_stride; c.out_bs = out_sub_stride;
+            if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, nf * nb, (hipStream_t)stream)) return rc;
+        }
+    }
+    return 0;
+}
+
+int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t nfacets, int64_t in_facet_stride,
+                                  int64_t in_sub_stride, int64_t in_row_stride, const int64_t* facet_off0s,
+                                  const int64_t* facet_off1s, void* out, int64_t out_sub_stride, int64_t out_row_stride,
+                                  const int64_t* subgrid_off1s, int64_t subgrid_size, const void* mask,
+                                  int64_t mask_batch_stride, int64_t nsub, void* stream) {
+    if (!h || !in || !out || !facet_off0s || !facet_off1s || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    CHECK_SUBGRID_SIZE();
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_facets: complex64 only");
+    if (nfacets <= 0 || nfacets > kSumFinishMaxFacets)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_facets: 1..%d facets supported", kSumFinishMaxFacets);
+    if (!sum_finish_supported(h->log_m, h->log_xM))
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_facets: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
+                    (long long)h->xM);
+    if (nsub <= 0) return 0;
+    const int xM = (int)h->xM, xA = (int)subgrid_size, m = (int)h->m;
+    SumFinishFacetArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in_fs = in_facet_stride; a.in_bs = in_sub_stride; a.in_rs = in_row_stride;
+    a.out_bs = out_sub_stride; a.out_rs = out_row_stride;
+    a.nrows = xM;
+    a.nfacets = (int)nfacets;
+    a.xA = xA;
+    for (int f = 0; f < nfacets; f++) {
+        const int sp0 = (int)floordiv(facet_off0s[f] * h->xM, h->N);
+        a.base0[f] = pmod(xM / 2 - m / 2 + sp0, xM);  // first padded-subgrid row facet f contributes to
+        a.sp1[f] = (int)floordiv(facet_off1s[f] * h->xM, h->N);
+    }
+    a.fn = h->fn_f;
+    a.mask_bs = mask ? mask_batch_stride : 0;
+    a.tw_m = twiddles<float>(h, h->log_m);
+    a.tw_x = twiddles<float>(h, h->log_xM);
+    if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
+    for (int64_t b0 = 0; b0 < nsub; b0 += kSumFinishMaxBatch) {
+        const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nsub - b0);
+        a.in = (const cx<float>*)in + b0 * in_sub_stride;
+        a.out = (cx<float>*)out + b0 * out_sub_stride;
+        a.mask = mask ? (const float*)mask + b0 * mask_batch_stride : nullptr;
+        for (int b = 0; b < nb; b++) a.st_a[b] = pmod(-(xM / 2 - xA / 2 + subgrid_off1s[b0 + b]), xM);
+        int e = launch_sum_finish_facets(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
         if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     return 0;
 }
+
+int swiftly_hip_debug_row_band_occupancy(void) { return swf::row_pass_band_occupancy(); }
 
 int swiftly_hip_debug_occupancy(int lds_bytes) { return swf::row_pass_half_occupancy(lds_bytes); }
 

@@ -49,8 +49,11 @@ struct ColPassArgs {
     long long out_bs_hi;
     int out_bdiv;
     // optional column gather on load (fuses extract_from_facet along the contiguous axis, core.py:243-253):
-    //   source column = (cg.base[z] + ((col + cg.rot[z]) mod cg_mod)) mod cg_full
+    //   source column = (cz.b_base[b] + ((col + cz.b_rot[b]) mod cg_mod)) mod cg_full
+    // and, when cg_band_len > 0, through the parity-split band layout of swiftly_rowpass.h (band_column)
     int cg_mod, cg_full;
+    int cg_band_start, cg_band_len, cg_band_half;
+    const int* ld_rowmap;  // optional (mapped load): physical input row of logical row idx (must be >= 0 for valid rows)
     int ncols;                      // columns (= rows of the primitive)
     int full_logn;                  // log2 of the full transform length the maps refer to
     // load: raw -> row = o*in_o_rows + i*in_i_rows ; mapped -> plain index i*ld_mul + o through the map
@@ -75,10 +78,19 @@ struct ColPassArgs {
     int conj_ld, conj_st, accumulate;
 };
 
-// per-batch-item column gather parameters (by value)
-constexpr int kColGatherMax = 192;
-struct ColGather {
-    int rot[kColGatherMax], base[kColGatherMax];
+// Per-batch-item parameters (by value).  Batch item z = f * nb + b  (f: facet index, b: subgrid index of the
+// wave); what varies with the SUBGRID lives in the b_* tables, what varies with the FACET in the f_* tables.
+constexpr int kColZB = 64;   // subgrids per launch
+constexpr int kColZF = 32;   // facets per launch
+enum { kZColGather = 1, kZLoadB = 2, kZLoadAF = 4, kZStoreAF = 8, kZStoreAB = 16 };
+struct ColZ {
+    int flags;
+    int nb;                            // z = f*nb + b ; nb >= 1
+    int b_rot[kColZB], b_base[kColZB];  // kZColGather: column gather (window) per subgrid
+    int b_lda[kColZB], b_ldc[kColZB];   // kZLoadB: load-map offsets (ld_a, ld_c) per subgrid (row window)
+    int b_sta[kColZB];                  // kZStoreAB: store-map offset st_a per subgrid
+    int f_lda[kColZF];                  // kZLoadAF: load-map offset ld_a per facet
+    int f_sta[kColZF];                  // kZStoreAF: store-map offset st_a per facet
 };
 
 template <int LOGN_, int LOGP_, bool SPLIT_>
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
                                                          const float* __restrict__ st_win2,
                                                          const int* __restrict__ st_rowmap,
                                                          const cx<float>* __restrict__ tw,
-                                                         const cx<float>* __restrict__ tw_full, const ColGather cg) {
+                                                         const cx<float>* __restrict__ tw_full, const ColZ cz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = G::P, T = G::T;
     static_assert(P <= 64, "one lane per row slot");
@@ -130,11 +142,25 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     const bool live = col < A.ncols;
     const int FN = 1 << A.full_logn;
     const int z = blockIdx.z;
+    const int zf = z / cz.nb, zb = z - zf * cz.nb;  // uniform
     int scol = col;
-    if (A.cg_mod > 0) {  // uniform
-        const int i = (col + cg.rot[z]) & (A.cg_mod - 1);
-        scol = (cg.base[z] + i) & (A.cg_full - 1);
+    if (cz.flags & kZColGather) {  // uniform
+        const int i = (col + cz.b_rot[zb]) & (A.cg_mod - 1);
+        scol = (cz.b_base[zb] + i) & (A.cg_full - 1);
+        if (A.cg_band_len > 0) {
+            int d = (scol - A.cg_band_start) & (A.cg_full - 1);
+            if (d >= A.cg_band_len) d = 0;  // cannot happen for a window of the plan; keeps the access in bounds
+            scol = (d & 1) * A.cg_band_half + (d >> 1);
+        }
     }
+    int ld_a = A.ld_a, ld_c = A.ld_c, st_a = A.st_a;
+    if (cz.flags & kZLoadB) {
+        ld_a = cz.b_lda[zb];
+        ld_c = cz.b_ldc[zb];
+    }
+    if (cz.flags & kZLoadAF) ld_a = cz.f_lda[zf];
+    if (cz.flags & kZStoreAF) st_a = cz.f_sta[zf];
+    if (cz.flags & kZStoreAB) st_a = cz.b_sta[zb];
     const long long in_off =
         A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs : (long long)z * A.in_bs;
     const cx<float>* __restrict__ in = gin + in_off + scol;
@@ -156,10 +182,11 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         } else {
             const int pi = i * A.ld_mul + o;
             const int ci = (pi + (FN >> 1)) & (FN - 1);
-            const int q = (ci + A.ld_a) & (FN - 1);
-            int idx = q + A.ld_c;
+            const int q = (ci + ld_a) & (FN - 1);
+            int idx = q + ld_c;
             if (idx >= A.ld_mod) idx -= A.ld_mod;
             const bool ok = q < A.ld_len;
+            if (A.ld_rowmap) idx = A.ld_rowmap[ok ? idx : 0];
             in_row = ok ? idx : -1;
             const int qs = ok ? q : 0;
             if (ld_win) in_w *= ld_win[qs];
@@ -181,7 +208,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         } else {
             const int pk = e * A.st_mul + o;
             const int ck = (pk + (FN >> 1)) & (FN - 1);
-            const int d = (ck + A.st_a) & (FN - 1);
+            const int d = (ck + st_a) & (FN - 1);
             int idx = d + A.st_c;
             if (idx >= A.st_mod) idx -= A.st_mod;
             const bool ok = d < A.st_len;
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
 constexpr int kColPassMinLog = 2;
 constexpr int kColPassMaxLog = 9;
 
-int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColGather& cg, int outer, int nbatch, hipStream_t s);
+int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s);
 int init_col_pass();
 
 }  // namespace swf

@@ -31,7 +31,22 @@ struct RowPassArgs {
     const cx<float>* tw;
     float scale;
     int conj_ld, conj_st, accumulate;
+    // -- row_pass_band_kernel only --------------------------------------------------------------------
+    // optional real factor per ROW folded into the scale (window of the OTHER axis, pre-applied: windows
+    // commute with transforms along the orthogonal axis)
+    const float* row_win;
+    // band store: only the outputs whose centred index ck lies in the cyclic range [band_start, band_start +
+    // band_len) are kept, in PARITY-SPLIT order: d = (ck - band_start) mod N lands at column
+    // (d & 1) * band_half + (d >> 1).  (The two workgroups of a row produce the even / odd outputs; with this
+    // layout each of them writes one contiguous run instead of every other element.)  band_len = 0: plain row.
+    int band_start, band_len, band_half;
 };
+
+// physical column of logical (centred) column ck in a parity-split band buffer, or -1
+__host__ __device__ inline int band_column(int ck, int n, int start, int len, int half) {
+    const int d = (ck - start) & (n - 1);
+    return d < len ? (d & 1) * half + (d >> 1) : -1;
+}
 
 template <int LOGN_, int LOGP_, bool SPLIT_, bool PAD_ = true>
 struct RGeo {
@@ -221,12 +236,12 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
     }
     if (A.in_rowmap) in_row = A.in_rowmap[in_row];
     // row base pointers are wave-uniform: pin them to SGPRs so that every access is SGPR base + 32-bit lane offset
-    const unsigned long long in_addr = (unsigned long long)(gin + (long long)in_row * A.in_pitch);
-    const unsigned long long out_addr = (unsigned long long)(gout + (long long)row * A.out_pitch);
-    const cx<float>* __restrict__ in = (const cx<float>*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(in_addr >> 32)) << 32) |
-                                                          (unsigned)__builtin_amdgcn_readfirstlane((int)in_addr));
-    cx<float>* __restrict__ out = (cx<float>*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(out_addr >> 32)) << 32) |
-                                               (unsigned)__builtin_amdgcn_readfirstlane((int)out_addr));
+    // the row indices are wave-uniform: pin them to SGPRs so that the row bases are scalar and every access is
+    // global_load/store  SGPR base + 32-bit lane offset  (the pointers keep their global address space;
+    // rebuilding them from integers would turn every access into a FLAT one)
+    in_row = __builtin_amdgcn_readfirstlane(in_row);
+    const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;
+    cx<float>* __restrict__ out = gout + (long long)__builtin_amdgcn_readfirstlane(row) * A.out_pitch;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
     // W_S^{q h} = (-i)^{(q h) mod 4 * (4/S)}: real/imag parts in {0, +-1}, uniform per workgroup
@@ -270,6 +285,100 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
     });
 }
 
+
+// Full-facet contiguous-axis transform for long rows (N = 2 * G::N = 32768 with G = RGeo<14, 5, true>):
+// K1 of the contiguous-axis-first pipeline (prepare_facet along the contiguous axis for every facet row,
+// DESIGN.md section 4) and a drop-in for the K2 column kernel.
+//
+// Same radix-2 decimation-in-frequency split as row_pass_split_kernel (half h of a row = one 16384-point
+// problem).  Two geometries: 512 threads x 32 points (66 KB LDS, <= 128 VGPRs: TWO workgroups resident per CU,
+// one's HBM phase overlaps the other's butterflies; two exchanges, radix 32, 32, 16) and 1024 threads x 16
+// points (one workgroup per CU).  Unlike the r1 kernel the load loop has no control flow and no dependent
+// table load per point, so ALL loads of a lane are in flight together (r1: "L L wait L wait" per point --
+// 59 % of wave cycles waiting): the inter-half twiddle W_N^j, j = t + T v, is W_N^t (ONE table load) times
+// the compile-time constant W_64^(v 64 T / N).
+template <class G, bool HAS_WIN, bool BAND>
+__global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
+                                                                 cx<float>* __restrict__ gout,
+                                                                 const float* __restrict__ ld_win,
+                                                                 const cx<float>* __restrict__ tw,
+                                                                 const cx<float>* __restrict__ tw_full) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int P = G::P, T = G::T, H = G::N, N = 2 * G::N;
+    static_assert(64 % (N / T) == 0, "the inter-half twiddle uses W_64 constants: j = t + T v, W_N^(T v) = W_64^(v 64 T / N)");
+    constexpr int WSTEP = 64 / (N / T);
+    const int t = threadIdx.x;
+    const int b = blockIdx.x;
+    const int h = (b >> 3) & 1;
+    const int row = ((b >> 4) << 3) + (b & 7);  // uniform; both halves of a row on the same XCD (b mod 8)
+    if (row >= A.nrows) return;
+    int in_row = row;
+    if (A.rm_mod > 0) {
+        int r1 = row + A.rm_inner;
+        if (r1 >= A.rm_mod) r1 -= A.rm_mod;
+        r1 += A.rm_outer;
+        if (r1 >= A.rm_full) r1 -= A.rm_full;
+        in_row = r1;
+    }
+    if (A.in_rowmap) in_row = A.in_rowmap[in_row];
+    const bool dead = in_row < 0;  // row not present in a compacted input: treated as zeros
+    if (dead) in_row = 0;
+    // the row indices are wave-uniform: pin them to SGPRs so that the row bases are scalar and every access is
+    // global_load/store  SGPR base + 32-bit lane offset  (the pointers keep their global address space;
+    // rebuilding them from integers would turn every access into a FLAT one)
+    in_row = __builtin_amdgcn_readfirstlane(in_row);
+    const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;
+    cx<float>* __restrict__ out = gout + (long long)__builtin_amdgcn_readfirstlane(row) * A.out_pitch;
+    const float sg_ld = A.conj_ld ? -1.f : 1.f;
+    const float sg_st = A.conj_st ? -1.f : 1.f;
+    const float sgn = h ? -1.f : 1.f;   // W_2^{q h}
+    const float alive = dead ? 0.f : 1.f;
+
+    // branch-free clamped loads; the compiler keeps as many of the 2 P loads of a lane in flight as the
+    // 128-VGPR budget (two workgroups per CU) allows
+    cx<float> x[P];
+    static_for<0, P>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        const int j = t + v * T;
+        cx<float> a[2];
+        static_for<0, 2>([&](auto qI) {
+            constexpr int q = decltype(qI)::value;
+            // plain index j + q*H -> centred index (j + q*H) ^ (N/2)
+            const int qq = ((((j + q * H) ^ (N >> 1)) + A.ld_a) & (N - 1));
+            const bool ok = qq < A.ld_len;
+            const int qs = ok ? qq : 0;
+            unsigned idx = (unsigned)(qs + A.ld_c);
+            if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
+            const cx<float> val = in[idx];
+            float w = ok ? alive : 0.f;
+            if constexpr (HAS_WIN) w *= ld_win[qs];
+            a[q] = cx<float>{val.x * w, val.y * w * sg_ld};
+        });
+        x[v] = cx<float>{a[0].x + sgn * a[1].x, a[0].y + sgn * a[1].y};
+    });
+    if (h) {  // uniform: odd outputs need W_N^j = W_N^t * W_64^v
+        const cx<float> wt = tw_full[t];
+        static_for<0, P>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v] = mul_w64<float, WSTEP * v>(cmul(x[v], wt));
+        });
+    }
+
+    float scale = A.scale;
+    if (A.row_win) scale *= A.row_win[row];
+    fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
+        const int ck = (2 * e + h) ^ (N >> 1);
+        v.x *= scale;
+        v.y *= scale * sg_st;
+        if constexpr (BAND) {
+            const int d = (ck - A.band_start) & (N - 1);
+            if (d < A.band_len) out[(d & 1) * A.band_half + (d >> 1)] = v;
+        } else {
+            out[ck] = v;
+        }
+    });
+}
+
 constexpr int kRowPassMinLog = 13;
 constexpr int kRowPassMaxLog = 15;
 int launch_row_pass(int logn, int mode, const RowPassArgs& a, hipStream_t s);
@@ -278,5 +387,8 @@ int row_pass_half_occupancy(int lds_bytes);
 // multi-workgroup form for N = 32768 (MODE 0 only); tw14 / tw13 = tables of length 16384 / 8192, tw_full of length N
 int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw13, const cx<float>* tw_full,
                           hipStream_t s);
+// 2 x 16384-point form with 512-thread workgroups (two per CU); a.band_len > 0 selects the band store
+int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s);
+int row_pass_band_occupancy();
 
 }  // namespace swf

@@ -114,6 +114,116 @@ __global__ __launch_bounds__(256) void sum_finish_rows_kernel(const SumFinishArg
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "sum over FACETS + finish": the second half of api_helper.sum_and_finish_subgrid (api_helper.py:81-112) with
+// the facet sum re-associated so that no accumulator ever lives in HBM.
+//
+// Input: G[f][b] = [m, m] per (facet, subgrid) = add_to_subgrid(axis 0) WITHOUT its placement:
+//     G[k, j] = Fn[k] * cfft_m(contribution[:, j])[(k + s'0_f) mod m]            (swiftly_hip_transform_contributions)
+// Row k of G[f][b] belongs to row  r = (k + xM/2 - m/2 + s'0_f) mod xM  of the padded subgrid.  For every padded row r
+// this kernel sums, over ALL facets f whose band covers r, the axis-1 transforms of G[f][b][k_f(r), :] placed by the
+// facet's off1 (core.py:274-285), then finishes axis 1 (inverse transform, crop, mask; core.py:316-323).  Each input
+// row is read exactly once; there is no zero-fill and no read-modify-write (r1: colacc zero-filled, re-written by one
+// launch per facet off0, re-read here).
+constexpr int kSumFinishMaxFacets = 64;
+
+struct SumFinishFacetArgs {
+    const cx<float>* in;   // G[f][b][k][m]
+    cx<float>* out;        // tmp[b][r][xA]
+    long long in_fs, in_bs, in_rs;  // element strides: facet, subgrid, row
+    long long out_bs, out_rs;
+    int nrows;             // padded rows per subgrid (xM)
+    int nfacets, xA;
+    int base0[kSumFinishMaxFacets];  // (xM/2 - m/2 + s'0_f) mod xM: first padded row of facet f's band
+    int sp1[kSumFinishMaxFacets];    // s'1_f = floor(facet_off1 * xM / N)
+    int st_a[kSumFinishMaxBatch];    // (-(xM/2 - xA//2 + off1_b)) mod xM per subgrid
+    const float* fn;       // Fn[m]
+    const float* mask;     // optional [nbatch][xA]
+    long long mask_bs;
+    const cx<float>* tw_m;
+    const cx<float>* tw_x;
+};
+
+template <int LOGM, int LOGX>
+__global__ __launch_bounds__(256) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
+    using S = SFGeo<LOGM, LOGX>;
+    using GM = typename S::GM;
+    using GX = typename S::GX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cx<float>* ex_m = reinterpret_cast<cx<float>*>(smem);
+    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + S::LDS_M);
+    constexpr int M = GM::N, X = GX::N, PM = GM::P, PX = GX::P, TR = S::TR;
+    const int t = threadIdx.x % TR, rb = threadIdx.x / TR;
+    const int b = blockIdx.y;
+    const int row0 = blockIdx.x * S::RB;
+    const int row = row0 + rb;
+    const bool live = row < A.nrows;
+
+    static_for<0, PX>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        acc[lds_pos<GX>(rb, t + v * TR, false)] = cx<float>{0.f, 0.f};
+    });
+    __syncthreads();
+
+    for (int f = 0; f < A.nfacets; f++) {
+        const int base = A.base0[f];
+        // workgroup-uniform skip: does any of this workgroup's rows lie in facet f's band?
+        bool any = false;
+        for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
+        if (!any) continue;  // uniform
+        const int k = (row - base) & (X - 1);
+        const bool on = live && k < M;
+        const cx<float>* __restrict__ in = A.in + (long long)f * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
+        const float wgt = on ? 1.f : 0.f;
+        cx<float> x[PM];
+        static_for<0, PM>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v] = in[(t + v * TR) ^ (M >> 1)];  // plain index -> centred element
+        });
+        static_for<0, PM>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            x[v].x *= wgt;
+            x[v].y *= wgt;
+        });
+        const int sp = A.sp1[f];
+        fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+            const int ck = e ^ (M >> 1);
+            const int kk = (ck - sp) & (M - 1);
+            const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);  // centred position in the padded subgrid
+            const float w = A.fn[kk];
+            cx<float>* p = acc + lds_pos<GX>(rb, dest ^ (X >> 1), false);  // stored at its plain iFFT index
+            cx<float> o = *p;
+            o.x += v.x * w;
+            o.y += v.y * w;
+            *p = o;
+        });
+        __syncthreads();  // also protects ex_m reuse by the next facet
+    }
+
+    cx<float> y[PX];
+    static_for<0, PX>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        cx<float> val = acc[lds_pos<GX>(rb, t + v * TR, false)];
+        val.y = -val.y;  // inverse transform = conj(FFT(conj(.)))
+        y[v] = val;
+    });
+    __syncthreads();
+    cx<float>* __restrict__ out = A.out + (long long)b * A.out_bs + (long long)(live ? row : 0) * A.out_rs;
+    const float* __restrict__ mask = A.mask ? A.mask + (long long)b * A.mask_bs : nullptr;
+    const int st_a = A.st_a[b];
+    const float scale = 1.f / (float)X;
+    fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
+        const int ck = e ^ (X >> 1);
+        const int d = (ck + st_a) & (X - 1);
+        if (d < A.xA && live) {
+            float w = scale;
+            if (mask) w *= mask[d];
+            out[d] = cx<float>{v.x * w, -v.y * w};
+        }
+    });
+}
+
+int launch_sum_finish_facets(int logm, int logx, const SumFinishFacetArgs& a, int nbatch, hipStream_t s);
 int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s);
 int init_sum_finish_rows();
 bool sum_finish_supported(int logm, int logx);

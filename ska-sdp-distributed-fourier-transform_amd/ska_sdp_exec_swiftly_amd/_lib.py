@@ -73,6 +73,20 @@ def _declare(lib):
     lib.swiftly_hip_sum_finish_rows.argtypes = [vp, c_int, vp, i64, i64, i64, i64, pi64, vp, i64, i64, pi64, i64, vp, i64, i64, vp]
     lib.swiftly_hip_add_to_subgrid_from_columns.restype = c_int
     lib.swiftly_hip_add_to_subgrid_from_columns.argtypes = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, pi64, vp]
+    lib.swiftly_hip_band_columns.restype = i64
+    lib.swiftly_hip_band_columns.argtypes = [i64]
+    lib.swiftly_hip_prepare_facet_band.restype = c_int
+    lib.swiftly_hip_prepare_facet_band.argtypes = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, c_int, vp]
+    lib.swiftly_hip_prepare_facet_columns.restype = c_int
+    lib.swiftly_hip_prepare_facet_columns.argtypes = [vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, i64, vp, vp]
+    lib.swiftly_hip_transform_contributions.restype = c_int
+    lib.swiftly_hip_transform_contributions.argtypes = [
+        vp, c_int, vp, c_int, i64, i64, i64, vp, i64, i64, i64, pi64, i64, pi64, vp, i64, i64, vp,
+    ]
+    lib.swiftly_hip_sum_finish_facets.restype = c_int
+    lib.swiftly_hip_sum_finish_facets.argtypes = [
+        vp, c_int, vp, i64, i64, i64, i64, pi64, pi64, vp, i64, i64, pi64, i64, vp, i64, i64, vp,
+    ]
     lib.swiftly_hip_malloc.restype = c_int
     lib.swiftly_hip_malloc.argtypes = [POINTER(vp), c_size_t]
     lib.swiftly_hip_free.restype = c_int

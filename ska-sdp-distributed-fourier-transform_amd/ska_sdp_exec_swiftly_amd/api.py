@@ -293,16 +293,20 @@ def _torch():
     return torch
 
 
-def preferred_wave_axis(swiftly_config, dtype=None):  # pylint: disable=unused-argument
-    """Which subgrid offset the forward engine groups "waves" by for row-major
-    facets: 0 = ``off0`` (the reference's column cache key, api.py:300-324),
-    1 = ``off1`` (full-facet transform along the contiguous axis first; the
-    axis order is free, the transforms are separable)."""
-    return 0
+def preferred_wave_axis(swiftly_config, dtype=None):
+    """Which subgrid offset the forward engine should group "waves" by for
+    row-major facets: 0 = ``off0`` (the reference's column cache key,
+    api.py:300-324; full-facet transform along the strided axis 0 first),
+    1 = ``off1`` (full-facet transform along the CONTIGUOUS axis first: one
+    kernel instead of a four-step with a facet-sized scratch; the axis order is
+    free because the transforms are separable).  1 when the kernels of that
+    pipeline exist for the configuration's sizes and dtype."""
+    return 1 if swiftly_config.core.supports_band_pipeline(dtype) else 0
 
 
 K1_DESCRIPTION = {
     0: "K1 prepare_facet(axis=0) per facet = col_pass<n1=128, mapped load> + col_pass<n2=256, mapped store>",
+    1: "K1 prepare_facet(axis=1) of all facet rows, band-compacted parity-split store = row_pass_band_kernel (2 workgroups per row)",
 }
 
 
@@ -376,11 +380,16 @@ class SwiftlyForward:
             raise ValueError("wave_axis must be 0 or 1")
         self.task_queue = TaskQueue(queue_size)
         # optional plan (extension): when the caller knows up front which subgrids it will ask for (sparse
-        # covers, scripts/demo_sparse_facet.py style), BF_F only keeps the rows those columns read
+        # covers, scripts/demo_sparse_facet.py style), the facet-sized intermediate only keeps what those read
         self._rowmap, self._n_rows = None, None
+        self._plan = None
         if subgrid_configs is not None:
-            self._rowmap, self._n_rows = self.core.subgrid_column_rows([sg.off0 for sg in subgrid_configs])
-            self._planned_off0 = {int(sg.off0) for sg in subgrid_configs}
+            self._plan = list(subgrid_configs)
+            if self.wave_axis == 0:
+                self._rowmap, self._n_rows = self.core.subgrid_column_rows([sg.off0 for sg in subgrid_configs])
+            self._planned_keys = {int(self._key(sg)) for sg in subgrid_configs}
+        self._band = None
+        self._wave_rowmaps = {}
         self.facet_configs = [cfg for cfg, _ in facet_tasks]
         self.queue_size = queue_size
         self._client = client
@@ -413,6 +422,8 @@ class SwiftlyForward:
     def prepare_all_facets(self, timer=None):
         """Stage 1 for every facet (idempotent).  ``timer`` (optional, bench.py's
         StageTimer) brackets each facet's launch group with HIP events."""
+        if self.wave_axis == 1:
+            return self._prepare_all_bands(timer)
         if self.BF_Fs_persist is None:
             self._prewindowed = self.dtype == _torch().complex64
             out = []
@@ -438,7 +449,7 @@ class SwiftlyForward:
             raise ValueError("get_NMBF_BFs_off0 only accepts the BF_Fs this object prepared itself")
         cols = self.lru.get(off0)
         if cols is None:
-            if self._rowmap is not None and int(off0) not in self._planned_off0:
+            if self._plan is not None and int(off0) not in self._planned_keys:
                 raise ValueError(f"subgrid column off0={off0} was not in the subgrid_configs plan")
             torch = _torch()
             core = self.core
@@ -486,11 +497,14 @@ class SwiftlyForward:
         the wave key and size).  ``timer`` brackets the stages with HIP events."""
         self.prepare_all_facets()
         t0 = timer.start() if timer is not None else None
-        self.get_NMBF_BFs_off0(sgs[0].off0)
+        if self.wave_axis == 1:
+            self._get_wave_columns(sgs[0].off1)
+        else:
+            self.get_NMBF_BFs_off0(sgs[0].off0)
         if timer is not None:
             timer.stop("K2_wave_facet_transform", t0)
             t0 = timer.start()
-        res = self._wave(sgs)
+        res = self._wave_b(sgs) if self.wave_axis == 1 else self._wave(sgs)
         if timer is not None:
             timer.stop("K345_extract_sum_finish", t0)
         return res
@@ -514,12 +528,101 @@ class SwiftlyForward:
 
     def _wave(self, sgs):
         # single-GPU route: the [m, m] contributions are never materialised -- the window gather is
-        # folded into the axis-0 accumulation kernel reading the column buffers directly
+        # folded into the axis-0 transform kernel reading the column buffers directly
+        cols = self.get_NMBF_BFs_off0(sgs[0].off0)
         try:
-            colacc = _colacc_from_columns(self.core, self.get_NMBF_BFs_off0(sgs[0].off0), self.facet_configs, sgs)
+            return _finish_from_columns(self.core, cols, 0, self.facet_configs, sgs, [sg.off1 for sg in sgs])
+        except NotImplementedError:
+            pass
+        try:
+            colacc = _colacc_from_columns(self.core, cols, self.facet_configs, sgs)
         except NotImplementedError:
             return sum_and_finish_wave(self.core, self.wave_contributions(sgs), self.facet_configs, sgs)
         return _finish_from_colacc(self.core, colacc, self.facet_configs, sgs)
+
+    # -- contiguous-axis-first pipeline (wave_axis == 1) ---------------------------
+    def _check_band_pipeline(self):
+        torch = _torch()
+        if not self.core.supports_band_pipeline(self.dtype):
+            raise ValueError("wave_axis=1 is not available for this configuration / dtype (see preferred_wave_axis)")
+        sizes = {tuple(t.shape) for t in self._facets}
+        if len(sizes) != 1 or any(t.stride(1) != 1 for t in self._facets) or self.dtype != torch.complex64:
+            raise ValueError("wave_axis=1 needs equally sized row-major complex64 facets")
+
+    def _prepare_all_bands(self, timer=None):
+        """K1: band buffers ``[F, yB, band columns]`` -- prepare_facet along axis 1 of every facet row, only the
+        columns some planned subgrid window reads, axis-0 window pre-applied."""
+        if self.BF_Fs_persist is None:
+            self._check_band_pipeline()
+            torch = _torch()
+            core = self.core
+            self._band = (
+                core.band_for_offsets([sg.off1 for sg in self._plan]) if self._plan is not None else (0, core.yN_size)
+            )
+            F, yB = len(self._facets), self._facets[0].shape[0]
+            bands = torch.empty((F, yB, core.band_columns(self._band)), dtype=self.dtype, device=core.device)
+            for j, (cfg, data) in enumerate(zip(self.facet_configs, self._facets)):
+                t0 = timer.start() if timer is not None else None
+                core.prepare_facet_band(data, cfg.off1, self._band, out=bands[j])
+                if timer is not None:
+                    timer.stop("K1_full_facet_transform", t0)
+            self.BF_Fs_persist = bands
+        return self.BF_Fs_persist
+
+    def _wave_rows(self, off1):
+        """(rowmap, n_rows) of the axis-0 rows the planned subgrids of wave ``off1`` read (None = all rows)."""
+        if self._plan is None:
+            return None, self.core.yN_size
+        key = int(off1)
+        if key not in self._wave_rowmaps:
+            off0s = [sg.off0 for sg in self._plan if int(sg.off1) == key]
+            self._wave_rowmaps[key] = self.core.subgrid_column_rows(off0s)
+        return self._wave_rowmaps[key]
+
+    def _get_wave_columns(self, off1):
+        """K2: ``Q[F, rows, m]`` for the subgrid wave ``off1`` (LRU cached like the reference's per-off0 columns)."""
+        hit = self.lru.get(("b", off1))
+        if hit is None:
+            if self._plan is not None and int(off1) not in self._planned_keys:
+                raise ValueError(f"subgrid wave off1={off1} was not in the subgrid_configs plan")
+            bands = self.prepare_all_facets()
+            rowmap, n_rows = self._wave_rows(off1)
+            Q = self.core.prepare_facet_columns(
+                bands, [cfg.off0 for cfg in self.facet_configs], self._band, off1, rowmap, n_rows
+            )
+            hit = (Q, rowmap)
+            self.lru.set(("b", off1), hit)
+        return hit
+
+    def _wave_b(self, sgs):
+        Q, rowmap = self._get_wave_columns(sgs[0].off1)
+        if self._plan is not None:
+            allowed = {(int(sg.off0), int(sg.off1)) for sg in self._plan}
+            if any((int(sg.off0), int(sg.off1)) not in allowed for sg in sgs):
+                raise ValueError("subgrid was not in the subgrid_configs plan")
+        return _finish_from_columns(self.core, Q, 1, self.facet_configs, sgs, [sg.off0 for sg in sgs], rowmap=rowmap)
+
+
+def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, rowmap=None, band=None):
+    """K3..K5 without any HBM accumulator: per-(facet, subgrid) axis-0 transforms gathered straight from the
+    wave's facet buffers (``src``), facet sum + axis-1 finish on chip, axis-0 finish."""
+    torch = _torch()
+    xM, xA, S = core.xM_size, sgs[0].size, len(sgs)
+    dt, dev = src.dtype, core.device
+    if dt != torch.complex64:
+        raise NotImplementedError("fused subgrid path is complex64 only")
+    off0s = [cfg.off0 for cfg in facet_configs]
+    off1s = [cfg.off1 for cfg in facet_configs]
+    G = core.transform_contributions(src, layout, off0s, window_offs, rowmap=rowmap, band=band)
+    mask1 = _mask_table(core, sgs, "mask1", xA, dt)
+    mask0 = _mask_table(core, sgs, "mask0", xA, dt)
+    tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
+    core.sum_finish_facets(G, off0s, off1s, tmp, [sg.off1 for sg in sgs], xA, mask=mask1)
+    res = torch.empty((S, xA, xA), dtype=dt, device=dev)
+    core.launch("finish_subgrid", tmp, xA, 1, xA, res, 1, xA, 0, size=xA, mask=mask0,
+                nbatch=S, in_bs=xM * xA, out_bs=xA * xA, offs=[sg.off0 for sg in sgs],
+                mask_bs=xA if mask0 is not None else 0)
+    return res
 
 
 def _facet_grid(facet_configs):

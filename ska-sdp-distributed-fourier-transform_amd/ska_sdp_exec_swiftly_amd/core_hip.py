@@ -396,6 +396,131 @@ class SwiftlyCoreHip:
         )
         return out
 
+    # ------------------------------------------------------------------ contiguous-axis-first pipeline
+    def supports_band_pipeline(self, dtype=None):
+        """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
+        torch = _torch()
+        if dtype is not None and dtype != torch.complex64:
+            return False
+        logs = {}
+        for name, n in (("yN", self.yN_size), ("xM", self.xM_size), ("m", self.xM_yN_size)):
+            if n <= 0 or n & (n - 1):
+                return False
+            logs[name] = n.bit_length() - 1
+        pairs = {(7, 8), (7, 10), (8, 9), (8, 10), (9, 10), (9, 11), (10, 11)}  # sum_finish instances
+        return logs["yN"] == 15 and 6 <= logs["m"] <= 9 and (logs["m"], logs["xM"]) in pairs
+
+    def band_for_offsets(self, subgrid_offs):
+        """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains
+        the ``xM_yN_size`` window of every given subgrid offset (core.py:243-253); ``(0, yN_size)`` = all."""
+        yN, m = self.yN_size, self.xM_yN_size
+        keep = numpy.zeros(yN, dtype=bool)
+        for off in set(int(o) for o in subgrid_offs):
+            s = off * yN // self.N
+            keep[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN] = True
+        if keep.all() or not keep.any():
+            return 0, yN
+        # largest run of unused indices on the ring; the band is its complement
+        idx = numpy.flatnonzero(keep)
+        gaps = numpy.diff(numpy.concatenate([idx, [idx[0] + yN]]))
+        g = int(numpy.argmax(gaps))
+        start = int(idx[(g + 1) % idx.size])
+        length = int(yN - (gaps[g] - 1))
+        return start, length
+
+    def band_columns(self, band):
+        """physical columns of a band buffer"""
+        return int(self._lib.swiftly_hip_band_columns(int(band[1])))
+
+    def prepare_facet_band(self, facet, facet_off, band, out=None, fold_other_axis_window=True):
+        """K1 (contiguous axis first): ``prepare_facet(facet, facet_off, axis=1)`` for every row of a row-major
+        device facet, keeping only the band of output columns (parity-split layout, see include/swiftly_hip.h),
+        times the 1/PSWF window of axis 0 when ``fold_other_axis_window``."""
+        torch = _torch()
+        if facet.dim() != 2 or facet.stride(1) != 1:
+            raise ValueError("prepare_facet_band needs a row-major 2-D device tensor")
+        ncols = self.band_columns(band)
+        if out is None:
+            out = torch.empty((facet.shape[0], ncols), dtype=facet.dtype, device=self._device)
+        elif tuple(out.shape) != (facet.shape[0], ncols) or out.stride(1) != 1:
+            raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(facet.shape[0], ncols)}!")
+        _lib.check(
+            self._lib.swiftly_hip_prepare_facet_band(
+                self._handle, self._code(facet), ctypes.c_void_p(facet.data_ptr()), int(facet.shape[0]),
+                int(facet.shape[1]), facet.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(0), int(facet_off),
+                int(band[0]), int(band[1]), int(bool(fold_other_axis_window)), self._stream(),
+            )
+        )
+        return out
+
+    def prepare_facet_columns(self, bands, facet_off0s, band, subgrid_off1, rowmap=None, n_rows=None, out=None):
+        """K2 (contiguous axis first): for every facet ``f``, gather the window of subgrid offset
+        ``subgrid_off1`` from the band buffer ``bands[f]`` (``[F, yB, band columns]``) and run
+        ``prepare_facet(., facet_off0s[f], axis=0)`` without its (pre-applied) window on it; keeps the rows
+        ``rowmap`` selects -> ``[F, n_rows, xM_yN_size]``."""
+        torch = _torch()
+        F, yB = bands.shape[0], bands.shape[1]
+        m = self.xM_yN_size
+        n_rows = self.yN_size if rowmap is None else int(n_rows)
+        if out is None:
+            out = torch.empty((F, n_rows, m), dtype=bands.dtype, device=self._device)
+        offs = (ctypes.c_int64 * F)(*[int(o) for o in facet_off0s])
+        _lib.check(
+            self._lib.swiftly_hip_prepare_facet_columns(
+                self._handle, self._code(bands), ctypes.c_void_p(bands.data_ptr()), int(yB), bands.stride(1),
+                bands.stride(0), F, offs, int(band[0]), int(band[1]), int(subgrid_off1),
+                ctypes.c_void_p(out.data_ptr()), out.stride(1), out.stride(0),
+                ctypes.c_void_p(rowmap.data_ptr()) if rowmap is not None else None, self._stream(),
+            )
+        )
+        return out
+
+    def transform_contributions(self, src, layout, facet_off0s, subgrid_offs, out=None, rowmap=None, band=None, nsub=None):
+        """K3 + K4a: ``out[f, b] = Fn * cfft_m(contribution_{f,b}, axis 0)`` rotated by the facet's ``off0``
+        (add_to_subgrid along axis 0 without the placement) with the contribution gathered on load from
+        ``src`` -- layout 0: ``[F, m, yN|band]`` column buffers, windows by subgrid ``off1``; layout 1:
+        ``[F, rows, m]`` (prepare_facet_columns), windows by subgrid ``off0`` through ``rowmap``; layout 2:
+        ``[F, S, m, m]`` materialised contributions."""
+        torch = _torch()
+        F = src.shape[0]
+        m = self.xM_yN_size
+        S = int(nsub) if layout == 2 else len(subgrid_offs)
+        if out is None:
+            out = torch.empty((F, S, m, m), dtype=src.dtype, device=self._device)
+        foffs = (ctypes.c_int64 * F)(*[int(o) for o in facet_off0s])
+        soffs = (ctypes.c_int64 * S)(*[int(o) for o in subgrid_offs]) if layout != 2 else None
+        if layout == 2:
+            row_stride, facet_stride, sub_stride = src.stride(2), src.stride(0), src.stride(1)
+        else:
+            row_stride, facet_stride, sub_stride = src.stride(1), src.stride(0), 0
+        band = band or (0, 0)
+        _lib.check(
+            self._lib.swiftly_hip_transform_contributions(
+                self._handle, self._code(src), ctypes.c_void_p(src.data_ptr()), int(layout), row_stride, facet_stride,
+                sub_stride, ctypes.c_void_p(rowmap.data_ptr()) if rowmap is not None else None, int(band[0]),
+                int(band[1]), F, foffs, S, soffs, ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1),
+                self._stream(),
+            )
+        )
+        return out
+
+    def sum_finish_facets(self, G, facet_off0s, facet_off1s, out, subgrid_off1s, subgrid_size, mask=None):
+        """K4b + K5a: sum over facets + axis-1 finish of ``G[F, S, m, m]`` (transform_contributions) ->
+        ``out[S, xM, subgrid_size]`` (see include/swiftly_hip.h)."""
+        F, S = G.shape[0], G.shape[1]
+        f0 = (ctypes.c_int64 * F)(*[int(o) for o in facet_off0s])
+        f1 = (ctypes.c_int64 * F)(*[int(o) for o in facet_off1s])
+        so = (ctypes.c_int64 * S)(*[int(o) for o in subgrid_off1s])
+        _lib.check(
+            self._lib.swiftly_hip_sum_finish_facets(
+                self._handle, self._code(G), ctypes.c_void_p(G.data_ptr()), F, G.stride(0), G.stride(1), G.stride(2),
+                f0, f1, ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1), so, int(subgrid_size),
+                ctypes.c_void_p(mask.data_ptr()) if mask is not None else None,
+                mask.stride(0) if mask is not None else 0, S, self._stream(),
+            )
+        )
+        return out
+
     # ------------------------------------------------------------------ facet -> subgrid
     def prepare_facet(self, facet, facet_off, axis, out=None):
         """Window with 1/PSWF, zero-pad to ``yN_size``, shift by ``facet_off``

@@ -1,0 +1,238 @@
+"""
+GPU parity of the kernels of the contiguous-axis-first forward pipeline
+(include/swiftly_hip.h: prepare_facet_band, prepare_facet_columns,
+transform_contributions, sum_finish_facets) against the oracle, primitive by
+primitive, plus the whole pipeline against the oracle replica of the reference
+dataflow.  complex64; tolerances: relative RMSE 2e-6 for a single transform of
+un-amplified data, 2e-5 end to end.
+"""
+import numpy
+import pytest
+
+import bench
+from oracle import separable as sep
+from oracle import swiftly_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+W64, N64, xM64, yN64, yB64 = 10.875, 65536, 1024, 32768, 22528
+
+
+def relrms(a, b):
+    return float(numpy.sqrt(numpy.mean(numpy.abs(a - b) ** 2) / numpy.mean(numpy.abs(b) ** 2)))
+
+
+def band_cols(yN, band):
+    """physical column of every logical (centred) column, -1 outside the band (parity-split layout)"""
+    start, length = band
+    half = (length + 1) // 2
+    d = (numpy.arange(yN) - start) % yN
+    return numpy.where(d < length, (d & 1) * half + (d >> 1), -1)
+
+
+_core64 = {}
+
+
+def core64():
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    if "c" not in _core64:
+        _core64["c"] = SwiftlyCoreHip(W64, N64, xM64, yN64)
+        _core64["o"] = orc.OracleCore(W64, N64, xM64, yN64)
+    return _core64["c"], _core64["o"]
+
+
+@pytest.mark.parametrize("band", [(0, yN64), (10736, 11472), (32001, 2049)])
+def test_prepare_facet_band(band):
+    import torch
+
+    core, ref = core64()
+    assert core.supports_band_pipeline(torch.complex64)
+    rng = numpy.random.default_rng(21)
+    rows = 7
+    x = (rng.standard_normal((rows, yB64)) + 1j * rng.standard_normal((rows, yB64))).astype(numpy.complex64)
+    xt = torch.from_numpy(x).cuda()
+    pc = band_cols(yN64, band)
+    for off, fold in ((0, False), (64 * 352, True), (-64 * 320, True)):
+        got = core.prepare_facet_band(xt, off, band, fold_other_axis_window=fold).cpu().numpy()
+        want = ref.prepare_facet(x.astype(complex), off, 1)
+        if fold:
+            want = want * ref.facet_window(rows)[:, None]
+        assert got.shape == (rows, core.band_columns(band))
+        keep = pc >= 0
+        rel = relrms(got[:, pc[keep]], want[:, keep])
+        assert rel < 2e-6, (band, off, rel)
+
+
+def test_band_for_offsets_and_supports():
+    core, _ = core64()
+    offs = [i * 928 for i in list(range(0, 13)) + list(range(59, 71))]
+    start, length = core.band_for_offsets(offs)
+    m, yN = core.xM_yN_size, core.yN_size
+    cover = numpy.zeros(yN, dtype=bool)
+    cover[(start + numpy.arange(length)) % yN] = True
+    for off in offs:
+        s = off * yN // core.N
+        assert cover[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN].all()
+    assert length < yN // 2
+    assert core.band_for_offsets([i * 928 for i in range(71)]) == (0, yN)
+
+
+@pytest.mark.parametrize("band,use_rowmap", [((0, yN64), False), ((10736, 11472), True)])
+def test_prepare_facet_columns(band, use_rowmap):
+    """K2: window gather from band buffers + strided-axis prepare_facet (no window) for 2 facets at once."""
+    import torch
+
+    core, ref = core64()
+    m, yN = core.xM_yN_size, core.yN_size
+    rng = numpy.random.default_rng(22)
+    yB0 = 176  # facet size along axis 0 (any size < yN works for the primitive)
+    F = 2
+    ncols = core.band_columns(band)
+    pc = band_cols(yN, band)
+    logical = (rng.standard_normal((F, yB0, yN)) + 1j * rng.standard_normal((F, yB0, yN))).astype(numpy.complex64)
+    packed = numpy.zeros((F, yB0, ncols), dtype=numpy.complex64)
+    packed[:, :, pc[pc >= 0]] = logical[:, :, pc >= 0]
+    bands = torch.from_numpy(packed).cuda()
+    off0s = [0, 22528]
+    sub_off0s = [0, 3 * 928, -5 * 928]
+    rowmap, n_rows = core.subgrid_column_rows(sub_off0s) if use_rowmap else (None, yN)
+    rm = rowmap.cpu().numpy() if rowmap is not None else numpy.arange(yN)
+    for off1 in (7 * 928, -11 * 928):
+        got = core.prepare_facet_columns(bands, off0s, band, off1, rowmap, n_rows).cpu().numpy()
+        assert got.shape == (F, n_rows, m)
+        for f in range(F):
+            win = ref.extract_from_facet(logical[f].astype(complex), off1, axis=1)  # [yB0, m]
+            want = ref.prepare_facet(win / ref.facet_window(yB0)[:, None], off0s[f], axis=0)  # window NOT applied
+            keep = rm >= 0
+            rel = relrms(got[f][rm[keep]], want[keep])
+            assert rel < 2e-6, (off1, f, rel)
+
+
+P11 = dict(W=11.0, N=1024, yB=352, yN=512, xA=192, xM=256)  # m = 128: sum_finish instance (7, 8)
+
+
+def _p11():
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    return (
+        SwiftlyCoreHip(P11["W"], P11["N"], P11["xM"], P11["yN"]),
+        orc.OracleCore(P11["W"], P11["N"], P11["xM"], P11["yN"]),
+    )
+
+
+def _G_want(ref, C, off0):
+    """Fn * cfft_m(C, axis 0) rotated by the facet offset, without placement: rows of add_to_subgrid(axis 0)."""
+    m, xM = ref.xM_yN_size, ref.xM_size
+    placed = ref.add_to_subgrid(C, off0, axis=0)
+    sp = off0 * xM // ref.N
+    return placed[(numpy.arange(m) + xM // 2 - m // 2 + sp) % xM]
+
+
+def test_transform_contributions_all_layouts():
+    import torch
+
+    core, ref = _p11()
+    m, yN, N = core.xM_yN_size, P11["yN"], P11["N"]
+    rng = numpy.random.default_rng(23)
+    fstep, sstep = core.facet_off_step, core.subgrid_off_step
+    foffs = [0, 88 * fstep, -40 * fstep]
+    soffs = [0, 96 * sstep, -17 * sstep, N // 2 + 10 * sstep]
+    F, S = len(foffs), len(soffs)
+    # layout 0: column buffers [F, m, yN], windows along the contiguous axis
+    cols = (rng.standard_normal((F, m, yN)) + 1j * rng.standard_normal((F, m, yN))).astype(numpy.complex64)
+    G = core.transform_contributions(torch.from_numpy(cols).cuda(), 0, foffs, soffs).cpu().numpy()
+    assert G.shape == (F, S, m, m)
+    for f in range(F):
+        for b in range(S):
+            C = ref.extract_from_facet(cols[f].astype(complex), soffs[b], axis=1)
+            assert relrms(G[f, b], _G_want(ref, C, foffs[f])) < 2e-6
+    # layout 1: [F, rows, m] with a row map, windows along the strided axis
+    rowmap, n_rows = core.subgrid_column_rows(soffs)
+    rm = rowmap.cpu().numpy()
+    full = (rng.standard_normal((F, yN, m)) + 1j * rng.standard_normal((F, yN, m))).astype(numpy.complex64)
+    compact = numpy.zeros((F, n_rows, m), dtype=numpy.complex64)
+    compact[:, rm[rm >= 0]] = full[:, rm >= 0]
+    G1 = core.transform_contributions(torch.from_numpy(compact).cuda(), 1, foffs, soffs, rowmap=rowmap).cpu().numpy()
+    G1b = core.transform_contributions(torch.from_numpy(full).cuda(), 1, foffs, soffs).cpu().numpy()
+    for f in range(F):
+        for b in range(S):
+            C = ref.extract_from_facet(full[f].astype(complex), soffs[b], axis=0)
+            want = _G_want(ref, C, foffs[f])
+            assert relrms(G1[f, b], want) < 2e-6
+            assert relrms(G1b[f, b], want) < 2e-6
+    # layout 2: materialised contributions [F, S, m, m]
+    contrib = (rng.standard_normal((F, S, m, m)) + 1j * rng.standard_normal((F, S, m, m))).astype(numpy.complex64)
+    G2 = core.transform_contributions(torch.from_numpy(contrib).cuda(), 2, foffs, None, nsub=S).cpu().numpy()
+    for f in range(F):
+        for b in range(S):
+            assert relrms(G2[f, b], _G_want(ref, contrib[f, b].astype(complex), foffs[f])) < 2e-6
+
+
+def test_sum_finish_facets():
+    import torch
+
+    core, ref = _p11()
+    m, xM, xA, N = core.xM_yN_size, P11["xM"], P11["xA"], P11["N"]
+    rng = numpy.random.default_rng(24)
+    fstep, sstep = core.facet_off_step, core.subgrid_off_step
+    f_offs = [(0, 0), (0, 88 * fstep), (88 * fstep, 0), (88 * fstep, 88 * fstep), (-44 * fstep, 20 * fstep)]
+    s_off1 = [0, 96 * sstep, -33 * sstep]
+    F, S = len(f_offs), len(s_off1)
+    contrib = (rng.standard_normal((F, S, m, m)) + 1j * rng.standard_normal((F, S, m, m))).astype(numpy.complex64)
+    G = core.transform_contributions(torch.from_numpy(contrib).cuda(), 2, [o[0] for o in f_offs], None, nsub=S)
+    mask = (rng.random((S, xA)) > 0.2).astype(numpy.float32)
+    out = torch.empty((S, xM, xA), dtype=torch.complex64, device="cuda")
+    core.sum_finish_facets(G, [o[0] for o in f_offs], [o[1] for o in f_offs], out, s_off1, xA,
+                           mask=torch.from_numpy(mask).cuda())
+    got = out.cpu().numpy()
+    for b in range(S):
+        acc = numpy.zeros((xM, xM), dtype=complex)
+        for f, (o0, o1) in enumerate(f_offs):
+            acc += ref.add_to_subgrid(ref.add_to_subgrid(contrib[f, b].astype(complex), o0, 0), o1, 1)
+        want = numpy.array([ref.finish_subgrid(acc[r], s_off1[b], xA) for r in range(xM)]) * mask[b][None, :]
+        rel = relrms(got[b], want)
+        assert rel < 3e-6, (b, rel)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_forward_pipelines_match_oracle_small_rows(axis):
+    """Both forward pipelines through SwiftlyForward at yN = 32768 with SMALL facets (yB = 352 so that the
+    2-D oracle is cheap): 4 facets, planned sparse subgrid set, complex64."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+
+    yB, xA = 352, 928
+    P = dict(W=W64, fov=1.0, N=N64, yB_size=yB, yN_size=yN64, xA_size=xA, xM_size=xM64)
+    cfg = sw.SwiftlyConfig(backend="hip", **P)
+    if axis == 1 and sw.api.preferred_wave_axis(cfg, torch.complex64) != 1:
+        pytest.skip("band pipeline not available")
+    ref = core64()[1]
+    fstep = cfg.facet_off_step
+    rng = numpy.random.default_rng(25)
+    facet_cfgs = [
+        sw.FacetConfig(o0, o1, yB, (rng.random(yB) > 0.1).astype(float), None)
+        for o0, o1 in ((0, 0), (0, 5 * fstep * 10), (-7 * fstep * 10, 0), (-7 * fstep * 10, 5 * fstep * 10))
+    ]
+    # separable dense facets (oracle/separable.py): the exact result per subgrid costs O(0.5 s) on the CPU
+    vectors = [sep.facet_vectors(500 + j, yB, rank=2) for j in range(len(facet_cfgs))]
+    facets = [bench.separable_facet(torch, vectors[j], c) for j, c in enumerate(facet_cfgs)]
+    sg_cfgs = [
+        sw.SubgridConfig(i0 * xA, i1 * xA, xA, None, (rng.random(xA) > 0.1).astype(float))
+        for i0, i1 in ((0, 0), (0, 3), (2, 0), (2, 3), (69, 3), (69, 70), (2, 70))
+    ]
+    key = (lambda c: c.off1) if axis == 1 else (lambda c: c.off0)
+    order = sorted(range(len(sg_cfgs)), key=lambda i: (key(sg_cfgs[i]), i))
+    ordered = [sg_cfgs[i] for i in order]
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=axis, lru_forward=2)
+    got = [t.cpu().numpy() for t in fwd.get_subgrid_tasks(ordered)]
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    so = sep.SeparableOracle(ref, items, vectors)
+    for g, c in zip(got, ordered):
+        w = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1))
+        rel = relrms(g, w)
+        assert rel < 2e-5, (axis, c.off0, c.off1, rel)
+    # unplanned subgrid is refused
+    with pytest.raises(ValueError):
+        fwd.get_subgrid_task(sw.SubgridConfig(5 * xA, 5 * xA, xA))
