@@ -16,8 +16,12 @@ template <int LOGN, int MODE>
 static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     using G = typename CGeoFor<LOGN>::type;
     dim3 grid((unsigned)((a.ncols + 63) / 64), (unsigned)outer, (unsigned)nbatch);
-    hipLaunchKernelGGL((col_pass_kernel<G, MODE>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
-                       a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
+    if (MODE == 2 || a.scratch_nt)
+        hipLaunchKernelGGL((col_pass_kernel<G, MODE, true>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
+                           a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
+    else
+        hipLaunchKernelGGL((col_pass_kernel<G, (MODE == 2 ? 0 : MODE), false>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in,
+                           a.out, a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
     return (int)hipGetLastError();
 }
 template <int LOGN>
@@ -30,8 +34,12 @@ template <int LOGN, int MODE>
 static int init_mode() {
     using G = typename CGeoFor<LOGN>::type;
     if (G::LDS_BYTES == 0) return 0;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if (!rc && MODE != 2)
+        rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, (MODE == 2 ? 0 : MODE), false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    return rc;
 }
 template <int LOGN>
 static int init_one() {

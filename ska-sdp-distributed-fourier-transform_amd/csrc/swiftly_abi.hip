@@ -416,10 +416,12 @@ static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const C
     hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
     if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
     int rc = 0;
+    static const int scratch_nt = getenv("SWIFTLY_SCRATCH_NT") ? atoi(getenv("SWIFTLY_SCRATCH_NT")) : 1;  // tuning knob
     for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
         const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
         // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
         ColPassArgs A = c;
+        A.scratch_nt = scratch_nt;
         A.ncols = wc;
         A.in = c.in + c0;
         A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)Ws; A.out_bs = (long long)(n * Ws);
@@ -433,6 +435,7 @@ static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const C
         if (rc) break;
         // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
         ColPassArgs B = c;
+        B.scratch_nt = scratch_nt;
         ColZ zb = cz;
         zb.flags &= ~(kZColGather | kZLoadB | kZLoadAF);  // the scratch is read plainly
         B.ncols = wc;
@@ -538,7 +541,7 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
         // default: the r2 kernel (all loads of a lane in flight, global-address-space accesses); SWIFTLY_K2_SPLIT
         // selects the r1 multi-workgroup kernels for A/B runs
         static const bool legacy = getenv("SWIFTLY_K2_SPLIT") != nullptr;
-        if (tw14 && !legacy) {
+        if (tw14 && !legacy && r.ld_c == 0 && r.ld_mod == r.ld_len) {  // load map of a prepare_* primitive
             int e2 = launch_row_pass_band(r, tw14, r.tw, st);
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
             return true;
@@ -1173,8 +1176,12 @@ int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* i
     c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = (int)((band_len + 1) / 2);
     c.in_bs = in_facet_stride;
     c.out_bs = out_facet_stride;
-    for (int64_t f0 = 0; f0 < nfacets; f0 += kColZF) {
-        const int nf = (int)std::min<int64_t>(kColZF, nfacets - f0);
+    // tuning knob: facets per launch group (both passes of a group run back to back; small groups keep the
+    // four-step intermediate of a group within reach of the Infinity Cache)
+    static const int per_env = getenv("SWIFTLY_K2_FACETS") ? atoi(getenv("SWIFTLY_K2_FACETS")) : kColZF;
+    const int per = std::max(1, std::min(per_env, (int)kColZF));
+    for (int64_t f0 = 0; f0 < nfacets; f0 += per) {
+        const int nf = (int)std::min<int64_t>(per, nfacets - f0);
         ColZ cz = plain_colz();
         cz.flags = kZColGather | kZLoadAF;
         cz.nb = 1;

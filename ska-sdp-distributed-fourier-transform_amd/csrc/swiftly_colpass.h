@@ -20,21 +20,23 @@ namespace swf {
 #ifndef SWF_NT
 #define SWF_NT 1
 #endif
+template <bool NT>
 __device__ __forceinline__ cx<float> cp_load(const cx<float>* p) {
-#if SWF_NT
-    const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
-    return {v.x, v.y};
-#else
-    return *p;
-#endif
+    if constexpr (NT) {
+        const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+        return {v.x, v.y};
+    } else {
+        return *p;
+    }
 }
+template <bool NT>
 __device__ __forceinline__ void cp_store(cx<float>* p, cx<float> v) {
-#if SWF_NT
-    const f32x2 w = {v.x, v.y};
-    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
-#else
-    *p = v;
-#endif
+    if constexpr (NT) {
+        const f32x2 w = {v.x, v.y};
+        __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
+    } else {
+        *p = v;
+    }
 }
 
 struct ColPassArgs {
@@ -76,6 +78,9 @@ struct ColPassArgs {
     int tw_on_store;
     float scale;
     int conj_ld, conj_st, accumulate;
+    // accesses to the four-step scratch (pass A stores, pass B loads) non-temporal (1, default) or cacheable (0:
+    // lets the intermediate live in the 256 MiB Infinity Cache when both passes of a slab run back to back)
+    int scratch_nt;
 };
 
 // Per-batch-item parameters (by value).  Batch item z = f * nb + b  (f: facet index, b: subgrid index of the
@@ -118,7 +123,7 @@ struct CGeo {
 // coalesced vector load per table instead of P dependent scalar loads), and
 // the main loops fetch the values with v_readlane.  The output-side
 // bookkeeping is issued before the butterflies so its latency hides under them.
-template <class G, int MODE>
+template <class G, int MODE, bool SNT>
 __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassArgs A, const cx<float>* __restrict__ gin,
                                                          cx<float>* __restrict__ gout,
                                                          const float* __restrict__ ld_win,
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     constexpr int P = G::P, T = G::T;
     static_assert(P <= 64, "one lane per row slot");
     constexpr bool RAW_LD = MODE == 1, RAW_ST = MODE == 0;
+    constexpr bool NT_LD = RAW_LD ? SNT : (SWF_NT != 0), NT_ST = RAW_ST ? SNT : (SWF_NT != 0);
     // last Stockham phase: radix 2^LR at stride 2^LNS  (phases are LOGP, LOGP, ..., remainder)
     constexpr int LR = G::LOGN <= G::LOGP ? G::LOGN : (G::LOGN % G::LOGP == 0 ? G::LOGP : G::LOGN % G::LOGP);
     constexpr int LNS = G::LOGN - LR;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         const int row = __builtin_amdgcn_readlane(in_row, v);
         cx<float> val = {0.f, 0.f};
         if (row >= 0) {  // uniform
-            if (live) val = cp_load(in + (unsigned)row * A.in_pitch);
+            if (live) val = cp_load<NT_LD>(in + (unsigned)row * A.in_pitch);
         }
         x[v] = val;
     });
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             w.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_tw.y), s));
             v = cmul(v, w);
             v.y *= sg_st;
-            if (live) cp_store(out + (unsigned)row * A.out_pitch, v);
+            if (live) cp_store<NT_ST>(out + (unsigned)row * A.out_pitch, v);
         } else {
             const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_w), s)) * col_w;
             v.x *= w;
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
                     v.y += old.y;
                 }
             }
-            if (live) cp_store(p, v);
+            if (live) cp_store<NT_ST>(p, v);
         }
     });
 }

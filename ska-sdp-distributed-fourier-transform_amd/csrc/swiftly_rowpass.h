@@ -324,37 +324,39 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     const bool dead = in_row < 0;  // row not present in a compacted input: treated as zeros
     if (dead) in_row = 0;
     // the row indices are wave-uniform: pin them to SGPRs so that the row bases are scalar and every access is
-    // global_load/store  SGPR base + 32-bit lane offset  (the pointers keep their global address space;
-    // rebuilding them from integers would turn every access into a FLAT one)
+    // global_load/store  SGPR base + 32-bit BYTE offset in one VGPR  (the pointers keep their global address
+    // space; rebuilding them from integers would turn every access into a FLAT one, and 64-bit per-lane
+    // addresses cost two VGPRs and a v_lshl_add_u64 per access)
     in_row = __builtin_amdgcn_readfirstlane(in_row);
-    const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;
-    cx<float>* __restrict__ out = gout + (long long)__builtin_amdgcn_readfirstlane(row) * A.out_pitch;
+    const char* __restrict__ inb = reinterpret_cast<const char*>(gin + (long long)in_row * A.in_pitch);
+    char* __restrict__ outb = reinterpret_cast<char*>(gout + (long long)__builtin_amdgcn_readfirstlane(row) * A.out_pitch);
+    const char* __restrict__ winb = reinterpret_cast<const char*>(ld_win);
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
     const float sgn = h ? -1.f : 1.f;   // W_2^{q h}
-    const float alive = dead ? 0.f : 1.f;
 
-    // branch-free clamped loads; the compiler keeps as many of the 2 P loads of a lane in flight as the
-    // 128-VGPR budget (two workgroups per CU) allows
+    // Load map of a prepare_* primitive (ld_c = 0, ld_mod = ld_len; host-checked): element q = (ci + ld_a) mod N
+    // of the zero-padded row is in[q] for q < ld_len.  Branch-free clamped loads; the compiler keeps as many of
+    // the 2 P loads of a lane in flight as the 128-VGPR budget (two workgroups per CU) allows.
+    const int base = (t + A.ld_a + (N >> 1)) & (N - 1);  // q of plain index j = t (centred index j ^ N/2 = j + N/2 mod N)
     cx<float> x[P];
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
-        const int j = t + v * T;
         cx<float> a[2];
         static_for<0, 2>([&](auto qI) {
             constexpr int q = decltype(qI)::value;
-            // plain index j + q*H -> centred index (j + q*H) ^ (N/2)
-            const int qq = ((((j + q * H) ^ (N >> 1)) + A.ld_a) & (N - 1));
+            const int qq = (base + v * T + q * H) & (N - 1);
             const bool ok = qq < A.ld_len;
-            const int qs = ok ? qq : 0;
-            unsigned idx = (unsigned)(qs + A.ld_c);
-            if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
-            const cx<float> val = in[idx];
-            float w = ok ? alive : 0.f;
-            if constexpr (HAS_WIN) w *= ld_win[qs];
-            a[q] = cx<float>{val.x * w, val.y * w * sg_ld};
+            const unsigned qs = ok ? (unsigned)qq : 0u;
+            const f32x2 val = *reinterpret_cast<const f32x2*>(inb + (qs << 3));
+            float w = ok ? 1.f : 0.f;
+            if constexpr (HAS_WIN) {
+                const float wv = *reinterpret_cast<const float*>(winb + (qs << 2));
+                w = ok ? wv : 0.f;
+            }
+            a[q] = cx<float>{val.x * w, val.y * w};
         });
-        x[v] = cx<float>{a[0].x + sgn * a[1].x, a[0].y + sgn * a[1].y};
+        x[v] = cx<float>{a[0].x + sgn * a[1].x, (a[0].y + sgn * a[1].y) * sg_ld};
     });
     if (h) {  // uniform: odd outputs need W_N^j = W_N^t * W_64^v
         const cx<float> wt = tw_full[t];
@@ -364,17 +366,20 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         });
     }
 
-    float scale = A.scale;
+    float scale = dead ? 0.f : A.scale;
     if (A.row_win) scale *= A.row_win[row];
+    const float scale_im = scale * sg_st;
+    // band store: d = (ck - band_start) mod N has the parity of h ^ band_start for the whole workgroup, so the
+    // destination (d & 1) * band_half + (d >> 1) is  region base + (d >> 1)
+    const unsigned region = BAND ? (unsigned)(((h ^ A.band_start) & 1) * A.band_half) << 3 : 0u;
     fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
         const int ck = (2 * e + h) ^ (N >> 1);
-        v.x *= scale;
-        v.y *= scale * sg_st;
+        const f32x2 val = {v.x * scale, v.y * scale_im};
         if constexpr (BAND) {
             const int d = (ck - A.band_start) & (N - 1);
-            if (d < A.band_len) out[(d & 1) * A.band_half + (d >> 1)] = v;
+            if (d < A.band_len) *reinterpret_cast<f32x2*>(outb + region + ((unsigned)(d >> 1) << 3)) = val;
         } else {
-            out[ck] = v;
+            *reinterpret_cast<f32x2*>(outb + ((unsigned)ck << 3)) = val;
         }
     });
 }

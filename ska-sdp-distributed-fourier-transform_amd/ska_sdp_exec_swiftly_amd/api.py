@@ -711,6 +711,8 @@ class SwiftlyBackward:
     :param lru_backward: number of subgrid columns (distinct ``off0``) whose
         partial sums ``NAF_MNAF [m, yN]`` per facet stay in HBM before they are
         folded into the facet accumulators
+    :param queue_size: bound on unfinished subgrid tasks (reference
+        ``TaskQueue``, api.py:466-522)
     """
 
     # pylint: disable=too-many-arguments,too-many-instance-attributes
@@ -719,6 +721,7 @@ class SwiftlyBackward:
         self.core = swiftly_config.core
         self.facets_config_list = facets_config_list
         self.queue_size = queue_size
+        self.task_queue = TaskQueue(queue_size)
         self._client = client
         self.lru = LRUCache(lru_backward)
         self.MNAF_BMNAFs_persist = [None for _ in facets_config_list]
@@ -728,34 +731,95 @@ class SwiftlyBackward:
 
     def add_new_subgrid_task(self, subgrid_config, new_subgrid_task):
         """Fold one subgrid into the facet sums (reference api.py:347-372)."""
+        return self.add_new_subgrid_tasks([subgrid_config], [new_subgrid_task])
+
+    def add_new_subgrid_tasks(self, subgrid_configs, new_subgrid_tasks):
+        """Fold a list of subgrids into the facet sums (extension: consecutive
+        subgrids sharing ``off0`` and ``size`` are processed as one wave with
+        batched launches; a single subgrid is a wave of one)."""
+        col = None
+        i = 0
+        while i < len(subgrid_configs):
+            j = i + 1
+            while (
+                j < len(subgrid_configs)
+                and subgrid_configs[j].off0 == subgrid_configs[i].off0
+                and subgrid_configs[j].size == subgrid_configs[i].size
+            ):
+                j += 1
+            col = self._add_wave(subgrid_configs[i:j], new_subgrid_tasks[i:j])
+            i = j
+        return col
+
+    def wave_contributions(self, sgs, subgrids):
+        """``prepare_and_split_subgrid`` (reference api_helper.py:115-139) for a
+        wave: contributions ``[F, S, m, m]`` of the subgrids ``sgs`` (same size)
+        to every facet -- what the reference ships from the subgrid's worker to
+        the facets' workers (api.py:357-364)."""
         torch = _torch()
         core = self.core
-        m, xM, yN = core.xM_yN_size, core.xM_size, core.yN_size
-        F = len(self.facets_config_list)
-        sub, _ = core._as_device(new_subgrid_task)  # pylint: disable=protected-access
-        if self.dtype is None:
-            self.dtype = sub.dtype
-        elif sub.dtype != self.dtype:
-            sub = sub.to(self.dtype)
+        m, xM = core.xM_yN_size, core.xM_size
+        F, S, D = len(self.facets_config_list), len(sgs), len(self._off0s)
+        xA = sgs[0].size
+        subs = []
+        for data in subgrids:
+            ten, _ = core._as_device(data)  # pylint: disable=protected-access
+            if self.dtype is None:
+                self.dtype = ten.dtype
+            elif ten.dtype != self.dtype:
+                ten = ten.to(self.dtype)
+            if tuple(ten.shape) != (xA, xA):
+                raise ValueError(f"subgrid has shape {tuple(ten.shape)}, expected {(xA, xA)}")
+            subs.append(ten)
         dev, dt = core.device, self.dtype
-        off0, off1 = subgrid_config.off0, subgrid_config.off1
-        # prepare_and_split_subgrid (api_helper.py:115-139)
-        prepared = core.prepare_subgrid(sub, [off0, off1])
-        D = len(self._off0s)
-        e0 = torch.empty((D, m, xM), dtype=dt, device=dev)
-        core.launch("extract_from_subgrid", prepared, xM, 1, xM, e0, 1, xM,
-                    nbatch=D, in_bs=0, out_bs=m * xM, offs=self._off0s)
-        parts = torch.empty((F, m, m), dtype=dt, device=dev)
+        sub = subs[0].unsqueeze(0) if S == 1 else torch.stack(subs)
+        sub = sub.contiguous()
+        # prepare_subgrid (core.py:328-368): axis 1 on the xA rows, then axis 0 on all xM columns
+        tmp = torch.empty((S, xA, xM), dtype=dt, device=dev)
+        core.launch("prepare_subgrid", sub, xA, xA, 1, tmp, xM, 1, 0, size=xA,
+                    nbatch=S, in_bs=xA * xA, out_bs=xA * xM, offs=[sg.off1 for sg in sgs])
+        prepared = torch.empty((S, xM, xM), dtype=dt, device=dev)
+        core.launch("prepare_subgrid", tmp, xM, 1, xM, prepared, 1, xM, 0, size=xA,
+                    nbatch=S, in_bs=xA * xM, out_bs=xM * xM, offs=[sg.off0 for sg in sgs])
+        # extract_from_subgrid along axis 0 once per distinct facet off0 (api_helper.py:125-131) ...
+        e0 = torch.empty((D, S, m, xM), dtype=dt, device=dev)
+        for d, off0_f in enumerate(self._off0s):
+            core.launch("extract_from_subgrid", prepared, xM, 1, xM, e0[d], 1, xM, off0_f,
+                        nbatch=S, in_bs=xM * xM, out_bs=m * xM)
+        # ... and along axis 1 per facet (api_helper.py:133-138)
+        parts = torch.empty((F, S, m, m), dtype=dt, device=dev)
         for j, cfg in enumerate(self.facets_config_list):
-            core.launch("extract_from_subgrid", e0[self._off0_of[j]], m, xM, 1, parts[j], m, 1, cfg.off1)
-        # accumulate_column (api_helper.py:142-152), column cache keyed by off0 (api.py:402-438)
+            core.launch("extract_from_subgrid", e0[self._off0_of[j]], m, xM, 1, parts[j], m, 1, cfg.off1,
+                        nbatch=S, in_bs=m * xM, out_bs=m * m)
+        return parts
+
+    def accumulate_wave(self, sgs, parts):
+        """``accumulate_column`` (reference api_helper.py:142-152) for a wave:
+        add the contributions ``parts[F, S, m, m]`` of subgrids sharing ``off0``
+        into that column's partial sums (LRU cache keyed by ``off0``, reference
+        api.py:402-438); evicted columns go to the facet accumulators."""
+        torch = _torch()
+        core = self.core
+        m, yN = core.xM_yN_size, core.yN_size
+        F = len(self.facets_config_list)
+        off0 = sgs[0].off0
         col = self.lru.get(off0)
         if col is None:
-            col = torch.zeros((F, m, yN), dtype=dt, device=dev)
-        core.launch("add_to_facet", parts, m, m, 1, col, yN, 1, off1, nbatch=F, in_bs=m * m, out_bs=m * yN)
+            col = torch.zeros((F, m, yN), dtype=parts.dtype, device=core.device)
+        # one launch per subgrid (batched over facets): launches are ordered on the stream, so subgrids whose
+        # windows overlap never update the same element concurrently
+        for b, sg in enumerate(sgs):
+            core.launch("add_to_facet", parts[:, b], m, m, 1, col, yN, 1, sg.off1,
+                        nbatch=F, in_bs=parts.stride(0), out_bs=m * yN)
         old_off0, old_col = self.lru.set(off0, col)
         if old_off0 is not None and old_col is not None:
             self.update_MNAF_BMNAFs(old_off0, old_col)
+        return col
+
+    def _add_wave(self, sgs, subgrids):
+        parts = self.wave_contributions(sgs, subgrids)
+        col = self.accumulate_wave(sgs, parts)
+        self.task_queue.process([col])
         return col
 
     def update_MNAF_BMNAFs(self, off0, NAF_MNAFs):
@@ -763,8 +827,8 @@ class SwiftlyBackward:
         api_helper.py:155-179): finish axis 1 (+mask1), add along axis 0."""
         torch = _torch()
         core = self.core
-        m, yN = core.xM_yN_size, core.yN_size
-        dev, dt = core.device, self.dtype
+        yN = core.yN_size
+        dev, dt = core.device, NAF_MNAFs.dtype
         for j, cfg in enumerate(self.facets_config_list):
             yB = cfg.size
             t = core.finish_facet(NAF_MNAFs[j], cfg.off1, yB, axis=1, mask=cfg.mask1)
@@ -789,4 +853,5 @@ class SwiftlyBackward:
                 out.append(torch.zeros((cfg.size, cfg.size), dtype=dt, device=core.device))
             else:
                 out.append(core.finish_facet(acc, cfg.off0, cfg.size, axis=0, mask=cfg.mask0))
+        self.task_queue.wait_all_done()
         return out
