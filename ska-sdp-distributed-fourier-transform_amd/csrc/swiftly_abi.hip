@@ -416,7 +416,12 @@ static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const C
     hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
     if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
     int rc = 0;
-    static const int scratch_nt = getenv("SWIFTLY_SCRATCH_NT") ? atoi(getenv("SWIFTLY_SCRATCH_NT")) : 1;  // tuning knob
+    // scratch accesses: a small intermediate is left cacheable so that pass B finds it in the 256 MiB Infinity
+    // Cache (measured: the 160 MB of a K5b wave, K3-5 12.5 -> 11.6 ms per pass); a large one is streamed
+    // non-temporally (measured: K2, 1.2 GB per wave, 18.5 ms vs 19.6 ms cacheable).  SWIFTLY_SCRATCH_NT forces.
+    static const int scratch_nt_env = getenv("SWIFTLY_SCRATCH_NT") ? atoi(getenv("SWIFTLY_SCRATCH_NT")) : -1;
+    const size_t scratch_bytes = (size_t)nb * n * (size_t)Ws * sizeof(cx<float>);
+    const int scratch_nt = scratch_nt_env >= 0 ? scratch_nt_env : (scratch_bytes > (size_t(192) << 20) ? 1 : 0);
     for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
         const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
         // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
