@@ -193,10 +193,43 @@ constexpr int lds_delta(int d, bool rowfast) {
 // butterfly inputs x[U + r*NB], r = 1..RAD-1.  Powers of two come from the
 // table (tw[k] = exp(-2 pi i k / N)), the rest from at most log2(RAD)-1
 // complex products, which keeps the error at a few ulp.
+// Two-factor form (default): r = Q*hi + lo with Q = 2^ceil(LOGR/2); w^lo (lo < Q) and w^(Q hi) come straight
+// from the table (exactly rounded), every other w^r is ONE product of two table values -- at most one extra
+// rounding per twiddle (the r1 form chained up to log2(RAD)-1 products: ~2x the twiddle error and, in its
+// register-lean variant, 49 products per radix-32 group instead of 21).
+#ifndef SWF_TW_TWO_FACTOR
+#define SWF_TW_TWO_FACTOR 1
+#endif
 template <typename R, int LOGR, int NB, int U, int PTOT, int N>
 __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx) {
     constexpr int RAD = 1 << LOGR;
-    if constexpr (LOGR >= 5) {
+    if constexpr (SWF_TW_TWO_FACTOR && LOGR >= 2) {
+        constexpr int LQ = (LOGR + 1) / 2, Q = 1 << LQ, NH = RAD / Q;
+        cx<R> wlo[Q];
+        static_for<1, Q>([&](auto lI) {
+            constexpr int lo = decltype(lI)::value;
+            wlo[lo] = tw[(kidx * lo) & (N - 1)];
+        });
+        static_for<0, NH>([&](auto hI) {
+            constexpr int hi = decltype(hI)::value;
+            cx<R> wh = {(R)1, (R)0};
+            if constexpr (hi > 0) wh = tw[(kidx * (Q * hi)) & (N - 1)];
+            static_for<0, Q>([&](auto lI) {
+                constexpr int lo = decltype(lI)::value;
+                constexpr int r = Q * hi + lo;
+                if constexpr (r > 0) {
+                    cx<R> w;
+                    if constexpr (hi == 0)
+                        w = wlo[lo];
+                    else if constexpr (lo == 0)
+                        w = wh;
+                    else
+                        w = cmul(wh, wlo[lo]);
+                    x[U + r * NB] = cmul(x[U + r * NB], w);
+                }
+            });
+        });
+    } else if constexpr (LOGR >= 5) {
         // register-lean form: keep only the LOGR table values alive and build
         // each w^r from the set bits of r
         cx<R> wp[LOGR];

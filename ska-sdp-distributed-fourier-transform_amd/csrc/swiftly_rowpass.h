@@ -13,6 +13,8 @@
 
 namespace swf {
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 struct RowPassArgs {
     const cx<float>* in;
     cx<float>* out;
@@ -336,25 +338,30 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     const float sgn = h ? -1.f : 1.f;   // W_2^{q h}
 
     // Load map of a prepare_* primitive (ld_c = 0, ld_mod = ld_len; host-checked): element q = (ci + ld_a) mod N
-    // of the zero-padded row is in[q] for q < ld_len.  Branch-free clamped loads; the compiler keeps as many of
-    // the 2 P loads of a lane in flight as the 128-VGPR budget (two workgroups per CU) allows.
-    const int base = (t + A.ld_a + (N >> 1)) & (N - 1);  // q of plain index j = t (centred index j ^ N/2 = j + N/2 mod N)
+    // of the zero-padded row is in[q] for q < ld_len.  The loads are BUFFER loads whose descriptors cover exactly
+    // the valid elements: the hardware range check returns 0 for the padding (no compare / select / clamp per
+    // element, no memory access for the padding), and a row that is absent from a compacted input gets an empty
+    // descriptor.  No control flow: the compiler keeps as many of the 2 P loads of a lane in flight as the
+    // 128-VGPR budget (two workgroups per CU) allows.
+    const unsigned valid = dead ? 0u : (unsigned)A.ld_len;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
+    // byte offset of plain index j = t (centred index j ^ N/2 = j + N/2 mod N), then + (v T + q H) * 8 mod 8 N
+    const unsigned base8 = (unsigned)((t + A.ld_a + (N >> 1)) & (N - 1)) << 3;
     cx<float> x[P];
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         cx<float> a[2];
         static_for<0, 2>([&](auto qI) {
             constexpr int q = decltype(qI)::value;
-            const int qq = (base + v * T + q * H) & (N - 1);
-            const bool ok = qq < A.ld_len;
-            const unsigned qs = ok ? (unsigned)qq : 0u;
-            const f32x2 val = *reinterpret_cast<const f32x2*>(inb + (qs << 3));
-            float w = ok ? 1.f : 0.f;
+            const unsigned off8 = (base8 + (unsigned)((v * T + q * H) << 3)) & (unsigned)((N << 3) - 1);
+            const f32x2 val = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)off8, 0, 0));
             if constexpr (HAS_WIN) {
-                const float wv = *reinterpret_cast<const float*>(winb + (qs << 2));
-                w = ok ? wv : 0.f;
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, (int)(off8 >> 1), 0, 0));
+                a[q] = cx<float>{val.x * w, val.y * w};
+            } else {
+                a[q] = cx<float>{val.x, val.y};
             }
-            a[q] = cx<float>{val.x * w, val.y * w};
         });
         x[v] = cx<float>{a[0].x + sgn * a[1].x, (a[0].y + sgn * a[1].y) * sg_ld};
     });
@@ -366,21 +373,27 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         });
     }
 
-    float scale = dead ? 0.f : A.scale;
+    float scale = A.scale;
     if (A.row_win) scale *= A.row_win[row];
     const float scale_im = scale * sg_st;
     // band store: d = (ck - band_start) mod N has the parity of h ^ band_start for the whole workgroup, so the
     // destination (d & 1) * band_half + (d >> 1) is  region base + (d >> 1)
     const unsigned region = BAND ? (unsigned)(((h ^ A.band_start) & 1) * A.band_half) << 3 : 0u;
+    // buffer stores: an offset outside the descriptor is dropped by the hardware, so outputs outside the band need
+    // no branch -- their offset is simply pushed out of range
+    const unsigned out_bytes = (unsigned)(BAND ? 2 * A.band_half : N) << 3;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb, (short)0, (int)out_bytes, 0x00020000);
     fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
         const int ck = (2 * e + h) ^ (N >> 1);
         const f32x2 val = {v.x * scale, v.y * scale_im};
+        unsigned off;
         if constexpr (BAND) {
             const int d = (ck - A.band_start) & (N - 1);
-            if (d < A.band_len) *reinterpret_cast<f32x2*>(outb + region + ((unsigned)(d >> 1) << 3)) = val;
+            off = d < A.band_len ? region + ((unsigned)(d >> 1) << 3) : 0xfffffff8u;
         } else {
-            *reinterpret_cast<f32x2*>(outb + ((unsigned)ck << 3)) = val;
+            off = (unsigned)ck << 3;
         }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)off, 0, 0);
     });
 }
 

@@ -47,6 +47,7 @@ __all__ = [
     "make_full_cover_config",
     "make_mask_from_slice",
     "sum_and_finish_wave",
+    "finish_from_blocks",
 ]
 
 log = logging.getLogger("fourier-logger")
@@ -526,6 +527,41 @@ class SwiftlyForward:
                         nbatch=S, in_bs=0, out_bs=m * m, offs=off1s)
         return contrib
 
+    def supports_fused_subgrid_side(self):
+        """transform_contributions / sum_finish_facets available for this configuration and dtype"""
+        return self.core.supports_fused_subgrid(self.dtype)
+
+    def _wave_source(self, sgs):
+        """(source tensor, layout, window offsets, row map) of the wave for transform_contributions"""
+        if self.wave_axis == 1:
+            Q, rowmap = self._get_wave_columns(sgs[0].off1)
+            return Q, 1, [sg.off0 for sg in sgs], rowmap
+        return self.get_NMBF_BFs_off0(sgs[0].off0), 0, [sg.off1 for sg in sgs], None
+
+    def wave_blocks(self, sgs, out=None, transformed=True):
+        """Per-(facet, subgrid) ``[m, m]`` blocks of THIS object's facets for the subgrids ``sgs`` of one wave,
+        ``[F, S, m, m]`` written into ``out`` (e.g. a slice of an all-to-all send buffer).  ``transformed``:
+        the axis-0-transformed blocks ``G`` of transform_contributions (what the fused subgrid side consumes)
+        instead of the raw contributions (reference api.py:263-277)."""
+        torch = _torch()
+        core = self.core
+        m = core.xM_yN_size
+        F, S = len(self.facet_configs), len(sgs)
+        if out is None:
+            out = torch.empty((F, S, m, m), dtype=self.dtype, device=core.device)
+        if transformed:
+            src, layout, offs, rowmap = self._wave_source(sgs)
+            core.transform_contributions(src, layout, [cfg.off0 for cfg in self.facet_configs], offs, out=out, rowmap=rowmap)
+            return out
+        if self.wave_axis != 0:
+            raise NotImplementedError("raw contributions are only produced by the wave_axis=0 pipeline")
+        cols = self.get_NMBF_BFs_off0(sgs[0].off0)
+        off1s = [sg.off1 for sg in sgs]
+        for j in range(F):
+            core.launch("extract_from_facet", cols[j], m, core.yN_size, 1, out[j], m, 1,
+                        nbatch=S, in_bs=0, out_bs=out.stride(1), offs=off1s)
+        return out
+
     def _wave(self, sgs):
         # single-GPU route: the [m, m] contributions are never materialised -- the window gather is
         # folded into the axis-0 transform kernel reading the column buffers directly
@@ -614,6 +650,16 @@ def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, row
     off0s = [cfg.off0 for cfg in facet_configs]
     off1s = [cfg.off1 for cfg in facet_configs]
     G = core.transform_contributions(src, layout, off0s, window_offs, rowmap=rowmap, band=band)
+    return _finish_from_G(core, G, facet_configs, sgs)
+
+
+def _finish_from_G(core, G, facet_configs, sgs):
+    """facet sum + axis-1 finish on chip (sum_finish_facets), then the axis-0 finish, for ``G[F, S, m, m]``."""
+    torch = _torch()
+    xM, xA, S = core.xM_size, sgs[0].size, len(sgs)
+    dt, dev = G.dtype, core.device
+    off0s = [cfg.off0 for cfg in facet_configs]
+    off1s = [cfg.off1 for cfg in facet_configs]
     mask1 = _mask_table(core, sgs, "mask1", xA, dt)
     mask0 = _mask_table(core, sgs, "mask0", xA, dt)
     tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
@@ -623,6 +669,15 @@ def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, row
                 nbatch=S, in_bs=xM * xA, out_bs=xA * xA, offs=[sg.off0 for sg in sgs],
                 mask_bs=xA if mask0 is not None else 0)
     return res
+
+
+def finish_from_blocks(core, blocks, facet_configs, sgs, transformed=True):
+    """Finished, masked subgrids ``[S, xA, xA]`` from the per-(facet, subgrid) blocks ``[F, S, m, m]`` of ALL
+    facets (``facet_configs`` in the blocks' facet order): the receiving side of the multi-GPU exchange.
+    ``transformed`` as in :py:meth:`SwiftlyForward.wave_blocks`."""
+    if transformed:
+        return _finish_from_G(core, blocks, facet_configs, sgs)
+    return sum_and_finish_wave(core, blocks, facet_configs, sgs)
 
 
 def _facet_grid(facet_configs):
@@ -811,6 +866,29 @@ class SwiftlyBackward:
         for b, sg in enumerate(sgs):
             core.launch("add_to_facet", parts[:, b], m, m, 1, col, yN, 1, sg.off1,
                         nbatch=F, in_bs=parts.stride(0), out_bs=m * yN)
+        old_off0, old_col = self.lru.set(off0, col)
+        if old_off0 is not None and old_col is not None:
+            self.update_MNAF_BMNAFs(old_off0, old_col)
+        return col
+
+    def accumulate_chunks(self, off0, chunks):
+        """:py:meth:`accumulate_wave` for contributions that arrive in several pieces (one per source rank of
+        the multi-GPU exchange): ``chunks = [(subgrid configs, parts[F, S_c, m, m]), ...]``, all of column ``off0``."""
+        torch = _torch()
+        core = self.core
+        m, yN = core.xM_yN_size, core.yN_size
+        F = len(self.facets_config_list)
+        col = self.lru.get(off0)
+        for sgs, parts in chunks:
+            if self.dtype is None:
+                self.dtype = parts.dtype
+            if col is None:
+                col = torch.zeros((F, m, yN), dtype=parts.dtype, device=core.device)
+            for b, sg in enumerate(sgs):
+                core.launch("add_to_facet", parts[:, b], m, m, 1, col, yN, 1, sg.off1,
+                            nbatch=F, in_bs=parts.stride(0), out_bs=m * yN)
+        if col is None:
+            return None
         old_off0, old_col = self.lru.set(off0, col)
         if old_off0 is not None and old_col is not None:
             self.update_MNAF_BMNAFs(old_off0, old_col)

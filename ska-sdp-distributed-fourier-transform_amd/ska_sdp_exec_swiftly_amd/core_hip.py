@@ -397,18 +397,26 @@ class SwiftlyCoreHip:
         return out
 
     # ------------------------------------------------------------------ contiguous-axis-first pipeline
-    def supports_band_pipeline(self, dtype=None):
-        """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
-        torch = _torch()
-        if dtype is not None and dtype != torch.complex64:
-            return False
+    def _logs(self):
         logs = {}
         for name, n in (("yN", self.yN_size), ("xM", self.xM_size), ("m", self.xM_yN_size)):
             if n <= 0 or n & (n - 1):
-                return False
+                return None
             logs[name] = n.bit_length() - 1
+        return logs
+
+    def supports_fused_subgrid(self, dtype=None):
+        """True when transform_contributions + sum_finish_facets (include/swiftly_hip.h) exist for these sizes."""
+        torch = _torch()
+        logs = self._logs()
+        if logs is None or (dtype is not None and dtype != torch.complex64):
+            return False
         pairs = {(7, 8), (7, 10), (8, 9), (8, 10), (9, 10), (9, 11), (10, 11)}  # sum_finish instances
-        return logs["yN"] == 15 and 6 <= logs["m"] <= 9 and (logs["m"], logs["xM"]) in pairs
+        return logs["m"] <= 9 and (logs["m"], logs["xM"]) in pairs
+
+    def supports_band_pipeline(self, dtype=None):
+        """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
+        return self.supports_fused_subgrid(dtype) and self._logs()["yN"] == 15 and self._logs()["m"] >= 6
 
     def band_for_offsets(self, subgrid_offs):
         """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains

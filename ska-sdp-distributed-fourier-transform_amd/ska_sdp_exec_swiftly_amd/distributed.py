@@ -1,20 +1,40 @@
 """
-Multi-GPU forward pass: one process per GPU (torch.distributed; backend "nccl"
-is RCCL on ROCm, xGMI underneath), facets block-cyclically sharded over ranks,
+Multi-GPU forward and backward passes: one process per GPU (torch.distributed;
+backend "nccl" is RCCL on ROCm, xGMI underneath), facets sharded over ranks,
 subgrids of a wave owned round-robin, and ONE exchange step per wave: the
 per-(facet, subgrid) contribution shuffle that the reference leaves to Dask's
-worker-to-worker transfers (reference api.py:263-277) becomes an
-``all_to_all_single`` of ``[m, m]`` blocks.
+worker-to-worker transfers (forward: reference api.py:263-277; backward:
+api.py:357-364, api_helper.py:133-139) becomes an ``all_to_all_single`` of
+``[m, m]`` blocks.
 
-The exchange logic is independent of who computes the blocks: it takes a
-``make_contributions(subgrid_configs) -> [F_local, S, m, m]`` callable and a
-``finish(contrib[F, S_local, m, m], subgrid_configs_local)`` callable, so the
-partitioning / ordering is covered by world_size-2 gloo tests on CPU while the
-product wires in the HIP kernels (:class:`DistributedForward`).
+Layout of the exchange (no staging copies on either side):
+
+* forward, sender: the kernels that produce the blocks write them straight into
+  the send buffer ``[dest rank][local facet][subgrid owned by dest][m, m]``
+  (``transform_contributions`` takes output strides);
+  receiver: the receive buffer ``[source rank][facet of source][my subgrid]
+  [m, m]`` IS ``[facet in arrival order][my subgrid][m, m]`` -- the consumer
+  (``sum_finish_facets``) just gets the facet offsets in arrival order.
+* backward, sender: contributions are computed with the facets in owner-major
+  order, so the result ``[facet][my subgrid][m, m]`` is already the send
+  buffer; receiver: one chunk ``[my facet][subgrid of source][m, m]`` per
+  source rank, consumed chunk by chunk.
+
+The exchange logic is independent of who computes the blocks, so the
+partitioning / ordering is covered by world_size-2/3 gloo tests on CPU
+(tests/test_distributed_cpu.py) while the product wires in the HIP kernels
+(:class:`DistributedForward`, :class:`DistributedBackward`).
 """
 import numpy
 
-__all__ = ["FacetSharding", "exchange_contributions", "start_exchange", "DistributedForward"]
+__all__ = [
+    "FacetSharding",
+    "exchange_contributions",
+    "start_exchange",
+    "exchange_blocks",
+    "DistributedForward",
+    "DistributedBackward",
+]
 
 
 def _torch():
@@ -25,34 +45,88 @@ def _torch():
 
 class FacetSharding:
     """Who owns what.  Facet ``j`` lives on rank ``j % world``; subgrid number
-    ``i`` of a wave is finished on rank ``i % world``."""
+    ``i`` of a wave is finished (forward) / held (backward) on rank ``i % world``."""
 
     def __init__(self, n_facets, rank, world):
         self.n_facets, self.rank, self.world = n_facets, rank, world
         self.facets_of = [[j for j in range(n_facets) if j % world == r] for r in range(world)]
         self.local_facets = self.facets_of[rank]
-        # facet order after concatenating received blocks in source-rank order
+        # facet order after concatenating received blocks in source-rank order (= owner-major order)
         self.arrival_order = [j for r in range(world) for j in self.facets_of[r]]
         self.to_global = numpy.argsort(self.arrival_order)  # arrival position of global facet j
 
     def subgrids_of(self, n_subgrids, rank=None):
-        """indices (within the wave) of the subgrids rank finishes"""
+        """indices (within the wave) of the subgrids of ``rank``"""
         rank = self.rank if rank is None else rank
         return list(range(rank, n_subgrids, self.world))
 
 
-class _Exchange:
-    """In-flight all-to-all of one wave (``wait()`` returns the re-ordered contributions)."""
+class _Pending:
+    """In-flight all-to-all (keeps the buffers alive until the collective is done)."""
 
-    def __init__(self, work, recv, send, sharding, n_mine, blk):
-        self.work, self.recv, self.send = work, recv, send  # send is kept alive until the collective is done
-        self.sharding, self.n_mine, self.blk = sharding, n_mine, blk
+    def __init__(self, work, recv, send):
+        self.work, self.recv, self.send = work, recv, send
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.recv
+
+
+def _all_to_all(send, in_counts, out_counts, group=None, async_op=True):
+    """``all_to_all_single`` of a contiguous (complex or real) 1-D tensor whose per-destination chunks are
+    consecutive; counts in elements.  RCCL has no complex type: complex data travels as interleaved reals."""
+    torch = _torch()
+    dist = torch.distributed
+    recv = torch.empty(int(sum(out_counts)), dtype=send.dtype, device=send.device)
+    if send.is_complex():
+        work = dist.all_to_all_single(
+            torch.view_as_real(recv).reshape(-1), torch.view_as_real(send).reshape(-1),
+            [2 * int(n) for n in out_counts], [2 * int(n) for n in in_counts], group=group, async_op=async_op,
+        )
+    else:
+        work = dist.all_to_all_single(recv, send, [int(n) for n in out_counts], [int(n) for n in in_counts],
+                                      group=group, async_op=async_op)
+    return _Pending(work if async_op else None, recv, send)
+
+
+def forward_layout(sharding, n_subgrids, blk):
+    """Element counts of the forward exchange: (per-destination subgrid index lists, in_counts, out_counts)."""
+    F_local = len(sharding.local_facets)
+    mine = sharding.subgrids_of(n_subgrids)
+    dests = [sharding.subgrids_of(n_subgrids, r) for r in range(sharding.world)]
+    in_counts = [F_local * len(d) * blk for d in dests]
+    out_counts = [len(sharding.facets_of[r]) * len(mine) * blk for r in range(sharding.world)]
+    return dests, in_counts, out_counts
+
+
+def backward_layout(sharding, n_subgrids, blk):
+    """Element counts of the backward exchange (subgrid holder -> facet owner)."""
+    mine = sharding.subgrids_of(n_subgrids)
+    F_local = len(sharding.local_facets)
+    in_counts = [len(sharding.facets_of[r]) * len(mine) * blk for r in range(sharding.world)]
+    out_counts = [F_local * len(sharding.subgrids_of(n_subgrids, r)) * blk for r in range(sharding.world)]
+    return in_counts, out_counts
+
+
+def exchange_blocks(send, in_counts, out_counts, group=None, async_op=True):
+    """Start the all-to-all of an already laid-out send buffer; ``wait()`` returns the flat receive buffer."""
+    torch = _torch()
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()) or len(in_counts) == 1:
+        return _Pending(None, send, send)
+    return _all_to_all(send.reshape(-1), in_counts, out_counts, group, async_op)
+
+
+# -- r1 interface (kept: generic tests and callers that materialise [F_local, S, m, m]) ------------------------
+class _Reordered:
+    def __init__(self, pending, sharding, n_mine, blk):
+        self.pending, self.sharding, self.n_mine, self.blk = pending, sharding, n_mine, blk
 
     def wait(self):
         torch = _torch()
-        if self.work is not None:
-            self.work.wait()
-        arrived = self.recv.reshape(self.sharding.n_facets, self.n_mine, *self.blk)  # source-rank (arrival) order
+        recv = self.pending.wait()
+        arrived = recv.reshape(self.sharding.n_facets, self.n_mine, *self.blk)  # arrival (owner-major) facet order
         return arrived[torch.as_tensor(self.sharding.to_global, device=arrived.device)]
 
 
@@ -65,106 +139,192 @@ class _Done:
 
 
 def start_exchange(contrib_local, sharding, group=None, async_op=True):
-    """Issue the all-to-all of one wave and return a handle whose ``wait()`` gives
-    ``[F, S_local, m, m]`` (all facets in global order, the subgrids this rank owns).
-
-    With ``async_op`` the collective runs on RCCL's own stream: kernels launched
-    afterwards on the compute stream (the next wave's column / extract kernels)
-    overlap with it, and only ``wait()`` orders the compute stream behind it.
-    """
+    """Issue the forward all-to-all of one wave for contributions materialised as ``[F_local, S, m, m]`` and
+    return a handle whose ``wait()`` gives ``[F, S_local, m, m]`` (all facets in GLOBAL order, the subgrids this
+    rank owns).  This convenience form stages the data twice (pack per destination, reorder on arrival);
+    :class:`DistributedForward` avoids both copies."""
     torch = _torch()
-    dist = torch.distributed
     world = sharding.world
     S = contrib_local.shape[1]
     blk = tuple(contrib_local.shape[2:])
-    mine = sharding.subgrids_of(S)
     if world == 1:
         return _Done(contrib_local)
-    # send buffer: for every destination rank the blocks [F_local, S_dest, m, m]
-    pieces = [contrib_local[:, sharding.subgrids_of(S, r)].reshape(-1) for r in range(world)]
-    send = torch.cat(pieces)
     nblk = int(numpy.prod(blk))
-    in_split = [p.numel() for p in pieces]
-    out_split = [len(sharding.facets_of[r]) * len(mine) * nblk for r in range(world)]
-    recv = torch.empty(sum(out_split), dtype=contrib_local.dtype, device=contrib_local.device)
-    if contrib_local.is_complex():
-        # RCCL has no complex type: ship as interleaved reals
-        work = dist.all_to_all_single(
-            torch.view_as_real(recv).reshape(-1),
-            torch.view_as_real(send).reshape(-1),
-            [2 * n for n in out_split],
-            [2 * n for n in in_split],
-            group=group,
-            async_op=async_op,
-        )
-    else:
-        work = dist.all_to_all_single(recv, send, out_split, in_split, group=group, async_op=async_op)
-    return _Exchange(work if async_op else None, recv, send, sharding, len(mine), blk)
+    dests, in_counts, out_counts = forward_layout(sharding, S, nblk)
+    send = torch.cat([contrib_local[:, d].reshape(-1) for d in dests])
+    pending = _all_to_all(send, in_counts, out_counts, group, async_op)
+    return _Reordered(pending, sharding, len(sharding.subgrids_of(S)), blk)
 
 
 def exchange_contributions(contrib_local, sharding, group=None):
-    """Blocking all-to-all of one wave.
-
-    :param contrib_local: ``[F_local, S, m, m]`` contributions of this rank's
-        facets to all ``S`` subgrids of the wave
-    :return: ``[F, S_local, m, m]`` contributions of ALL facets (global facet
-        order) to the subgrids this rank owns (``sharding.subgrids_of(S)``)
-    """
+    """Blocking form of :func:`start_exchange`."""
     return start_exchange(contrib_local, sharding, group, async_op=False).wait()
+
+
+def _dist_info(group):
+    torch = _torch()
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
 
 
 class DistributedForward:
     """Facet-sharded ``SwiftlyForward`` (HIP).  Every rank constructs it with
     the FULL list of facet configs but only the data of its own facets
     (``facet_data[j]`` for ``j in sharding.local_facets``; other entries are
-    ignored and may be ``None``)."""
+    ignored and may be ``None``).
 
-    def __init__(self, swiftly_config, facet_configs, facet_data, lru_forward=1, group=None, subgrid_configs=None):
-        from .api import SwiftlyForward  # pylint: disable=import-outside-toplevel
+    Per wave each rank runs K1/K2 for its facets, computes the axis-0-transformed
+    contributions ``G`` (``transform_contributions``) of its facets to ALL
+    subgrids of the wave directly into the send buffer, the all-to-all moves the
+    blocks to the subgrids' owners, and the owners run ``sum_finish_facets`` +
+    the axis-0 finish.  ``dtype``: complex dtype of the pass (all ranks must
+    agree; a rank without facets cannot infer it)."""
+
+    def __init__(self, swiftly_config, facet_configs, facet_data, lru_forward=1, group=None, subgrid_configs=None,
+                 wave_axis=None, dtype=None):
+        from .api import SwiftlyForward, preferred_wave_axis  # pylint: disable=import-outside-toplevel
 
         torch = _torch()
-        dist = torch.distributed
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank, self.world = _dist_info(group)
         self.config = swiftly_config
+        self.core = swiftly_config.core
         self.facet_configs = list(facet_configs)
         self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world)
         local = self.sharding.local_facets
+        self.dtype = dtype if dtype is not None else torch.complex64
+        if wave_axis is None:
+            wave_axis = preferred_wave_axis(swiftly_config, self.dtype)
         self.local = SwiftlyForward(
             swiftly_config,
             [(self.facet_configs[j], facet_data[j]) for j in local],
             lru_forward=lru_forward,
             subgrid_configs=subgrid_configs,
+            wave_axis=wave_axis,
         )
+        if local and self.local.dtype != self.dtype:
+            raise ValueError(f"local facets are {self.local.dtype}, the pass was declared {self.dtype}")
+        self.local.dtype = self.dtype
+        self.wave_axis = wave_axis
+        self.arrival_cfgs = [self.facet_configs[j] for j in self.sharding.arrival_order]
+        self.fused = self.dtype == torch.complex64 and self.local.supports_fused_subgrid_side()
+
+    def prepare_all_facets(self):
+        """K1 for the local facets"""
+        if self.sharding.local_facets:
+            self.local.prepare_all_facets()
 
     def start_wave(self, sgs):
-        """Compute this rank's contributions to the subgrids ``sgs`` (same
-        ``off0`` / ``size``) and start their all-to-all; returns a handle for
-        :py:meth:`finish_wave`.  Starting wave w+1 before finishing wave w
-        overlaps the exchange with the column and extract kernels."""
+        """Compute this rank's blocks for the subgrids ``sgs`` (one wave: same wave key and size) and start
+        their all-to-all; returns a handle for :py:meth:`finish_wave`.  Starting wave w+1 before finishing
+        wave w overlaps the exchange (RCCL's stream) with the facet-side kernels (compute stream)."""
         torch = _torch()
-        if self.sharding.local_facets:
-            contrib = self.local.wave_contributions(sgs)
-        else:
-            core = self.config.core
-            m = core.xM_yN_size
-            contrib = torch.empty((0, len(sgs), m, m), dtype=self.local.dtype, device=core.device)
-        return sgs, start_exchange(contrib, self.sharding, self.group)
+        core = self.core
+        m = core.xM_yN_size
+        S = len(sgs)
+        dests, in_counts, out_counts = forward_layout(self.sharding, S, m * m)
+        F_local = len(self.sharding.local_facets)
+        send = torch.empty(sum(in_counts), dtype=self.dtype, device=core.device)
+        pos = 0
+        for d, cnt in zip(dests, in_counts):
+            if cnt:
+                block = send[pos : pos + cnt].view(F_local, len(d), m, m)
+                self.local.wave_blocks([sgs[i] for i in d], block, transformed=self.fused)
+            pos += cnt
+        return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
 
     def finish_wave(self, handle):
         """Finish the subgrids of a started wave that this rank owns: returns
         ``(indices within sgs, tensor [S_local, xA, xA] or None)``."""
-        from .api import sum_and_finish_wave  # pylint: disable=import-outside-toplevel
+        from .api import finish_from_blocks  # pylint: disable=import-outside-toplevel
 
-        sgs, exch = handle
+        sgs, pending = handle
         mine = self.sharding.subgrids_of(len(sgs))
-        allc = exch.wait()
+        recv = pending.wait()
         if not mine:
             return mine, None
-        res = sum_and_finish_wave(self.config.core, allc, self.facet_configs, [sgs[i] for i in mine])
+        m = self.core.xM_yN_size
+        blocks = recv.view(len(self.facet_configs), len(mine), m, m)  # facets in arrival order
+        res = finish_from_blocks(self.core, blocks, self.arrival_cfgs, [sgs[i] for i in mine], transformed=self.fused)
         return mine, res
 
     def get_subgrid_wave(self, sgs):
         """start_wave + finish_wave"""
         return self.finish_wave(self.start_wave(sgs))
+
+
+class DistributedBackward:
+    """Facet-sharded ``SwiftlyBackward`` (HIP): subgrid ``i`` of a wave is held
+    by rank ``i % world`` (where the forward pass left it), its contributions to
+    every facet are computed there (``prepare_and_split_subgrid``, reference
+    api_helper.py:115-139) in owner-major facet order -- which makes the result
+    the send buffer -- and the mirror all-to-all delivers them to the facets'
+    owners, who accumulate (api_helper.py:142-179) and finally finish their
+    facets (api_helper.py:182-197)."""
+
+    def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None):
+        from .api import SwiftlyBackward  # pylint: disable=import-outside-toplevel
+
+        self.group = group
+        self.rank, self.world = _dist_info(group)
+        self.config = swiftly_config
+        self.core = swiftly_config.core
+        self.facet_configs = list(facet_configs)
+        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world)
+        # facet owner side: accumulators of the local facets
+        self.local = SwiftlyBackward(
+            swiftly_config, [self.facet_configs[j] for j in self.sharding.local_facets], lru_backward=lru_backward
+        )
+        # subgrid holder side: contributions to ALL facets, owner-major order
+        self.splitter = SwiftlyBackward(
+            swiftly_config, [self.facet_configs[j] for j in self.sharding.arrival_order], lru_backward=1
+        )
+
+    def start_wave(self, sgs, subgrids_mine):
+        """``sgs``: all subgrid configs of the wave (same ``off0`` and size, identical on every rank);
+        ``subgrids_mine``: data of the subgrids this rank holds, in the order of
+        ``sharding.subgrids_of(len(sgs))``.  Starts the exchange; returns a handle for :py:meth:`finish_wave`."""
+        torch = _torch()
+        core = self.core
+        m = core.xM_yN_size
+        S = len(sgs)
+        mine = self.sharding.subgrids_of(S)
+        if len(subgrids_mine) != len(mine):
+            raise ValueError(f"rank {self.rank} holds {len(mine)} subgrids of this wave, got {len(subgrids_mine)}")
+        in_counts, out_counts = backward_layout(self.sharding, S, m * m)
+        if mine:
+            send = self.splitter.wave_contributions([sgs[i] for i in mine], subgrids_mine).reshape(-1)
+            self.local.dtype = self.local.dtype or send.dtype
+        else:
+            dt = self.local.dtype or self.splitter.dtype or torch.complex64
+            send = torch.empty(0, dtype=dt, device=core.device)
+        return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
+
+    def finish_wave(self, handle):
+        """Accumulate the received contributions into this rank's facets."""
+        sgs, pending = handle
+        recv = pending.wait()
+        F_local = len(self.sharding.local_facets)
+        if not F_local:
+            return
+        m = self.core.xM_yN_size
+        S = len(sgs)
+        chunks = []
+        pos = 0
+        for r in range(self.world):
+            idx = self.sharding.subgrids_of(S, r)
+            cnt = F_local * len(idx) * m * m
+            if cnt:
+                chunks.append(([sgs[i] for i in idx], recv[pos : pos + cnt].view(F_local, len(idx), m, m)))
+            pos += cnt
+        self.local.accumulate_chunks(sgs[0].off0, chunks)
+
+    def add_wave(self, sgs, subgrids_mine):
+        """start_wave + finish_wave"""
+        self.finish_wave(self.start_wave(sgs, subgrids_mine))
+
+    def finish(self):
+        """Finished facets of this rank: ``(global facet indices, list of tensors)``."""
+        return self.sharding.local_facets, (self.local.finish() if self.sharding.local_facets else [])

@@ -15,7 +15,14 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import swiftly_oracle as orc
-from ska_sdp_exec_swiftly_amd.distributed import FacetSharding, exchange_contributions, start_exchange
+from ska_sdp_exec_swiftly_amd.distributed import (
+    FacetSharding,
+    backward_layout,
+    exchange_blocks,
+    exchange_contributions,
+    forward_layout,
+    start_exchange,
+)
 
 P = dict(W=11.0, N=512, yB_size=176, yN_size=256, xA_size=96, xM_size=128)
 
@@ -106,3 +113,97 @@ def test_sharding_bookkeeping():
     one = FacetSharding(3, 0, 1)
     t = torch.zeros((3, 2, 4, 4))
     assert exchange_contributions(t, one) is t
+
+
+# --------------------------------------------------------------------------------------------------------------
+# The copy-free layouts DistributedForward / DistributedBackward use (blocks written straight into the send
+# buffer, receive buffer consumed in arrival order), forward + backward round trip, compute by the oracle.
+def _roundtrip_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        core, facet_items, sg_items, facets = _problem()
+        m = core.xM_yN_size
+        S = len(sg_items)
+        sh = FacetSharding(len(facet_items), rank, world)
+        F_local = len(sh.local_facets)
+        local = _contribs(core, facet_items, facets, sg_items, sh.local_facets)  # [F_local, S, m, m]
+        # ---- forward: send buffer [dest][local facet][subgrid of dest][m, m]
+        dests, in_counts, out_counts = forward_layout(sh, S, m * m)
+        send = torch.empty(sum(in_counts), dtype=torch.complex128)
+        pos = 0
+        for d, cnt in zip(dests, in_counts):
+            if cnt:
+                send[pos : pos + cnt].view(F_local, len(d), m, m).copy_(torch.from_numpy(local[:, d]))
+            pos += cnt
+        recv = exchange_blocks(send, in_counts, out_counts).wait()
+        mine = sh.subgrids_of(S)
+        blocks = recv.view(len(facet_items), len(mine), m, m).numpy()  # facets in ARRIVAL order
+        arrival_items = [facet_items[j] for j in sh.arrival_order]
+        subgrids = [
+            orc.sum_and_finish_subgrid(core, list(blocks[:, k]), arrival_items, sg_items[i]) for k, i in enumerate(mine)
+        ]
+        # ---- backward: contributions of my subgrids to ALL facets in owner-major order = the send buffer
+        in_counts, out_counts = backward_layout(sh, S, m * m)
+        parts = numpy.empty((len(facet_items), len(mine), m, m), dtype=complex)
+        for k, i in enumerate(mine):
+            split = orc.prepare_and_split_subgrid(core, subgrids[k], [sg_items[i].off0, sg_items[i].off1], arrival_items)
+            for f, c in enumerate(split):
+                parts[f, k] = c
+        recv = exchange_blocks(torch.from_numpy(parts).reshape(-1), in_counts, out_counts).wait()
+        cols = [None] * F_local
+        pos = 0
+        for r in range(world):
+            idx = sh.subgrids_of(S, r)
+            cnt = F_local * len(idx) * m * m
+            if cnt:
+                chunk = recv[pos : pos + cnt].view(F_local, len(idx), m, m).numpy()
+                for a in range(F_local):
+                    for b, i in enumerate(idx):
+                        cols[a] = orc.accumulate_column(core, chunk[a, b], cols[a], sg_items[i].off1)
+            pos += cnt
+        out = []
+        for a, j in enumerate(sh.local_facets):
+            acc = orc.accumulate_facet(core, cols[a], None, facet_items[j], sg_items[0].off0)
+            out.append(orc.finish_facet_2d(core, acc, facet_items[j]))
+        q.put((rank, mine, subgrids, sh.local_facets, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_copy_free_layouts_forward_backward(world):
+    core, facet_items, sg_items, facets = _problem()
+    want_sg = orc.forward_all(core, facet_items, facets, sg_items)
+    want_f = orc.backward_all(core, facet_items, sg_items, want_sg)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_roundtrip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got_sg, got_f = {}, {}
+    for _ in range(world):
+        _, mine, subgrids, lf, fac = q.get(timeout=240)
+        got_sg.update(dict(zip(mine, subgrids)))
+        got_f.update(dict(zip(lf, fac)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(got_sg) == list(range(len(sg_items))) and sorted(got_f) == list(range(len(facet_items)))
+    for i, w in enumerate(want_sg):
+        assert numpy.allclose(got_sg[i], w, rtol=0, atol=1e-13 * numpy.abs(w).max())
+    for j, w in enumerate(want_f):
+        assert numpy.allclose(got_f[j], w, rtol=0, atol=1e-12 * numpy.abs(w).max())
+
+
+def test_layout_counts():
+    sh = FacetSharding(9, 2, 4)  # local facets [2, 6]
+    dests, inc, outc = forward_layout(sh, 10, 5)
+    assert dests == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    assert inc == [2 * 3 * 5, 2 * 3 * 5, 2 * 2 * 5, 2 * 2 * 5]
+    assert outc == [3 * 2 * 5, 2 * 2 * 5, 2 * 2 * 5, 2 * 2 * 5]  # facets of src x my 2 subgrids
+    binc, boutc = backward_layout(sh, 10, 5)
+    assert binc == outc and boutc == inc  # the backward exchange is the transpose of the forward one
