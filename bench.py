@@ -315,8 +315,8 @@ def main():
     sg_cfgs = select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
     force_dist = os.environ.get("SWIFTLY_BENCH_FORCE_DIST") == "1"  # exercise the multi-GPU code path on 1 GPU
     single = world == 1 and not force_dist
-    wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64) if single else 0
-    if args.wave_axis is not None and single:
+    wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64)
+    if args.wave_axis is not None:
         wave_axis = args.wave_axis
     key = (lambda c: c.off1) if wave_axis == 1 else (lambda c: c.off0)
     waves = {}
@@ -367,8 +367,11 @@ def main():
     else:
 
         def one_pass(timer=None, keep=None):  # pylint: disable=unused-argument
-            dfw = DistributedForward(cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs)
-            dfw.local._get_BF_Fs()  # pylint: disable=protected-access
+            dfw = DistributedForward(
+                cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs, wave_axis=wave_axis,
+                dtype=torch.complex64,
+            )
+            dfw.prepare_all_facets()
             # software pipeline: the all-to-all of wave w runs while wave w+1's column/extract kernels do
             n = 0
             pending = None
@@ -451,20 +454,28 @@ def main():
     if roofline is None and local:
         # multi-GPU: time K1 of one local facet on this rank (outside the timed region) for the roofline object
         core = cfg.core
-        rowmap, n_rows = core.subgrid_column_rows([sg.off0 for sg in sg_cfgs])
         j0 = local[0]
-        buf = core.prepare_facet_rows(facet_data[j0], facet_cfgs[j0].off0, rowmap, n_rows, fold_axis1_window=True)
+        if wave_axis == 1:
+            band = core.band_for_offsets([sg.off1 for sg in sg_cfgs])
+            buf = core.prepare_facet_band(facet_data[j0], facet_cfgs[j0].off1, band)
+            k1 = lambda: core.prepare_facet_band(facet_data[j0], facet_cfgs[j0].off1, band, out=buf)  # noqa: E731
+        else:
+            rowmap, n_rows = core.subgrid_column_rows([sg.off0 for sg in sg_cfgs])
+            buf = core.prepare_facet_rows(facet_data[j0], facet_cfgs[j0].off0, rowmap, n_rows, fold_axis1_window=True)
+            k1 = lambda: core.prepare_facet_rows(  # noqa: E731
+                facet_data[j0], facet_cfgs[j0].off0, rowmap, n_rows, out=buf, fold_axis1_window=True
+            )
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            core.prepare_facet_rows(facet_data[j0], facet_cfgs[j0].off0, rowmap, n_rows, out=buf, fold_axis1_window=True)
+            k1()
         e1.record()
         torch.cuda.synchronize()
         k1_ms = e0.elapsed_time(e1) / 3
         k1_bytes = parts["K1"] / F
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         roofline = dict(
-            kernel="K1 prepare_facet(axis=0) per facet (rank 0) = col_pass<n1> + col_pass<n2>",
+            kernel=sw_api.K1_DESCRIPTION[wave_axis] + " (rank 0, one facet)",
             bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
             algorithmic_bytes_per_launch=k1_bytes, avg_launch_ms=round(k1_ms, 4),

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         unsigned off;
         if constexpr (BAND) {
             const int d = (ck - A.band_start) & (N - 1);
-            off = d < A.band_len ? region + ((unsigned)(d >> 1) << 3) : 0xfffffff8u;
+            off = d < A.band_len ? region + ((unsigned)(d >> 1) << 3) : 0x40000000u;
         } else {
             off = (unsigned)ck << 3;
         }

@@ -186,3 +186,45 @@ def test_forward_c64_test_params_fused_paths():
     got2 = [s.cpu().numpy() for s in fwd2.get_subgrid_tasks(sg_cfgs)]
     for a, b in zip(got2, want):
         assert relrms(a, b) < 1e-10
+
+
+@pytest.mark.parametrize("params,dtype", [(TEST_PARAMS, numpy.complex64), (SMALL11_PARAMS, numpy.complex128)])
+def test_distributed_classes_world1(params, dtype):
+    """DistributedForward / DistributedBackward with a single rank (no process group): same results as the
+    single-process classes, through the exchange layouts (send buffer written in place, arrival-order consumption).
+    TEST_PARAMS/complex64 takes the fused route (transformed blocks), SMALL11/complex128 the raw-contribution route."""
+    import torch
+
+    from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
+
+    sw, cfg, facet_cfgs, sg_cfgs, facets = small_problem(params, dtype, 777)
+    tdt = torch.complex64 if dtype == numpy.complex64 else torch.complex128
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), wave_axis=0)
+    dfw = DistributedForward(cfg, facet_cfgs, [torch.from_numpy(f).cuda() for f in facets], dtype=tdt, wave_axis=0)
+    assert dfw.fused == (dtype == numpy.complex64)
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=2)
+    dbw = DistributedBackward(cfg, facet_cfgs, lru_backward=2)
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off0, []).append(c)
+    pending = None
+    results = []
+    for wave in waves.values():  # pipelined like bench.py: start w+1 before finishing w
+        handle = dfw.start_wave(wave)
+        if pending is not None:
+            results.append(dfw.finish_wave(pending))
+        pending = handle
+    results.append(dfw.finish_wave(pending))
+    tol = 3e-6 if dtype == numpy.complex64 else 1e-12
+    for wave, (mine, res) in zip(waves.values(), results):
+        assert mine == list(range(len(wave)))
+        want = fwd.get_wave(wave)
+        scale = float(want.abs().max())
+        assert float((res - want).abs().max()) <= tol * scale
+        bwd.add_new_subgrid_tasks(wave, [want[k] for k in range(len(wave))])
+        dbw.add_wave(wave, [want[k] for k in range(len(wave))])
+    idx, got = dbw.finish()
+    ref = bwd.finish()
+    assert idx == list(range(len(facet_cfgs)))
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
