@@ -90,8 +90,18 @@ static int launch_band_geo(const RowPassArgs& a, const cx<float>* tw14, const cx
 #undef SWF_LAUNCH_BAND
     return (int)hipGetLastError();
 }
+using BandGeo64k = RGeo<15, 5, true>;  // yN = 65536: 2 x 32768 points, 1024 threads x 32, 132 KB LDS, one workgroup per CU
+using BandGeo16k = RGeo<13, 4, true>;  // yN = 16384: 2 x  8192 points,  512 threads x 16, 33 KB LDS
 int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
+    return launch_row_pass_band_n(15, a, tw14, tw_full, s);
+}
+// logn = log2 of the full row length (14, 15 or 16); tw_half = table of length 2^(logn-1), tw_full of length 2^logn
+int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s) {
     if (a.nrows <= 0) return 0;
+    if (logn == 16) return launch_band_geo<BandGeo64k>(a, tw_half, tw_full, s);
+    if (logn == 14) return launch_band_geo<BandGeo16k>(a, tw_half, tw_full, s);
+    if (logn != 15) return -1;
+    const cx<float>* tw14 = tw_half;
     // tuning knob SWIFTLY_ROW_GEO: 5 (512 threads x 32 points, two workgroups per CU) | 4 (1024 x 16, one per CU);
     // default: 5 for the band store (1 spilled VGPR), 4 for the plain store (the 512-thread form spills ~49 there)
     static const int geo_env = getenv("SWIFTLY_ROW_GEO") ? atoi(getenv("SWIFTLY_ROW_GEO")) : 0;
@@ -137,6 +147,8 @@ int init_row_pass() {
     {
         int rcb = init_band_geo<BandGeo5>();
         if (!rcb) rcb = init_band_geo<BandGeo4>();
+        if (!rcb) rcb = init_band_geo<BandGeo64k>();
+        if (!rcb) rcb = init_band_geo<BandGeo16k>();
         if (rcb) return rcb;
     }
     {

@@ -124,7 +124,7 @@ static int upload(swiftly_hip* h, T** dst, const std::vector<T>& v) {
 static int make_twiddles(swiftly_hip* h, int logn) {
     if (logn < kMinLogN) return 0;
     const int n = 1 << logn;
-    if (logn <= kMaxLogNFloat && !h->tw_f.count(logn)) {
+    if (logn <= kMaxLogNFloat + 1 && !h->tw_f.count(logn)) {  // 2^16: only the band row kernel and the column passes use it
         std::vector<cx<float>> t(n);
         for (int k = 0; k < n; k++) {
             // exact octant symmetry is not needed; evaluate in long double
@@ -255,6 +255,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             if (!rc && l >= kTwoPassMinLog) rc = make_twiddles(h, l - l / 2);
             if (!rc && l == 15) rc = make_twiddles(h, 14);  // multi-workgroup row kernels
             if (!rc && l == 15) rc = make_twiddles(h, 13);
+            if (!rc && (l == 16 || l == 14)) rc = make_twiddles(h, l - 1);  // band row kernel halves
         }
     if (rc) {
         swiftly_hip_destroy(h);
@@ -1120,7 +1121,8 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: complex64 only");
     CHECK_FACET_SIZE();
     const int yN = (int)h->yN;
-    if (h->log_yN != 15) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: padded facet size %d not supported (32768)", yN);
+    if (h->log_yN < 14 || h->log_yN > 16)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: padded facet size %d not supported (16384, 32768, 65536)", yN);
     if (rows < 0 || rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "bad row count");
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN)
         return fail(SWIFTLY_ERR_PARAM, "band [%lld, +%lld) is not a cyclic range of [0, %d)", (long long)band_start, (long long)band_len, yN);
@@ -1140,10 +1142,10 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     r.conj_ld = r.conj_st = 1;
     r.row_win = fold_other_axis_window ? h->invp_f + (yN / 2 - (int)(rows / 2)) : nullptr;
     r.band_start = (int)band_start; r.band_len = (int)band_len; r.band_half = (int)((band_len + 1) / 2);
-    const cx<float>* tw14 = twiddles<float>(h, 14);
-    const cx<float>* twf = twiddles<float>(h, 15);
-    if (!tw14 || !twf) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    int e = launch_row_pass_band(r, tw14, twf, (hipStream_t)stream);
+    const cx<float>* twh = twiddles<float>(h, h->log_yN - 1);
+    const cx<float>* twf = twiddles<float>(h, h->log_yN);
+    if (!twh || !twf) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
+    int e = launch_row_pass_band_n(h->log_yN, r, twh, twf, (hipStream_t)stream);
     if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return 0;
 }

@@ -193,12 +193,14 @@ constexpr int lds_delta(int d, bool rowfast) {
 // butterfly inputs x[U + r*NB], r = 1..RAD-1.  Powers of two come from the
 // table (tw[k] = exp(-2 pi i k / N)), the rest from at most log2(RAD)-1
 // complex products, which keeps the error at a few ulp.
-// Two-factor form (default): r = Q*hi + lo with Q = 2^ceil(LOGR/2); w^lo (lo < Q) and w^(Q hi) come straight
-// from the table (exactly rounded), every other w^r is ONE product of two table values -- at most one extra
-// rounding per twiddle (the r1 form chained up to log2(RAD)-1 products: ~2x the twiddle error and, in its
-// register-lean variant, 49 products per radix-32 group instead of 21).
+// Two-factor form (SWF_TW_TWO_FACTOR=1, off by default): r = Q*hi + lo with Q = 2^ceil(LOGR/2); w^lo (lo < Q) and
+// w^(Q hi) come straight from the table (exactly rounded), every other w^r is ONE product of two table values.
+// Measured on MI355X (r2, same-box A/B): end-to-end complex64 error 1.0137e-5 vs 1.0172e-5 for the chained form
+// below -- twiddle rounding is NOT what sets the float32 floor (storage rounding of window-amplified intermediates
+// is) -- while its Q live table values cost registers in the 128-VGPR row kernel
+// (K1 20.3 -> 21.8 ms per pass).
 #ifndef SWF_TW_TWO_FACTOR
-#define SWF_TW_TWO_FACTOR 1
+#define SWF_TW_TWO_FACTOR 0
 #endif
 template <typename R, int LOGR, int NB, int U, int PTOT, int N>
 __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx) {

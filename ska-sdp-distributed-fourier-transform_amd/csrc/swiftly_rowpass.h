@@ -15,6 +15,16 @@ namespace swf {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// buffer (range-checked) accesses in the band row kernel: A/B switches.  Measured (r2, same box, K1 per pass):
+// global loads + exec-masked stores 20.2 ms (at 86 spilled VGPRs in some variants: 51 ms -- the kernel sits at the
+// 128-VGPR limit), buffer loads 20.3 ms with ~10 % fewer instructions and no spills (default), buffer stores too 20.7 ms.
+#ifndef SWF_ROW_BUFFER
+#define SWF_ROW_BUFFER 1
+#endif
+#ifndef SWF_ROW_BUFFER_ST
+#define SWF_ROW_BUFFER_ST 0
+#endif
+
 struct RowPassArgs {
     const cx<float>* in;
     cx<float>* out;
@@ -343,6 +353,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     // element, no memory access for the padding), and a row that is absent from a compacted input gets an empty
     // descriptor.  No control flow: the compiler keeps as many of the 2 P loads of a lane in flight as the
     // 128-VGPR budget (two workgroups per CU) allows.
+#if SWF_ROW_BUFFER
     const unsigned valid = dead ? 0u : (unsigned)A.ld_len;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
@@ -365,6 +376,29 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         });
         x[v] = cx<float>{a[0].x + sgn * a[1].x, (a[0].y + sgn * a[1].y) * sg_ld};
     });
+#else
+    const int base = (t + A.ld_a + (N >> 1)) & (N - 1);  // q of plain index j = t (centred index j ^ N/2 = j + N/2 mod N)
+    const float alive = dead ? 0.f : 1.f;
+    cx<float> x[P];
+    static_for<0, P>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        cx<float> a[2];
+        static_for<0, 2>([&](auto qI) {
+            constexpr int q = decltype(qI)::value;
+            const int qq = (base + v * T + q * H) & (N - 1);
+            const bool ok = qq < A.ld_len;
+            const unsigned qs = ok ? (unsigned)qq : 0u;
+            const f32x2 val = *reinterpret_cast<const f32x2*>(inb + (qs << 3));
+            float w = ok ? alive : 0.f;
+            if constexpr (HAS_WIN) {
+                const float wv = *reinterpret_cast<const float*>(winb + (qs << 2));
+                w = ok ? wv * alive : 0.f;
+            }
+            a[q] = cx<float>{val.x * w, val.y * w};
+        });
+        x[v] = cx<float>{a[0].x + sgn * a[1].x, (a[0].y + sgn * a[1].y) * sg_ld};
+    });
+#endif
     if (h) {  // uniform: odd outputs need W_N^j = W_N^t * W_64^v
         const cx<float> wt = tw_full[t];
         static_for<0, P>([&](auto vI) {
@@ -379,13 +413,16 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     // band store: d = (ck - band_start) mod N has the parity of h ^ band_start for the whole workgroup, so the
     // destination (d & 1) * band_half + (d >> 1) is  region base + (d >> 1)
     const unsigned region = BAND ? (unsigned)(((h ^ A.band_start) & 1) * A.band_half) << 3 : 0u;
+#if SWF_ROW_BUFFER_ST
     // buffer stores: an offset outside the descriptor is dropped by the hardware, so outputs outside the band need
     // no branch -- their offset is simply pushed out of range
     const unsigned out_bytes = (unsigned)(BAND ? 2 * A.band_half : N) << 3;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb, (short)0, (int)out_bytes, 0x00020000);
+#endif
     fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
         const int ck = (2 * e + h) ^ (N >> 1);
         const f32x2 val = {v.x * scale, v.y * scale_im};
+#if SWF_ROW_BUFFER_ST
         unsigned off;
         if constexpr (BAND) {
             const int d = (ck - A.band_start) & (N - 1);
@@ -394,6 +431,14 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
             off = (unsigned)ck << 3;
         }
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)off, 0, 0);
+#else
+        if constexpr (BAND) {
+            const int d = (ck - A.band_start) & (N - 1);
+            if (d < A.band_len) *reinterpret_cast<f32x2*>(outb + region + ((unsigned)(d >> 1) << 3)) = val;
+        } else {
+            *reinterpret_cast<f32x2*>(outb + ((unsigned)ck << 3)) = val;
+        }
+#endif
     });
 }
 
@@ -407,6 +452,7 @@ int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<
                           hipStream_t s);
 // 2 x 16384-point form with 512-thread workgroups (two per CU); a.band_len > 0 selects the band store
 int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s);
+int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s);
 int row_pass_band_occupancy();
 
 }  // namespace swf

@@ -416,7 +416,7 @@ class SwiftlyCoreHip:
 
     def supports_band_pipeline(self, dtype=None):
         """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
-        return self.supports_fused_subgrid(dtype) and self._logs()["yN"] == 15 and self._logs()["m"] >= 6
+        return self.supports_fused_subgrid(dtype) and self._logs()["yN"] in (14, 15, 16) and self._logs()["m"] >= 6
 
     def band_for_offsets(self, subgrid_offs):
         """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains

@@ -44,13 +44,22 @@ def _torch():
 
 
 class FacetSharding:
-    """Who owns what.  Facet ``j`` lives on rank ``j % world``; subgrid number
-    ``i`` of a wave is finished (forward) / held (backward) on rank ``i % world``."""
+    """Who owns what.  Facet ``j`` lives on rank ``j % world``.  The subgrids of
+    a wave are finished (forward) / held (backward) round-robin by the ranks
+    with the FEWEST facets: when the facet count does not divide by the world
+    size (the catalogue's 3x3 facets on 8 GPUs) the ranks that carry an extra
+    facet already have the longest facet-side critical path, so they take no
+    subgrid-side work (``balance=False``: every rank takes subgrids)."""
 
-    def __init__(self, n_facets, rank, world):
+    def __init__(self, n_facets, rank, world, balance=True):
         self.n_facets, self.rank, self.world = n_facets, rank, world
         self.facets_of = [[j for j in range(n_facets) if j % world == r] for r in range(world)]
         self.local_facets = self.facets_of[rank]
+        counts = [len(f) for f in self.facets_of]
+        if balance and min(counts) < max(counts):
+            self.subgrid_ranks = [r for r in range(world) if counts[r] == min(counts)]
+        else:
+            self.subgrid_ranks = list(range(world))
         # facet order after concatenating received blocks in source-rank order (= owner-major order)
         self.arrival_order = [j for r in range(world) for j in self.facets_of[r]]
         self.to_global = numpy.argsort(self.arrival_order)  # arrival position of global facet j
@@ -58,7 +67,9 @@ class FacetSharding:
     def subgrids_of(self, n_subgrids, rank=None):
         """indices (within the wave) of the subgrids of ``rank``"""
         rank = self.rank if rank is None else rank
-        return list(range(rank, n_subgrids, self.world))
+        if rank not in self.subgrid_ranks:
+            return []
+        return list(range(self.subgrid_ranks.index(rank), n_subgrids, len(self.subgrid_ranks)))
 
 
 class _Pending:

@@ -108,8 +108,14 @@ def test_sharding_bookkeeping():
     assert sh.local_facets == [1, 5]
     assert sh.arrival_order == [0, 4, 8, 1, 5, 2, 6, 3, 7]
     assert [sh.arrival_order[p] for p in sh.to_global] == list(range(9))
-    assert sh.subgrids_of(10) == [1, 5, 9]
-    assert sh.subgrids_of(10, 3) == [3, 7]
+    # ranks 1..3 carry 2 facets, rank 0 carries 3: rank 0 takes no subgrids
+    assert sh.subgrid_ranks == [1, 2, 3]
+    assert sh.subgrids_of(10) == [0, 3, 6, 9]
+    assert sh.subgrids_of(10, 3) == [2, 5, 8]
+    assert sh.subgrids_of(10, 0) == []
+    flat = FacetSharding(9, 1, 4, balance=False)
+    assert flat.subgrids_of(10) == [1, 5, 9] and flat.subgrids_of(10, 3) == [3, 7]
+    assert FacetSharding(8, 5, 8).subgrids_of(20) == [5, 13]  # even split: plain round-robin
     one = FacetSharding(3, 0, 1)
     t = torch.zeros((3, 2, 4, 4))
     assert exchange_contributions(t, one) is t
@@ -200,7 +206,7 @@ def test_copy_free_layouts_forward_backward(world):
 
 
 def test_layout_counts():
-    sh = FacetSharding(9, 2, 4)  # local facets [2, 6]
+    sh = FacetSharding(9, 2, 4, balance=False)  # local facets [2, 6]
     dests, inc, outc = forward_layout(sh, 10, 5)
     assert dests == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
     assert inc == [2 * 3 * 5, 2 * 3 * 5, 2 * 2 * 5, 2 * 2 * 5]

@@ -1,0 +1,92 @@
+"""
+GPU parity at the sizes of the other BASELINE.json configurations and for sparse FACET lists (rows g1, f2),
+complex64, against the separable oracle (oracle/separable.py) on a few facets / subgrids each:
+
+  * config 3 parameters (W=11, N=32768, yB=4096, yN=8192, xA=2048, xM=4096 -> m=1024): the sizes without fused
+    kernels (m > 512, xM = 4096) take the general launch sequence;
+  * config 5, catalogue 128k[1]-n64k-1k (N=131072, yB=45056, yN=65536, xM=1024, m=512): yN = 65536 runs through the
+    contiguous-axis-first pipeline (band row kernel at 2 x 32768 points, 256 x 256 column passes);
+  * a sparse facet list (scripts/demo_sparse_facet.py:34-134 style: only the facets that intersect a region) on the
+    fused path: facets that do not form an off0 x off1 grid.
+"""
+import numpy
+import pytest
+
+import bench
+from oracle import separable as sep
+from oracle import swiftly_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def relrms(a, b):
+    return float(numpy.sqrt(numpy.mean(numpy.abs(a - b) ** 2) / numpy.mean(numpy.abs(b) ** 2)))
+
+
+def _run(P, facet_cfgs, sg_cfgs, wave_axis, tol, plan=True, seed=900):
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+
+    cfg = sw.SwiftlyConfig(backend="hip", **P)
+    yB = P["yB_size"]
+    vectors = [sep.facet_vectors(seed + j, yB, rank=2) for j in range(len(facet_cfgs))]
+    facets = [bench.separable_facet(torch, vectors[j], c) for j, c in enumerate(facet_cfgs)]
+    if wave_axis is None:
+        wave_axis = sw.api.preferred_wave_axis(cfg, torch.complex64)
+    key = (lambda c: c.off1) if wave_axis == 1 else (lambda c: c.off0)
+    ordered = sorted(sg_cfgs, key=lambda c: (key(c), c.off0, c.off1))
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs if plan else None,
+                            wave_axis=wave_axis)
+    got = [t.cpu().numpy() for t in fwd.get_subgrid_tasks(ordered)]
+    ref = orc.OracleCore(P["W"], P["N"], P["xM_size"], P["yN_size"])
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    so = sep.SeparableOracle(ref, items, vectors)
+    errs = []
+    for g, c in zip(got, ordered):
+        w = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1))
+        assert g.dtype == numpy.complex64 and g.shape == w.shape
+        errs.append(relrms(g, w))
+    print(f"N={P['N']} wave_axis={wave_axis}: relRMSE {['%.2e' % e for e in errs]}")
+    assert max(errs) < tol, errs
+    return wave_axis
+
+
+def test_config3_sizes_m1024_xM4096():
+    import ska_sdp_exec_swiftly_amd as sw
+
+    P = dict(W=11.0, fov=1.0, N=32768, yB_size=4096, yN_size=8192, xA_size=2048, xM_size=4096)
+    cover = sw.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
+    facet_cfgs = [c for c in cover if (c.off0, c.off1) in ((0, 0), (4096, 4096 * 7))]
+    sgs = sw.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
+    sg_cfgs = [c for c in sgs if (c.off0 // 2048, c.off1 // 2048) in ((0, 0), (0, 15), (3, 2))]
+    _run(P, facet_cfgs, sg_cfgs, 0, 2e-5, plan=False)
+
+
+def test_config5_sizes_yN65536():
+    import ska_sdp_exec_swiftly_amd as sw
+
+    P = dict(W=10.875, fov=1.0, N=131072, yB_size=45056, yN_size=65536, xA_size=928, xM_size=1024)
+    cover = sw.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
+    facet_cfgs = [c for c in cover if (c.off0, c.off1) in ((0, 45056), (90112, 0))]
+    sgs = sw.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
+    want = ((0, 0), (1, 0), (140, 3), (7, 141))
+    sg_cfgs = [c for c in sgs if (c.off0 // 928, c.off1 // 928) in want]
+    assert len(sg_cfgs) == len(want)
+    axis = _run(P, facet_cfgs, sg_cfgs, None, 2e-5)
+    assert axis == 1  # the yN = 65536 kernels exist only in the contiguous-axis-first pipeline
+
+
+@pytest.mark.parametrize("wave_axis", [0, 1])
+def test_sparse_facet_list_on_fused_path(wave_axis):
+    """Five of the nine facets of the 64k configuration (a plus shape: no off0 x off1 grid) with small-ish data
+    (yB = 1024 keeps the test cheap; yN = 32768 so that both pipelines exist)."""
+    import ska_sdp_exec_swiftly_amd as sw
+
+    yB = 1024
+    P = dict(W=10.875, fov=1.0, N=65536, yB_size=yB, yN_size=32768, xA_size=928, xM_size=1024)
+    offs = [(0, 0), (0, 22528), (22528, 0), (0, 45056), (45056, 0)]
+    rng = numpy.random.default_rng(3)
+    facet_cfgs = [sw.FacetConfig(o0, o1, yB, (rng.random(yB) > 0.05).astype(float), None) for o0, o1 in offs]
+    sg_cfgs = [sw.SubgridConfig(i0 * 928, i1 * 928, 928) for i0, i1 in ((0, 0), (0, 2), (3, 0), (3, 2), (70, 2))]
+    _run(P, facet_cfgs, sg_cfgs, wave_axis, 2e-5)
