@@ -5,6 +5,7 @@ HIP kernels behind the reference's own API.
 
 Public interface mirrors reference src/ska_sdp_exec_swiftly/__init__.py:4-35.
 """
+from . import api  # noqa: F401  (submodule access: sw.api.preferred_wave_axis, ...)
 from .api import (
     FacetConfig,
     SubgridConfig,

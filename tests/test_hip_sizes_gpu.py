@@ -56,9 +56,9 @@ def test_config3_sizes_m1024_xM4096():
     import ska_sdp_exec_swiftly_amd as sw
 
     P = dict(W=11.0, fov=1.0, N=32768, yB_size=4096, yN_size=8192, xA_size=2048, xM_size=4096)
-    cover = sw.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
+    cover = sw.api.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
     facet_cfgs = [c for c in cover if (c.off0, c.off1) in ((0, 0), (4096, 4096 * 7))]
-    sgs = sw.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
+    sgs = sw.api.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
     sg_cfgs = [c for c in sgs if (c.off0 // 2048, c.off1 // 2048) in ((0, 0), (0, 15), (3, 2))]
     _run(P, facet_cfgs, sg_cfgs, 0, 2e-5, plan=False)
 
@@ -67,9 +67,9 @@ def test_config5_sizes_yN65536():
     import ska_sdp_exec_swiftly_amd as sw
 
     P = dict(W=10.875, fov=1.0, N=131072, yB_size=45056, yN_size=65536, xA_size=928, xM_size=1024)
-    cover = sw.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
+    cover = sw.api.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
     facet_cfgs = [c for c in cover if (c.off0, c.off1) in ((0, 45056), (90112, 0))]
-    sgs = sw.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
+    sgs = sw.api.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
     want = ((0, 0), (1, 0), (140, 3), (7, 141))
     sg_cfgs = [c for c in sgs if (c.off0 // 928, c.off1 // 928) in want]
     assert len(sg_cfgs) == len(want)
