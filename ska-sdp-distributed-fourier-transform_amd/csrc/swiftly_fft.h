@@ -47,6 +47,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef SWF_PACKED_CMUL
 #define SWF_PACKED_CMUL 0
 #endif
+// packed complex add / subtract (one v_pk_add_f32 per complex operation): A/B switch
+#ifndef SWF_PACKED_ADD
+#define SWF_PACKED_ADD 0
+#endif
+#if SWF_PACKED_ADD
+__device__ __forceinline__ cx<float> operator+(cx<float> a, cx<float> b) {
+    const f32x2 r = f32x2{a.x, a.y} + f32x2{b.x, b.y};
+    return {r.x, r.y};
+}
+__device__ __forceinline__ cx<float> operator-(cx<float> a, cx<float> b) {
+    const f32x2 r = f32x2{a.x, a.y} - f32x2{b.x, b.y};
+    return {r.x, r.y};
+}
+#endif
 #if SWF_PACKED_CMUL
 template <>
 __device__ __forceinline__ cx<float> cmul<float>(cx<float> a, cx<float> b) {
