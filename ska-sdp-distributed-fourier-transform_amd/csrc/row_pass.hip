@@ -77,15 +77,17 @@ template <class G>
 static int launch_band_geo(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
     const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
     const bool band = a.band_len > 0;
-#define SWF_LAUNCH_BAND(WIN, BAND)                                                                                  \
-    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, BAND>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, \
+#define SWF_LAUNCH_BAND(WIN, ST)                                                                                  \
+    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, \
                        a.out, a.ld_win, tw14, tw_full)
-    if (a.ld_win) {
-        if (band) SWF_LAUNCH_BAND(true, true);
-        else SWF_LAUNCH_BAND(true, false);
+    if (a.band_len < 0) {  // mapped (crop + window) store: finish_* primitives
+        SWF_LAUNCH_BAND(false, 2);
+    } else if (a.ld_win) {
+        if (band) SWF_LAUNCH_BAND(true, 1);
+        else SWF_LAUNCH_BAND(true, 0);
     } else {
-        if (band) SWF_LAUNCH_BAND(false, true);
-        else SWF_LAUNCH_BAND(false, false);
+        if (band) SWF_LAUNCH_BAND(false, 1);
+        else SWF_LAUNCH_BAND(false, 0);
     }
 #undef SWF_LAUNCH_BAND
     return (int)hipGetLastError();
@@ -111,21 +113,22 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
 }
 int row_pass_band_occupancy() {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_band_kernel<BandGeo5, true, true>, BandGeo5::NT,
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_band_kernel<BandGeo5, true, 1>, BandGeo5::NT,
                                                        BandGeo5::LDS_BYTES);
     return n;
 }
-template <class G, bool WIN, bool BAND>
+template <class G, bool WIN, int ST>
 static int init_band() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, BAND>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 template <class G>
 static int init_band_geo() {
-    int rc = init_band<G, true, true>();
-    if (!rc) rc = init_band<G, true, false>();
-    if (!rc) rc = init_band<G, false, true>();
-    if (!rc) rc = init_band<G, false, false>();
+    int rc = init_band<G, true, 1>();
+    if (!rc) rc = init_band<G, true, 0>();
+    if (!rc) rc = init_band<G, false, 1>();
+    if (!rc) rc = init_band<G, false, 0>();
+    if (!rc) rc = init_band<G, false, 2>();
     return rc;
 }
 // occupancy query (blocks per CU) for tuning / DESIGN.md

@@ -521,7 +521,7 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     static const bool disabled = getenv("SWIFTLY_NO_ROWPASS") != nullptr;
     if (disabled) return false;
     if (a.rowfast || a.in_cs != 1 || a.out_cs != 1 || tab.use != 0 || (a.nbatch > 1)) return false;
-    if (logn < kRowPassMinLog || logn > kRowPassMaxLog) return false;
+    if (logn < kRowPassMinLog || logn > kRowPassMaxLog + 1) return false;
     if (a.ld.win2 || a.st_win_bs != 0) return false;
     const int n = 1 << logn;
     const bool ident_ld = a.ld.a == 0 && a.ld.len == n && a.ld.c == 0 && !a.ld.win;
@@ -541,13 +541,15 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     r.scale = a.scale; r.conj_ld = a.conj_ld; r.conj_st = a.conj_st; r.accumulate = a.accumulate;
     const int mode = ident_st ? 0 : (ident_ld ? 1 : 2);
     static const bool no_half = getenv("SWIFTLY_NO_HALF") != nullptr;
+    // default for N = 32768: the r2 kernel (all loads of a lane in flight, buffer accesses); SWIFTLY_K2_SPLIT
+    // selects the r1 multi-workgroup kernels for A/B runs
+    static const bool legacy = getenv("SWIFTLY_K2_SPLIT") != nullptr;
+    const bool prep_ld = r.ld_c == 0 && r.ld_mod == r.ld_len;    // load map of a prepare_* primitive (or identity)
+    const bool fin_st = r.st_c == 0 && r.st_mod == r.st_len;     // store map of a finish_* primitive
     if (logn == 15 && mode == 0 && !a.accumulate && !no_half) {
         const cx<float>* tw14 = twiddles<float>(h, 14);
         const cx<float>* tw13 = twiddles<float>(h, 13);
-        // default: the r2 kernel (all loads of a lane in flight, global-address-space accesses); SWIFTLY_K2_SPLIT
-        // selects the r1 multi-workgroup kernels for A/B runs
-        static const bool legacy = getenv("SWIFTLY_K2_SPLIT") != nullptr;
-        if (tw14 && !legacy && r.ld_c == 0 && r.ld_mod == r.ld_len) {  // load map of a prepare_* primitive
+        if (tw14 && !legacy && prep_ld) {
             int e2 = launch_row_pass_band(r, tw14, r.tw, st);
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
             return true;
@@ -557,6 +559,24 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
             return true;
         }
+    }
+    if (logn == 15 && mode == 1 && fin_st && !legacy && !no_half) {  // finish_* along the contiguous axis
+        const cx<float>* tw14 = twiddles<float>(h, 14);
+        if (tw14) {
+            r.band_len = -1;  // selects the mapped-store variant
+            int e2 = launch_row_pass_band(r, tw14, r.tw, st);
+            *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
+            return true;
+        }
+    }
+    if (logn == 16) {  // 65536-point rows: only the two-workgroup kernel exists (prepare_* loads / finish_* stores)
+        const cx<float>* tw15 = twiddles<float>(h, 15);
+        const bool ok0 = mode == 0 && prep_ld && !a.accumulate, ok1 = mode == 1 && fin_st;
+        if (!tw15 || !(ok0 || ok1)) return false;
+        if (ok1) r.band_len = -1;
+        int e2 = launch_row_pass_band_n(16, r, tw15, r.tw, st);
+        *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
+        return true;
     }
     int e = launch_row_pass(logn, mode, r, st);
     *rc_out = e ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e)) : 0;
@@ -584,6 +604,9 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
         if (try_col_pass(h, logn, a, tab, st, &rc)) return rc;
         if (try_row_pass(h, logn, a, tab, st, &rc)) return rc;
     }
+    if (logn > kMaxLogNFloat && sizeof(R) == 4)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "transform length 65536 is only supported for complex64 prepare_* / finish_* "
+                    "calls with unit stride along the transform axis or along a strided axis of contiguous rows");
     if (!(a.rowfast && logn >= kTwoPassMinLog)) return launch_checked(logn, a, tab, st);
 
     // ---- four-step: N = n1 * n2, input index y = y1*n2 + y2, output index k = k1 + n1*k2
@@ -647,7 +670,7 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
 template <typename R, class Fill>
 static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, const Batch& bt, int use_bits, Fill&& fill,
                     hipStream_t st) {
-    constexpr int maxlog = sizeof(R) == 8 ? kMaxLogNDouble : kMaxLogNFloat;
+    constexpr int maxlog = sizeof(R) == 8 ? kMaxLogNDouble : kMaxLogNFloat + 1;  // 2^16: lean complex64 kernels only
     if (logn < kMinLogN || logn > maxlog)
         return fail(SWIFTLY_ERR_UNSUPPORTED,
                     "transform length %s is not supported by the HIP backend (power of two in [8, %d] required for %s)",

@@ -309,7 +309,9 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // table load per point, so ALL loads of a lane are in flight together (r1: "L L wait L wait" per point --
 // 59 % of wave cycles waiting): the inter-half twiddle W_N^j, j = t + T v, is W_N^t (ONE table load) times
 // the compile-time constant W_64^(v 64 T / N).
-template <class G, bool HAS_WIN, bool BAND>
+// ST: 0 = plain row store, 1 = band store (parity-split), 2 = mapped store of a finish_* primitive (shift, crop to
+// st_len, windows st_win * st_win2; st_c = 0, st_mod = st_len host-checked) -- finish_facet along the contiguous axis.
+template <class G, bool HAS_WIN, int ST>
 __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                  cx<float>* __restrict__ gout,
                                                                  const float* __restrict__ ld_win,
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
                                                                  const cx<float>* __restrict__ tw_full) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = G::P, T = G::T, H = G::N, N = 2 * G::N;
+    constexpr bool BAND = ST == 1;
     static_assert(64 % (N / T) == 0, "the inter-half twiddle uses W_64 constants: j = t + T v, W_N^(T v) = W_64^(v 64 T / N)");
     constexpr int WSTEP = 64 / (N / T);
     const int t = threadIdx.x;
@@ -419,6 +422,28 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     const unsigned out_bytes = (unsigned)(BAND ? 2 * A.band_half : N) << 3;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb, (short)0, (int)out_bytes, 0x00020000);
 #endif
+    if constexpr (ST == 2) {
+        const unsigned vlen = (unsigned)A.st_len;
+        const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.st_win), (short)0, (int)(A.st_win ? vlen << 2 : 0u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.st_win2), (short)0, (int)(A.st_win2 ? vlen << 2 : 0u), 0x00020000);
+        const bool has1 = A.st_win != nullptr, has2 = A.st_win2 != nullptr;  // uniform
+        fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
+            const int ck = (2 * e + h) ^ (N >> 1);
+            const int d = (ck + A.st_a) & (N - 1);
+            float w = scale;
+            if (has1) w *= __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w1, d << 2, 0, 0));
+            if (has2) w *= __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w2, d << 2, 0, 0));
+            if (d < A.st_len) {
+                f32x2 val = {v.x * w, v.y * w * sg_st};
+                if (A.accumulate) {
+                    const f32x2 old = *reinterpret_cast<const f32x2*>(outb + ((unsigned)d << 3));
+                    val += old;
+                }
+                *reinterpret_cast<f32x2*>(outb + ((unsigned)d << 3)) = val;
+            }
+        });
+        return;
+    }
     fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
         const int ck = (2 * e + h) ^ (N >> 1);
         const f32x2 val = {v.x * scale, v.y * scale_im};

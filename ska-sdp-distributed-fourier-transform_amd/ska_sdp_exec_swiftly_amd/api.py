@@ -352,6 +352,95 @@ def _mask_table(core, configs, which, size, cdtype):
     return hit[1]
 
 
+class _FacetIngest:
+    """Host -> device facet upload overlapped with compute.
+
+    Device tensors are used in place.  Host (numpy) facets are uploaded LAZILY on a separate HIP stream in slabs of
+    ``SLAB`` bytes through two pinned staging buffers (pageable memory cannot be copied asynchronously, and pinning
+    a whole 4 GB facet would cost more than the copy): ``ready(j)`` makes the CURRENT stream wait for facet ``j``
+    (a stream-side wait) and returns the tensor; ``prefetch(j)`` starts the upload of facet ``j`` -- the streaming
+    classes call it for facet j+1 right after queueing the full-facet transform of facet j, so the transfer runs
+    under that kernel."""
+
+    SLAB = 128 << 20
+
+    def __init__(self, core):
+        self.core = core
+        self.host, self.tensors, self.events = [], [], []
+        self._stream = None
+        self._staging = None
+        self._staging_free = None
+
+    def add(self, data):
+        """register a facet; returns (dtype, shape, is_row_major)"""
+        torch = _torch()
+        if isinstance(data, torch.Tensor):
+            ten, _ = self.core._as_device(data)  # pylint: disable=protected-access
+            self.host.append(None)
+            self.tensors.append(ten)
+        else:
+            arr = numpy.asarray(data)
+            if not numpy.iscomplexobj(arr):
+                arr = arr.astype(numpy.complex64 if arr.dtype == numpy.float32 else numpy.complex128)
+            elif arr.dtype not in (numpy.complex64, numpy.complex128):
+                arr = arr.astype(numpy.complex128)
+            self.host.append(numpy.ascontiguousarray(arr))
+            self.tensors.append(None)
+        self.events.append(None)
+        j = len(self.tensors) - 1
+        src = self.tensors[j] if self.tensors[j] is not None else self.host[j]
+        tdt = src.dtype if self.tensors[j] is not None else (
+            torch.complex64 if src.dtype == numpy.complex64 else torch.complex128
+        )
+        row_major = src.stride(-1) == 1 if self.tensors[j] is not None else True
+        return tdt, tuple(src.shape), row_major
+
+    def prefetch(self, j):
+        """start the upload of facet ``j`` (no-op for device facets / out of range / already started)"""
+        torch = _torch()
+        if j < 0 or j >= len(self.tensors) or self.tensors[j] is not None:
+            return
+        core = self.core
+        arr = self.host[j]
+        tdt = torch.complex64 if arr.dtype == numpy.complex64 else torch.complex128
+        dev = torch.empty(arr.shape, dtype=tdt, device=core.device)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=core.device)
+            self._staging = [torch.empty(self.SLAB, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self._staging_free = [None, None]
+        src = torch.from_numpy(arr.reshape(-1).view(numpy.uint8))
+        dst = dev.reshape(-1).view(torch.uint8)
+        nbytes = src.numel()
+        # the new tensor's memory may still be in use by work queued on the current stream (caching allocator)
+        self._stream.wait_stream(torch.cuda.current_stream(core.device))
+        with torch.cuda.stream(self._stream):
+            for k, pos in enumerate(range(0, nbytes, self.SLAB)):
+                n = min(self.SLAB, nbytes - pos)
+                slot = k % 2
+                if self._staging_free[slot] is not None:
+                    self._staging_free[slot].synchronize()  # staging slot still in flight
+                self._staging[slot][:n].copy_(src[pos : pos + n])  # host memcpy into pinned memory
+                dst[pos : pos + n].copy_(self._staging[slot][:n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+                self._staging_free[slot] = ev
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        dev.record_stream(self._stream)
+        self.tensors[j] = dev
+        self.events[j] = done
+        self.host[j] = None
+
+    def ready(self, j):
+        """facet ``j`` on the device with the current stream ordered behind its upload"""
+        self.prefetch(j)
+        ev = self.events[j]
+        if ev is not None:
+            _torch().cuda.current_stream(self.core.device).wait_event(ev)
+            self.events[j] = None
+        return self.tensors[j]
+
+
 class SwiftlyForward:
     """Facet -> subgrid streaming transform (reference api.py:217-324).
 
@@ -398,11 +487,14 @@ class SwiftlyForward:
         self.BF_Fs_persist = None
         self._prewindowed = False
         torch = _torch()
-        self._facets = []
-        for _, data in facet_tasks:
-            ten, _ = self.core._as_device(data)  # pylint: disable=protected-access
-            self._facets.append(ten)
-        dtypes = {t.dtype for t in self._facets}
+        # facet ingestion (host <-> device edge): device tensors are used in place; host (numpy) facets are
+        # uploaded on a dedicated copy stream through a small ring of pinned staging buffers, and the compute
+        # stream waits per facet only when a kernel first needs it -- the PCIe transfer of facet j+1 overlaps
+        # the full-facet transform of facet j
+        self._ingest = _FacetIngest(self.core)
+        self._facet_info = [self._ingest.add(data) for _, data in facet_tasks]
+        self._ingest.prefetch(0)
+        dtypes = {info[0] for info in self._facet_info}
         if len(dtypes) > 1:
             raise ValueError("all facets must have the same dtype")
         self.dtype = dtypes.pop() if dtypes else torch.complex64
@@ -412,7 +504,7 @@ class SwiftlyForward:
         """BF_F of facet ``j`` as the streaming classes keep it: (optionally) row-compacted and with the
         axis-1 window of extract_column already applied (it commutes with the axis-0 transform), so the
         column kernel has no window loads; complex128 and unsupported sizes use the plain primitive."""
-        cfg, data = self.facet_configs[j], self._facets[j]
+        cfg, data = self.facet_configs[j], self._ingest.ready(j)
         n_rows = self._n_rows if self._rowmap is not None else self.core.yN_size
         if self._prewindowed or self._rowmap is not None:
             return self.core.prepare_facet_rows(
@@ -431,6 +523,7 @@ class SwiftlyForward:
             for j in range(len(self.facet_configs)):
                 t0 = timer.start() if timer is not None else None
                 out.append(self._prepare_one_facet(j))
+                self._ingest.prefetch(j + 1)
                 if timer is not None:
                     timer.stop("K1_full_facet_transform", t0)
             self.BF_Fs_persist = out
@@ -581,8 +674,8 @@ class SwiftlyForward:
         torch = _torch()
         if not self.core.supports_band_pipeline(self.dtype):
             raise ValueError("wave_axis=1 is not available for this configuration / dtype (see preferred_wave_axis)")
-        sizes = {tuple(t.shape) for t in self._facets}
-        if len(sizes) != 1 or any(t.stride(1) != 1 for t in self._facets) or self.dtype != torch.complex64:
+        sizes = {info[1] for info in self._facet_info}
+        if len(sizes) != 1 or not all(info[2] for info in self._facet_info) or self.dtype != torch.complex64:
             raise ValueError("wave_axis=1 needs equally sized row-major complex64 facets")
 
     def _prepare_all_bands(self, timer=None):
@@ -595,11 +688,13 @@ class SwiftlyForward:
             self._band = (
                 core.band_for_offsets([sg.off1 for sg in self._plan]) if self._plan is not None else (0, core.yN_size)
             )
-            F, yB = len(self._facets), self._facets[0].shape[0]
+            F, yB = len(self._facet_info), self._facet_info[0][1][0]
             bands = torch.empty((F, yB, core.band_columns(self._band)), dtype=self.dtype, device=core.device)
-            for j, (cfg, data) in enumerate(zip(self.facet_configs, self._facets)):
+            for j, cfg in enumerate(self.facet_configs):
+                data = self._ingest.ready(j)
                 t0 = timer.start() if timer is not None else None
                 core.prepare_facet_band(data, cfg.off1, self._band, out=bands[j])
+                self._ingest.prefetch(j + 1)
                 if timer is not None:
                     timer.stop("K1_full_facet_transform", t0)
             self.BF_Fs_persist = bands

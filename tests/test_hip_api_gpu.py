@@ -75,6 +75,11 @@ def test_forward_backward_golden(golden_dir, gfile, params, seed, dtype, ftol, b
     for sg_cfg, data in zip(sg_cfgs, sgs):
         bwd.add_new_subgrid_task(sg_cfg, data)
     out = numpy.array([f.cpu().numpy() for f in bwd.finish()])
+    # wave-batched form (all subgrids at once, grouped by off0 internally) gives the same facets
+    bwd2 = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, queue_size=2)
+    bwd2.add_new_subgrid_tasks(sg_cfgs, sgs)
+    out2 = numpy.array([f.cpu().numpy() for f in bwd2.finish()])
+    assert relrms(out2, out) < (1e-12 if dtype == numpy.complex128 else 3e-6)
     e3 = relrms(out[:, ::9, ::7], g["facets_out_sample"])
     e4 = relrms(out[g["facet_full_idx"]], g["facets_out_full"])
     print(f"backward relRMSE {dtype.__name__}: sample {e3:.3e} full {e4:.3e}")

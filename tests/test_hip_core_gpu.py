@@ -321,3 +321,43 @@ def test_backward_long_rows_yN32768_c64():
     m = core.xM_yN_size
     c = (rng.standard_normal((5, m)) + 1j * rng.standard_normal((5, m))).astype(numpy.complex64)
     assert numpy.array_equal(core.add_to_facet(c, 928 * 7, axis=1), ref.add_to_facet(c, 928 * 7, 1))
+
+
+def test_long_rows_yN65536_c64():
+    """yN = 65536 (catalogue 128k[1]-n64k-1k): prepare_facet / finish_facet along the contiguous axis (two workgroups per
+    row at 2 x 32768 points) and along the strided axis (256 x 256 column passes), extract_column, add_to_facet."""
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    W, N, xM, yN, yB = 10.875, 131072, 1024, 65536, 45056
+    core = SwiftlyCoreHip(W, N, xM, yN)
+    ref = orc.OracleCore(W, N, xM, yN)
+    rng = numpy.random.default_rng(13)
+    rows = (rng.standard_normal((3, yB)) + 1j * rng.standard_normal((3, yB))).astype(numpy.complex64)
+    for off in (0, 128 * 352, -128 * 300):
+        got = core.prepare_facet(rows, off, axis=1)
+        want = ref.prepare_facet(rows.astype(complex), off, 1)
+        rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+        assert got.dtype == numpy.complex64 and got.shape == (3, yN) and rel < 2e-6, rel
+    acc = (rng.standard_normal((3, yN)) + 1j * rng.standard_normal((3, yN))).astype(numpy.complex64)
+    mask = (rng.random(yB) > 0.3).astype(float)
+    for off in (0, 45056, -40960):
+        got = core.finish_facet(acc, off, yB, axis=1, mask=mask)
+        want = ref.finish_facet(acc.astype(complex), off, yB, 1) * mask[None, :]
+        rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+        assert got.shape == (3, yB) and rel < 3e-6, rel
+    # strided axis
+    cols = numpy.ascontiguousarray(rows.T)  # [yB, 3]
+    got = core.prepare_facet(cols, 128 * 352, axis=0)
+    want = ref.prepare_facet(cols.astype(complex), 128 * 352, 0)
+    assert numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2)) < 2e-6
+    accT = numpy.ascontiguousarray(acc.T)  # [yN, 3]
+    got = core.finish_facet(accT, 45056, yB, axis=0)
+    want = ref.finish_facet(accT.astype(complex), 45056, yB, 0)
+    assert got.shape == (yB, 3)
+    assert numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2)) < 3e-6
+    m = core.xM_yN_size
+    c = (rng.standard_normal((5, m)) + 1j * rng.standard_normal((5, m))).astype(numpy.complex64)
+    assert numpy.array_equal(core.add_to_facet(c, 928 * 7, axis=1), ref.add_to_facet(c, 928 * 7, 1))
+    # refused loudly where no 65536-point kernel exists (complex128)
+    with pytest.raises(NotImplementedError):
+        core.prepare_facet(rows.astype(complex), 0, axis=1)
