@@ -148,3 +148,63 @@ def test_extract_column_rowmap_on_strided_bf(dtype):
             assert got.shape == (m, yN)
             rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
             assert rel < tol, rel
+
+
+def test_integration_binding_host_staging():
+    """The reference-side binding of INTEGRATION.md section B, verbatim in spirit: numpy arrays staged through
+    swiftly_hip_malloc / memcpy, one ABI call per `ska_sdp_func`-style method (2-D arrays, last axis, `.T` views for
+    axis 0, accumulate ops read `out`), including prepare_subgrid_inplace[_2d] on pre-padded arrays."""
+    import ctypes
+
+    from ska_sdp_exec_swiftly_amd import _lib, calculate_pswf
+
+    lib = _lib.load()
+    W, N, xM, yN = P["W"], P["N"], P["xM_size"], P["yN_size"]
+    ref = orc.OracleCore(W, N, xM, yN)
+    h = ctypes.c_void_p()
+    pswf = numpy.ascontiguousarray(calculate_pswf(W, yN))
+    _lib.check(lib.swiftly_hip_create(ctypes.byref(h), N, yN, xM, float(W),
+                                      pswf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0))
+
+    def run(name, a, out, *tail):
+        dt = 0 if a.dtype == numpy.complex64 else 1
+        d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.swiftly_hip_malloc(ctypes.byref(d_in), a.size * a.itemsize))
+        _lib.check(lib.swiftly_hip_malloc(ctypes.byref(d_out), out.size * out.itemsize))
+        ac, oc = numpy.ascontiguousarray(a), numpy.ascontiguousarray(out)
+        lib.swiftly_hip_memcpy_h2d(d_in, ac.ctypes.data, ac.nbytes, None)
+        lib.swiftly_hip_memcpy_h2d(d_out, oc.ctypes.data, oc.nbytes, None)
+        args = [h, dt, d_in, a.shape[0]]
+        if name in ("prepare_facet", "prepare_subgrid"):
+            args.append(a.shape[1])
+        args += [a.shape[1], 1, d_out, out.shape[1], 1, *tail, None]
+        _lib.check(getattr(lib, "swiftly_hip_" + name)(*args))
+        lib.swiftly_hip_memcpy_d2h(oc.ctypes.data, d_out, oc.nbytes, None)
+        _lib.check(lib.swiftly_hip_stream_synchronize(None))
+        out[...] = oc
+        lib.swiftly_hip_free(d_in)
+        lib.swiftly_hip_free(d_out)
+
+    rng = numpy.random.default_rng(8)
+    yB, m, xA = P["yB_size"], ref.xM_yN_size, P["xA_size"]
+    facet = rng.standard_normal((5, yB)) + 1j * rng.standard_normal((5, yB))
+    out = numpy.empty((5, yN), dtype=complex)
+    run("prepare_facet", facet, out, 8)
+    want = ref.prepare_facet(facet, 8, axis=1)
+    assert numpy.abs(out - want).max() <= 1e-12 * numpy.abs(want).max()
+    # axis 0 as a .T view + accumulation into a pre-filled output
+    contrib = rng.standard_normal((m, 7)) + 1j * rng.standard_normal((m, 7))
+    acc = rng.standard_normal((xM, 7)) + 1j * rng.standard_normal((xM, 7))
+    want = acc + ref.add_to_subgrid(contrib, -12, axis=0)
+    run("add_to_subgrid", contrib.T, acc.T, -12)
+    assert numpy.abs(acc - want).max() <= 1e-12 * numpy.abs(want).max()
+    # prepare_subgrid_inplace_2d on an array that pad_mid has already padded (reference core.py:849-853)
+    sg = rng.standard_normal((xA, xA)) + 1j * rng.standard_normal((xA, xA))
+    padded = numpy.zeros((xM, xM), dtype=complex)
+    lo = xM // 2 - xA // 2
+    padded[lo : lo + xA, lo : lo + xA] = sg
+    run("prepare_subgrid", padded.copy(), padded, 6)           # axis 1
+    run("prepare_subgrid", padded.T.copy(), padded.T, -4)      # axis 0
+    want = ref.prepare_subgrid(sg, [-4, 6])
+    assert numpy.abs(padded - want).max() <= 1e-12 * numpy.abs(want).max()
+    lib.swiftly_hip_destroy(h)
