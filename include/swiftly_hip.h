@@ -29,7 +29,9 @@
  *  - return value 0 = success; non-zero = failure, message available from
  *    swiftly_hip_last_error() (thread local).  Nothing throws across the ABI.
  *    SWIFTLY_ERR_UNSUPPORTED is returned for transform lengths that are not
- *    a power of two in [8, 32768] (complex64) / [8, 8192] (complex128).
+ *    a power of two in [8, 32768] (complex64) / [8, 8192] (complex128);
+ *    65536 is supported in complex64 for prepare_* / finish_* along a
+ *    unit-stride axis and along the strided axis of contiguous rows.
  *  - a handle is immutable after creation and may be used concurrently from
  *    several host threads / streams (the reference scatters one core object
  *    to all Dask worker threads, api.py:145-147).  Handles may be created

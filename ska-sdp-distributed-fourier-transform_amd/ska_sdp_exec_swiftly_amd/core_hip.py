@@ -108,6 +108,7 @@ class SwiftlyCoreHip:
     # Pickle support like SwiftlyCoreFunc (core.py:512-525): only the four
     # parameters travel, the native handle is rebuilt on the receiving side.
     def __getstate__(self):
+        # no device pointers, no caches
         return {"W": self.W, "N": self.N, "xM_size": self.xM_size, "yN_size": self.yN_size}
 
     def __setstate__(self, state):
@@ -184,7 +185,19 @@ class SwiftlyCoreHip:
         torch = _torch()
         rdtype = torch.float32 if cdtype == torch.complex64 else torch.float64
         if not isinstance(vec, torch.Tensor):
-            vec = torch.from_numpy(numpy.ascontiguousarray(numpy.asarray(vec, dtype=float)))
+            host = numpy.ascontiguousarray(numpy.asarray(vec, dtype=float))
+            if host.size != size:
+                raise ValueError(f"Mask has {host.size} elements, expected {size}!")
+            # cached by content: a pageable upload is ordered behind all queued work (one bubble per call otherwise;
+            # the streaming classes pass the same few facet / subgrid masks over and over)
+            key = (str(rdtype), host.tobytes())
+            cache = self.__dict__.setdefault("_mask_cache", {})
+            hit = cache.get(key)
+            if hit is None:
+                if len(cache) >= 1024:
+                    cache.pop(next(iter(cache)))
+                hit = cache[key] = torch.from_numpy(host).to(device=self._device, dtype=rdtype).contiguous()
+            return hit
         vec = vec.to(device=self._device, dtype=rdtype).contiguous()
         if vec.numel() != size:
             raise ValueError(f"Mask has {vec.numel()} elements, expected {size}!")
@@ -363,13 +376,23 @@ class SwiftlyCoreHip:
         tensor [yN_size] with -1 for unused rows, number of rows kept)``."""
         torch = _torch()
         yN, m = self.yN_size, self.xM_yN_size
+        # cached per core: the upload is a pageable host-to-device copy, which is ordered behind everything already
+        # queued on the device (a pipeline bubble per wave if it were repeated every pass)
+        key = tuple(sorted(set(int(o) for o in subgrid_off0s)))
+        cache = self.__dict__.setdefault("_rowmap_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
         keep = numpy.zeros(yN, dtype=bool)
-        for off0 in set(int(o) for o in subgrid_off0s):
+        for off0 in key:
             s = off0 * yN // self.N
             keep[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN] = True
         rowmap = numpy.full(yN, -1, dtype=numpy.int32)
         rowmap[keep] = numpy.arange(int(keep.sum()), dtype=numpy.int32)
-        return torch.from_numpy(rowmap).to(self._device), int(keep.sum())
+        if len(cache) >= 4096:
+            cache.pop(next(iter(cache)))
+        cache[key] = (torch.from_numpy(rowmap).to(self._device), int(keep.sum()))
+        return cache[key]
 
     def prepare_facet_rows(self, facet, facet_off, rowmap, n_rows, out=None, fold_axis1_window=False):
         """``prepare_facet(facet, facet_off, axis=0)`` keeping only the rows
