@@ -210,11 +210,13 @@ def cpu_baseline(p, F, S, C):
     threaded), every process working on its own bounded sample concurrently (so
     memory-bandwidth contention between cores is in the numbers), extrapolated
     linearly by unit counts."""
+    import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
 
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    with ProcessPoolExecutor(cores) as pool:
+    # spawn: the parent holds an initialised HIP runtime, which must not be forked
+    with ProcessPoolExecutor(cores, mp_context=multiprocessing.get_context("spawn")) as pool:
         res = list(pool.map(_cpu_sample, [(p, F, 1000 + i) for i in range(cores)]))
     wall = time.perf_counter() - t0
     t_k1 = float(numpy.mean([r[0] for r in res]))
