@@ -194,12 +194,14 @@ class DistributedForward:
     agree; a rank without facets cannot infer it)."""
 
     def __init__(self, swiftly_config, facet_configs, facet_data, lru_forward=1, group=None, subgrid_configs=None,
-                 wave_axis=None, dtype=None):
+                 wave_axis=None, dtype=None, rank_world=None):
         from .api import SwiftlyForward, preferred_wave_axis  # pylint: disable=import-outside-toplevel
 
         torch = _torch()
         self.group = group
-        self.rank, self.world = _dist_info(group)
+        # rank_world=(rank, world) overrides the process group: "virtual ranks" of one process, used with
+        # pack_wave / unpack_wave and a caller-provided exchange (tests of the multi-rank layouts on one GPU)
+        self.rank, self.world = rank_world if rank_world is not None else _dist_info(group)
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facet_configs = list(facet_configs)
@@ -227,15 +229,13 @@ class DistributedForward:
         if self.sharding.local_facets:
             self.local.prepare_all_facets()
 
-    def start_wave(self, sgs):
-        """Compute this rank's blocks for the subgrids ``sgs`` (one wave: same wave key and size) and start
-        their all-to-all; returns a handle for :py:meth:`finish_wave`.  Starting wave w+1 before finishing
-        wave w overlaps the exchange (RCCL's stream) with the facet-side kernels (compute stream)."""
+    def pack_wave(self, sgs):
+        """Compute this rank's blocks for the subgrids ``sgs`` (one wave: same wave key and size) straight into
+        the send buffer ``[dest][local facet][subgrid of dest][m, m]``; returns ``(send, in_counts, out_counts)``."""
         torch = _torch()
         core = self.core
         m = core.xM_yN_size
-        S = len(sgs)
-        dests, in_counts, out_counts = forward_layout(self.sharding, S, m * m)
+        dests, in_counts, out_counts = forward_layout(self.sharding, len(sgs), m * m)
         F_local = len(self.sharding.local_facets)
         send = torch.empty(sum(in_counts), dtype=self.dtype, device=core.device)
         pos = 0
@@ -244,22 +244,32 @@ class DistributedForward:
                 block = send[pos : pos + cnt].view(F_local, len(d), m, m)
                 self.local.wave_blocks([sgs[i] for i in d], block, transformed=self.fused)
             pos += cnt
-        return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
+        return send, in_counts, out_counts
 
-    def finish_wave(self, handle):
-        """Finish the subgrids of a started wave that this rank owns: returns
-        ``(indices within sgs, tensor [S_local, xA, xA] or None)``."""
+    def unpack_wave(self, sgs, recv):
+        """Finish the subgrids of the wave that this rank owns from the flat receive buffer ``[source][facet of
+        source][my subgrid][m, m]``: returns ``(indices within sgs, tensor [S_local, xA, xA] or None)``."""
         from .api import finish_from_blocks  # pylint: disable=import-outside-toplevel
 
-        sgs, pending = handle
         mine = self.sharding.subgrids_of(len(sgs))
-        recv = pending.wait()
         if not mine:
             return mine, None
         m = self.core.xM_yN_size
         blocks = recv.view(len(self.facet_configs), len(mine), m, m)  # facets in arrival order
         res = finish_from_blocks(self.core, blocks, self.arrival_cfgs, [sgs[i] for i in mine], transformed=self.fused)
         return mine, res
+
+    def start_wave(self, sgs):
+        """:py:meth:`pack_wave` + start of the all-to-all; returns a handle for :py:meth:`finish_wave`.
+        Starting wave w+1 before finishing wave w overlaps the exchange (RCCL's stream) with the facet-side
+        kernels (compute stream)."""
+        send, in_counts, out_counts = self.pack_wave(sgs)
+        return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
+
+    def finish_wave(self, handle):
+        """Wait for the exchange of a started wave and :py:meth:`unpack_wave`."""
+        sgs, pending = handle
+        return self.unpack_wave(sgs, pending.wait())
 
     def get_subgrid_wave(self, sgs):
         """start_wave + finish_wave"""
@@ -275,11 +285,11 @@ class DistributedBackward:
     owners, who accumulate (api_helper.py:142-179) and finally finish their
     facets (api_helper.py:182-197)."""
 
-    def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None):
+    def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None, rank_world=None):
         from .api import SwiftlyBackward  # pylint: disable=import-outside-toplevel
 
         self.group = group
-        self.rank, self.world = _dist_info(group)
+        self.rank, self.world = rank_world if rank_world is not None else _dist_info(group)
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facet_configs = list(facet_configs)
@@ -293,10 +303,11 @@ class DistributedBackward:
             swiftly_config, [self.facet_configs[j] for j in self.sharding.arrival_order], lru_backward=1
         )
 
-    def start_wave(self, sgs, subgrids_mine):
+    def pack_wave(self, sgs, subgrids_mine):
         """``sgs``: all subgrid configs of the wave (same ``off0`` and size, identical on every rank);
         ``subgrids_mine``: data of the subgrids this rank holds, in the order of
-        ``sharding.subgrids_of(len(sgs))``.  Starts the exchange; returns a handle for :py:meth:`finish_wave`."""
+        ``sharding.subgrids_of(len(sgs))``.  Returns ``(send, in_counts, out_counts)``: the contributions of my
+        subgrids to all facets, owner-major, flat."""
         torch = _torch()
         core = self.core
         m = core.xM_yN_size
@@ -311,12 +322,11 @@ class DistributedBackward:
         else:
             dt = self.local.dtype or self.splitter.dtype or torch.complex64
             send = torch.empty(0, dtype=dt, device=core.device)
-        return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
+        return send, in_counts, out_counts
 
-    def finish_wave(self, handle):
-        """Accumulate the received contributions into this rank's facets."""
-        sgs, pending = handle
-        recv = pending.wait()
+    def unpack_wave(self, sgs, recv):
+        """Accumulate the received contributions (one chunk ``[my facet][subgrid of source][m, m]`` per source
+        rank) into this rank's facets."""
         F_local = len(self.sharding.local_facets)
         if not F_local:
             return
@@ -331,6 +341,16 @@ class DistributedBackward:
                 chunks.append(([sgs[i] for i in idx], recv[pos : pos + cnt].view(F_local, len(idx), m, m)))
             pos += cnt
         self.local.accumulate_chunks(sgs[0].off0, chunks)
+
+    def start_wave(self, sgs, subgrids_mine):
+        """:py:meth:`pack_wave` + start of the mirror all-to-all; returns a handle for :py:meth:`finish_wave`."""
+        send, in_counts, out_counts = self.pack_wave(sgs, subgrids_mine)
+        return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
+
+    def finish_wave(self, handle):
+        """Wait for the exchange and :py:meth:`unpack_wave`."""
+        sgs, pending = handle
+        self.unpack_wave(sgs, pending.wait())
 
     def add_wave(self, sgs, subgrids_mine):
         """start_wave + finish_wave"""

@@ -233,3 +233,66 @@ def test_distributed_classes_world1(params, dtype):
     assert idx == list(range(len(facet_cfgs)))
     for a, b in zip(got, ref):
         assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+
+
+def _virtual_all_to_all(sends, in_counts):
+    """In-process stand-in for all_to_all_single: rank r receives, from every source s in order, the chunk s sent
+    to r (``sends[s]`` flat buffers, ``in_counts[s][r]`` elements)."""
+    import torch
+
+    world = len(sends)
+    starts = [numpy.concatenate([[0], numpy.cumsum(c)]) for c in in_counts]
+    return [
+        torch.cat([sends[s][int(starts[s][r]) : int(starts[s][r + 1])] for s in range(world)]) for r in range(world)
+    ]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_distributed_virtual_ranks(world):
+    """The multi-rank layouts with REAL HIP kernels on one GPU: `world` virtual ranks in one process (facet sharding,
+    send buffers written in place per destination, arrival-order consumption, weighted subgrid ownership, the mirror
+    exchange of the backward pass), the all-to-all replaced by an in-process shuffle of the flat buffers.  Results
+    must equal the single-process classes."""
+    import torch
+
+    from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
+
+    sw, cfg, facet_cfgs, sg_cfgs, facets = small_problem(TEST_PARAMS, numpy.complex64, 31)
+    dev_facets = [torch.from_numpy(f).cuda() for f in facets]
+    ref_fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, dev_facets)), wave_axis=0)
+    ref_bwd = sw.SwiftlyBackward(cfg, facet_cfgs)
+    fwds = [
+        DistributedForward(cfg, facet_cfgs, dev_facets, dtype=torch.complex64, wave_axis=0, rank_world=(r, world))
+        for r in range(world)
+    ]
+    bwds = [DistributedBackward(cfg, facet_cfgs, rank_world=(r, world)) for r in range(world)]
+    assert sorted(j for f in fwds for j in f.sharding.local_facets) == list(range(len(facet_cfgs)))
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off0, []).append(c)
+    for wave in waves.values():
+        want = ref_fwd.get_wave(wave)
+        packed = [f.pack_wave(wave) for f in fwds]
+        recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+        got = {}
+        for r, f in enumerate(fwds):
+            assert recvs[r].numel() == sum(packed[r][2])  # out_counts
+            mine, res = f.unpack_wave(wave, recvs[r])
+            for k, i in enumerate(mine):
+                got[i] = res[k]
+        assert sorted(got) == list(range(len(wave)))
+        scale = float(want.abs().max())
+        for i in range(len(wave)):
+            assert float((got[i] - want[i]).abs().max()) <= 3e-6 * scale
+        # backward: every virtual rank sends the contributions of the subgrids it holds
+        ref_bwd.add_new_subgrid_tasks(wave, [want[i] for i in range(len(wave))])
+        packed = [b.pack_wave(wave, [want[i] for i in b.sharding.subgrids_of(len(wave))]) for b in bwds]
+        recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+        for r, b in enumerate(bwds):
+            assert recvs[r].numel() == sum(packed[r][2])
+            b.unpack_wave(wave, recvs[r])
+    ref = ref_bwd.finish()
+    for b in bwds:
+        idx, out = b.finish()
+        for j, o in zip(idx, out):
+            assert float((o - ref[j]).abs().max()) <= 3e-6 * float(ref[j].abs().max())
