@@ -257,9 +257,12 @@ def test_distributed_virtual_ranks(world):
 
     from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
 
-    sw, cfg, facet_cfgs, sg_cfgs, facets = small_problem(TEST_PARAMS, numpy.complex64, 31)
+    # W = 11 family (well conditioned in float32) with sizes that have the fused subgrid kernels (m = 128, xM = 256)
+    params = dict(W=11.0, fov=1.0, N=1024, yB_size=352, yN_size=512, xA_size=192, xM_size=256)
+    sw, cfg, facet_cfgs, sg_cfgs, facets = small_problem(params, numpy.complex64, 31)
     dev_facets = [torch.from_numpy(f).cuda() for f in facets]
     ref_fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, dev_facets)), wave_axis=0)
+    assert ref_fwd.supports_fused_subgrid_side()
     ref_bwd = sw.SwiftlyBackward(cfg, facet_cfgs)
     fwds = [
         DistributedForward(cfg, facet_cfgs, dev_facets, dtype=torch.complex64, wave_axis=0, rank_world=(r, world))
@@ -283,7 +286,8 @@ def test_distributed_virtual_ranks(world):
         assert sorted(got) == list(range(len(wave)))
         scale = float(want.abs().max())
         for i in range(len(wave)):
-            assert float((got[i] - want[i]).abs().max()) <= 3e-6 * scale
+            # same kernels, different facet summation order (arrival order): float32 rounding only
+            assert float((got[i] - want[i]).abs().max()) <= 2e-5 * scale
         # backward: every virtual rank sends the contributions of the subgrids it holds
         ref_bwd.add_new_subgrid_tasks(wave, [want[i] for i in range(len(wave))])
         packed = [b.pack_wave(wave, [want[i] for i in b.sharding.subgrids_of(len(wave))]) for b in bwds]
@@ -295,4 +299,4 @@ def test_distributed_virtual_ranks(world):
     for b in bwds:
         idx, out = b.finish()
         for j, o in zip(idx, out):
-            assert float((o - ref[j]).abs().max()) <= 3e-6 * float(ref[j].abs().max())
+            assert float((o - ref[j]).abs().max()) <= 2e-5 * float(ref[j].abs().max())
