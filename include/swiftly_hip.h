@@ -301,6 +301,31 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
                                   const int64_t* subgrid_off1s, int64_t subgrid_size, const void* mask,
                                   int64_t mask_batch_stride, int64_t nsub, void* stream);
 
+/* One forward wave as TWO native calls (per-wave host work = two ABI calls; what the streaming classes use):
+ *
+ * wave_facet_side: K2 (prepare_facet_columns into the workspace q_work[nfacets][n_rows][m]; skipped when
+ *   compute_q == 0 and q_work still holds the wave's result) followed by K3 + K4a (transform_contributions, layout 1)
+ *   for the subgrids sub_off0s[nsub] of the wave.  Block (f, b) is written at
+ *       g_out + g_offsets[b] + f * g_facet_strides[b]            when g_offsets != NULL
+ *       g_out + f * g_facet_stride + b * g_sub_stride             otherwise
+ *   (elements) -- the first form fills a rank-ordered all-to-all send buffer [dest][facet][subgrid of dest] in place.
+ * wave_subgrid_side: K4b + K5a (sum_finish_facets into tmp_work[nsub][xM][subgrid_size]) and K5b
+ *   (finish_subgrid along axis 0 with mask0) -> out[nsub][subgrid_size][subgrid_size] for the blocks g[f][b] of ALL
+ *   facets (facet order = order of facet_off0s / facet_off1s, e.g. arrival order of the exchange).
+ * Host arrays: facet / subgrid offsets, g_offsets, g_facet_strides.  masks: device, real, [nsub][subgrid_size] with
+ * batch strides (0 = shared), or NULL. */
+int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
+                                int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
+                                int64_t band_start, int64_t band_len, int64_t wave_off1, const int32_t* rowmap,
+                                int64_t n_rows, void* q_work, int compute_q, int64_t nsub, const int64_t* sub_off0s,
+                                void* g_out, int64_t g_facet_stride, int64_t g_sub_stride, const int64_t* g_offsets,
+                                const int64_t* g_facet_strides, void* stream);
+int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
+                                  int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
+                                  int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
+                                  const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
+                                  void* tmp_work, void* out, void* stream);
+
 /* -- device memory helpers for callers that do not bring their own allocator
  *    (the Python mirror uses torch for device memory and never calls these) -- */
 int swiftly_hip_malloc(void** ptr, size_t bytes);

@@ -1227,13 +1227,16 @@ int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* i
     return 0;
 }
 
-int swiftly_hip_transform_contributions(swiftly_hip_t* h, int dtype, const void* in, int layout, int64_t in_row_stride,
+} // extern "C" (helper follows)
+// out_offs / out_fstrides (optional, per subgrid): item (f, b) is written at out + out_offs[b] + f*out_fstrides[b]
+// instead of out + f*out_facet_stride + b*out_sub_stride
+static int transform_contributions_impl(swiftly_hip_t* h, int dtype, const void* in, int layout, int64_t in_row_stride,
                                         int64_t in_facet_stride, int64_t in_sub_stride, const int32_t* in_rowmap,
                                         int64_t band_start, int64_t band_len, int64_t nfacets,
                                         const int64_t* facet_off0s, int64_t nsub, const int64_t* subgrid_offs,
-                                        void* out, int64_t out_facet_stride, int64_t out_sub_stride, void* stream) {
+                                        void* out, int64_t out_facet_stride, int64_t out_sub_stride,
+                                        const int64_t* out_offs, const int64_t* out_fstrides, void* stream) {
     if (!h || !in || !out || !facet_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "transform_contributions: complex64 only");
     if (layout < 0 || layout > 2) return fail(SWIFTLY_ERR_PARAM, "bad layout %d", layout);
     if (layout != 2 && !subgrid_offs) return fail(SWIFTLY_ERR_PARAM, "null argument");
@@ -1288,10 +1291,31 @@ int swiftly_hip_transform_contributions(swiftly_hip_t* h, int dtype, const void*
             c.in_bdiv = nb; c.in_bs_hi = in_facet_stride; c.in_bs = layout == 2 ? in_sub_stride : 0;
             c.out = (cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
             c.out_bdiv = nb; c.out_bs_hi = out_facet_stride; c.out_bs = out_sub_stride;
+            if (out_offs) {
+                cz.flags |= kZOutB;
+                c.out = (cx<float>*)out;
+                for (int b = 0; b < nb; b++) {
+                    cz.b_out_fs[b] = out_fstrides[b0 + b];
+                    cz.b_out_off[b] = out_offs[b0 + b] + f0 * out_fstrides[b0 + b];
+                }
+            }
             if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, nf * nb, (hipStream_t)stream)) return rc;
         }
     }
     return 0;
+}
+
+extern "C" {
+int swiftly_hip_transform_contributions(swiftly_hip_t* h, int dtype, const void* in, int layout, int64_t in_row_stride,
+                                        int64_t in_facet_stride, int64_t in_sub_stride, const int32_t* in_rowmap,
+                                        int64_t band_start, int64_t band_len, int64_t nfacets,
+                                        const int64_t* facet_off0s, int64_t nsub, const int64_t* subgrid_offs,
+                                        void* out, int64_t out_facet_stride, int64_t out_sub_stride, void* stream) {
+    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    return transform_contributions_impl(h, dtype, in, layout, in_row_stride, in_facet_stride, in_sub_stride, in_rowmap,
+                                        band_start, band_len, nfacets, facet_off0s, nsub, subgrid_offs, out,
+                                        out_facet_stride, out_sub_stride, nullptr, nullptr, stream);
 }
 
 int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t nfacets, int64_t in_facet_stride,
@@ -1337,6 +1361,48 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
         if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     return 0;
+}
+
+
+/* One forward wave in two calls (the whole launch sequence runs natively: per-wave host work is two ABI calls). */
+int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
+                                int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
+                                int64_t band_start, int64_t band_len, int64_t wave_off1, const int32_t* rowmap,
+                                int64_t n_rows, void* q_work, int compute_q, int64_t nsub, const int64_t* sub_off0s, void* g_out,
+                                int64_t g_facet_stride, int64_t g_sub_stride, const int64_t* g_offsets,
+                                const int64_t* g_facet_strides, void* stream) {
+    if (!h || (!bands && compute_q) || !q_work || !g_out || !facet_off0s || !sub_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    if (nfacets <= 0 || nsub <= 0) return 0;
+    const int64_t m = h->m;
+    if (n_rows <= 0 || n_rows > h->yN) return fail(SWIFTLY_ERR_PARAM, "bad row count %lld", (long long)n_rows);
+    // K2: Q[f] = [n_rows, m] (skipped when the caller still holds the wave's Q: compute_q = 0)
+    if (compute_q) {
+        int rc = swiftly_hip_prepare_facet_columns(h, dtype, bands, rows, band_row_stride, band_facet_stride, nfacets,
+                                                   facet_off0s, band_start, band_len, wave_off1, q_work, m, n_rows * m,
+                                                   rowmap, stream);
+        if (rc) return rc;
+    }
+    DeviceGuard device_guard_(h->device);
+    // K3 + K4a from Q (layout 1)
+    return transform_contributions_impl(h, dtype, q_work, 1, m, n_rows * m, 0, rowmap, 0, 0, nfacets, facet_off0s, nsub,
+                                        sub_off0s, g_out, g_facet_stride, g_sub_stride, g_offsets, g_facet_strides, stream);
+}
+
+int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
+                                  int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
+                                  int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
+                                  const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
+                                  void* tmp_work, void* out, void* stream) {
+    if (!h || !g || !tmp_work || !out || !sub_off0s || !sub_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    if (nsub <= 0) return 0;
+    const int64_t m = h->m, xM = h->xM, xA = subgrid_size;
+    // K4b + K5a: tmp[b] = [xM, xA]
+    int rc = swiftly_hip_sum_finish_facets(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, m, facet_off0s, facet_off1s,
+                                           tmp_work, xM * xA, xA, sub_off1s, subgrid_size, mask1, mask1_bs, nsub, stream);
+    if (rc) return rc;
+    // K5b: finish_subgrid along axis 0 (strided): rows of the op = xA columns
+    return swiftly_hip_finish_subgrid_batch(h, dtype, tmp_work, xA, 1, xA, out, 1, xA, 0, subgrid_size, mask0, nsub,
+                                            xM * xA, xA * xA, sub_off0s, mask0 ? mask0_bs : 0, stream);
 }
 
 int swiftly_hip_debug_row_band_occupancy(void) { return swf::row_pass_band_occupancy(); }

@@ -87,13 +87,16 @@ struct ColPassArgs {
 // wave); what varies with the SUBGRID lives in the b_* tables, what varies with the FACET in the f_* tables.
 constexpr int kColZB = 64;   // subgrids per launch
 constexpr int kColZF = 32;   // facets per launch
-enum { kZColGather = 1, kZLoadB = 2, kZLoadAF = 4, kZStoreAF = 8, kZStoreAB = 16 };
+enum { kZColGather = 1, kZLoadB = 2, kZLoadAF = 4, kZStoreAF = 8, kZStoreAB = 16, kZOutB = 32 };
 struct ColZ {
     int flags;
     int nb;                            // z = f*nb + b ; nb >= 1
     int b_rot[kColZB], b_base[kColZB];  // kZColGather: column gather (window) per subgrid
     int b_lda[kColZB], b_ldc[kColZB];   // kZLoadB: load-map offsets (ld_a, ld_c) per subgrid (row window)
     int b_sta[kColZB];                  // kZStoreAB: store-map offset st_a per subgrid
+    // kZOutB: output placement per subgrid -- item (f, b) writes at out + b_out_off[b] + f * b_out_fs[b] (elements):
+    // lets one launch fill a rank-ordered all-to-all send buffer [dest][facet][subgrid of dest]
+    long long b_out_off[kColZB], b_out_fs[kColZB];
     int f_lda[kColZF];                  // kZLoadAF: load-map offset ld_a per facet
     int f_sta[kColZF];                  // kZStoreAF: store-map offset st_a per facet
 };
@@ -171,7 +174,9 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs : (long long)z * A.in_bs;
     const cx<float>* __restrict__ in = gin + in_off + scol;
     const long long out_off =
-        A.out_bdiv > 0 ? (long long)(z / A.out_bdiv) * A.out_bs_hi + (long long)(z % A.out_bdiv) * A.out_bs : (long long)z * A.out_bs;
+        (cz.flags & kZOutB) ? cz.b_out_off[zb] + (long long)zf * cz.b_out_fs[zb]
+        : A.out_bdiv > 0 ? (long long)(z / A.out_bdiv) * A.out_bs_hi + (long long)(z % A.out_bdiv) * A.out_bs
+                         : (long long)z * A.out_bs;
     cx<float>* __restrict__ out = gout + out_off + col;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;

@@ -87,6 +87,14 @@ def _declare(lib):
     lib.swiftly_hip_sum_finish_facets.argtypes = [
         vp, c_int, vp, i64, i64, i64, i64, pi64, pi64, vp, i64, i64, pi64, i64, vp, i64, i64, vp,
     ]
+    lib.swiftly_hip_wave_facet_side.restype = c_int
+    lib.swiftly_hip_wave_facet_side.argtypes = [
+        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, vp, c_int, i64, pi64, vp, i64, i64, pi64, pi64, vp,
+    ]
+    lib.swiftly_hip_wave_subgrid_side.restype = c_int
+    lib.swiftly_hip_wave_subgrid_side.argtypes = [
+        vp, c_int, vp, i64, i64, i64, pi64, pi64, i64, pi64, pi64, i64, vp, i64, vp, i64, vp, vp, vp,
+    ]
     lib.swiftly_hip_malloc.restype = c_int
     lib.swiftly_hip_malloc.argtypes = [POINTER(vp), c_size_t]
     lib.swiftly_hip_free.restype = c_int

@@ -590,6 +590,8 @@ class SwiftlyForward:
         """Finished, masked subgrids ``[S, xA, xA]`` of one wave (configs sharing
         the wave key and size).  ``timer`` brackets the stages with HIP events."""
         self.prepare_all_facets()
+        if timer is None and self.wave_axis == 1:
+            return self._wave_b(sgs)  # two native calls per wave
         t0 = timer.start() if timer is not None else None
         if self.wave_axis == 1:
             self._get_wave_columns(sgs[0].off1)
@@ -598,7 +600,7 @@ class SwiftlyForward:
         if timer is not None:
             timer.stop("K2_wave_facet_transform", t0)
             t0 = timer.start()
-        res = self._wave_b(sgs) if self.wave_axis == 1 else self._wave(sgs)
+        res = self._wave_b_staged(sgs) if self.wave_axis == 1 else self._wave(sgs)
         if timer is not None:
             timer.stop("K345_extract_sum_finish", t0)
         return res
@@ -654,6 +656,16 @@ class SwiftlyForward:
             core.launch("extract_from_facet", cols[j], m, core.yN_size, 1, out[j], m, 1,
                         nbatch=S, in_bs=0, out_bs=out.stride(1), offs=off1s)
         return out
+
+    def wave_blocks_into(self, sgs, flat, layout):
+        """:py:meth:`wave_blocks` (transformed) of a whole wave with per-subgrid placement inside the flat buffer
+        ``flat``: block (f, i) at ``layout[0][i] + f * layout[1][i]`` elements -- one native call
+        (contiguous-axis-first pipeline only)."""
+        self._check_planned(sgs)
+        bands = self.prepare_all_facets()
+        Q, rowmap, n_rows, compute = self._wave_Q(sgs[0].off1)
+        self.core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,
+                                  n_rows, Q, compute, [sg.off0 for sg in sgs], flat, g_layout=layout)
 
     def _wave(self, sgs):
         # single-GPU route: the [m, m] contributions are never materialised -- the window gather is
@@ -725,13 +737,49 @@ class SwiftlyForward:
             self.lru.set(("b", off1), hit)
         return hit
 
-    def _wave_b(self, sgs):
-        Q, rowmap = self._get_wave_columns(sgs[0].off1)
+    def _check_planned(self, sgs):
         if self._plan is not None:
-            allowed = {(int(sg.off0), int(sg.off1)) for sg in self._plan}
+            allowed = self.__dict__.setdefault("_plan_set", {(int(sg.off0), int(sg.off1)) for sg in self._plan})
             if any((int(sg.off0), int(sg.off1)) not in allowed for sg in sgs):
                 raise ValueError("subgrid was not in the subgrid_configs plan")
+
+    def _wave_b_staged(self, sgs):
+        """stage-by-stage form (one ABI call per kernel group; used when the stages are timed separately)"""
+        Q, rowmap = self._get_wave_columns(sgs[0].off1)
+        self._check_planned(sgs)
         return _finish_from_columns(self.core, Q, 1, self.facet_configs, sgs, [sg.off0 for sg in sgs], rowmap=rowmap)
+
+    def _wave_Q(self, off1):
+        """(Q workspace, rowmap, n_rows, needs computing) of wave ``off1`` (LRU cached like _get_wave_columns)"""
+        torch = _torch()
+        hit = self.lru.get(("b", off1))
+        if hit is not None:
+            return hit[0], hit[1], hit[0].shape[1], False
+        if self._plan is not None and int(off1) not in self._planned_keys:
+            raise ValueError(f"subgrid wave off1={off1} was not in the subgrid_configs plan")
+        rowmap, n_rows = self._wave_rows(off1)
+        core = self.core
+        Q = torch.empty((len(self.facet_configs), n_rows, core.xM_yN_size), dtype=self.dtype, device=core.device)
+        self.lru.set(("b", off1), (Q, rowmap))
+        return Q, rowmap, n_rows, True
+
+    def _wave_b(self, sgs):
+        """One wave = two native calls: facet side (K2 + K3 + K4a) and subgrid side (K4b + K5)."""
+        torch = _torch()
+        core = self.core
+        self._check_planned(sgs)
+        bands = self.prepare_all_facets()
+        Q, rowmap, n_rows, compute = self._wave_Q(sgs[0].off1)
+        m = core.xM_yN_size
+        G = torch.empty((len(self.facet_configs), len(sgs), m, m), dtype=self.dtype, device=core.device)
+        try:
+            core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,
+                                 n_rows, Q, compute, [sg.off0 for sg in sgs], G)
+        except Exception:
+            if compute:
+                self.lru._items.pop(("b", sgs[0].off1), None)  # pylint: disable=protected-access
+            raise
+        return _finish_from_G(core, G, self.facet_configs, sgs)
 
 
 def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, rowmap=None, band=None):
@@ -758,12 +806,9 @@ def _finish_from_G(core, G, facet_configs, sgs):
     mask1 = _mask_table(core, sgs, "mask1", xA, dt)
     mask0 = _mask_table(core, sgs, "mask0", xA, dt)
     tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
-    core.sum_finish_facets(G, off0s, off1s, tmp, [sg.off1 for sg in sgs], xA, mask=mask1)
     res = torch.empty((S, xA, xA), dtype=dt, device=dev)
-    core.launch("finish_subgrid", tmp, xA, 1, xA, res, 1, xA, 0, size=xA, mask=mask0,
-                nbatch=S, in_bs=xM * xA, out_bs=xA * xA, offs=[sg.off0 for sg in sgs],
-                mask_bs=xA if mask0 is not None else 0)
-    return res
+    return core.wave_subgrid_side(G, off0s, off1s, [sg.off0 for sg in sgs], [sg.off1 for sg in sgs], xA, mask0, mask1,
+                                  tmp, res)
 
 
 def finish_from_blocks(core, blocks, facet_configs, sgs, transformed=True):

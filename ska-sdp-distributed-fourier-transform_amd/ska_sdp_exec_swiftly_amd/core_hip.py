@@ -535,6 +535,48 @@ class SwiftlyCoreHip:
         )
         return out
 
+    @staticmethod
+    def _i64(values):
+        return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+
+    def wave_facet_side(self, bands, facet_off0s, band, wave_off1, rowmap, n_rows, Q, compute_q, sub_off0s, g_out,
+                        g_layout=None):
+        """K2 + K3 + K4a of one wave natively (``swiftly_hip_wave_facet_side``): ``bands[F, yB, band columns]`` ->
+        workspace ``Q[F, n_rows, m]`` (computed when ``compute_q``) -> blocks written into ``g_out``: a
+        ``[F, S, m, m]`` tensor, or a flat send buffer with ``g_layout = (offsets[S], facet_strides[S])``."""
+        F, S = Q.shape[0], len(sub_off0s)
+        cvp = ctypes.c_void_p
+        if g_layout is None:
+            fs, ss, offs, fstr = g_out.stride(0), g_out.stride(1), None, None
+        else:
+            fs, ss, offs, fstr = 0, 0, self._i64(g_layout[0]), self._i64(g_layout[1])
+        _lib.check(
+            self._lib.swiftly_hip_wave_facet_side(
+                self._handle, self._code(Q), cvp(bands.data_ptr()) if bands is not None else None,
+                int(bands.shape[1]) if bands is not None else 0, bands.stride(1) if bands is not None else 0,
+                bands.stride(0) if bands is not None else 0, F, self._i64(facet_off0s), int(band[0]), int(band[1]),
+                int(wave_off1), cvp(rowmap.data_ptr()) if rowmap is not None else None, int(n_rows),
+                cvp(Q.data_ptr()), int(bool(compute_q)), S, self._i64(sub_off0s), cvp(g_out.data_ptr()), fs, ss, offs,
+                fstr, self._stream(),
+            )
+        )
+
+    def wave_subgrid_side(self, G, facet_off0s, facet_off1s, sub_off0s, sub_off1s, subgrid_size, mask0, mask1, tmp, out):
+        """K4b + K5 of one wave natively (``swiftly_hip_wave_subgrid_side``): ``G[F, S, m, m]`` -> ``out[S, xA, xA]``
+        through the workspace ``tmp[S, xM, xA]``."""
+        F, S = G.shape[0], G.shape[1]
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_wave_subgrid_side(
+                self._handle, self._code(G), cvp(G.data_ptr()), F, G.stride(0), G.stride(1), self._i64(facet_off0s),
+                self._i64(facet_off1s), S, self._i64(sub_off0s), self._i64(sub_off1s), int(subgrid_size),
+                cvp(mask0.data_ptr()) if mask0 is not None else None, mask0.stride(0) if mask0 is not None else 0,
+                cvp(mask1.data_ptr()) if mask1 is not None else None, mask1.stride(0) if mask1 is not None else 0,
+                cvp(tmp.data_ptr()), cvp(out.data_ptr()), self._stream(),
+            )
+        )
+        return out
+
     def sum_finish_facets(self, G, facet_off0s, facet_off1s, out, subgrid_off1s, subgrid_size, mask=None):
         """K4b + K5a: sum over facets + axis-1 finish of ``G[F, S, m, m]`` (transform_contributions) ->
         ``out[S, xM, subgrid_size]`` (see include/swiftly_hip.h)."""

@@ -238,6 +238,18 @@ class DistributedForward:
         dests, in_counts, out_counts = forward_layout(self.sharding, len(sgs), m * m)
         F_local = len(self.sharding.local_facets)
         send = torch.empty(sum(in_counts), dtype=self.dtype, device=core.device)
+        if self.fused and self.wave_axis == 1 and F_local:
+            # one native call for the whole wave: block (f, i) of subgrid i = dests[d][k] goes to
+            # chunk_base[d] + f * len(dests[d]) * m^2 + k * m^2
+            offs, fstr = [0] * len(sgs), [0] * len(sgs)
+            base = 0
+            for d, cnt in zip(dests, in_counts):
+                for k, i in enumerate(d):
+                    offs[i] = base + k * m * m
+                    fstr[i] = len(d) * m * m
+                base += cnt
+            self.local.wave_blocks_into(sgs, send, (offs, fstr))
+            return send, in_counts, out_counts
         pos = 0
         for d, cnt in zip(dests, in_counts):
             if cnt:
