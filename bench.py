@@ -63,6 +63,8 @@ WORKLOADS = {
         params=dict(W=13.5625, fov=1.0, N=1024, yB_size=416, yN_size=512, xA_size=228, xM_size=256),
         sparse_radius=None,
         name="reference TEST_PARAMS N=1024, 3x3 facets -> 5x5 subgrids",
+        # W = 13.56 has max 1/pswf ~ 4.9e3: float32 storage alone gives ~8e-3 here; plumbing only
+        parity_tol=3e-2,
     ),
 }
 
@@ -118,7 +120,7 @@ def separable_facet(torch, vec, cfg, pixels=None, device="cuda"):
     return out
 
 
-def verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got_by_index, pixels=None):
+def verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got_by_index, pixels=None, tol=None):
     """Compare finished subgrids (dict: index into sg_cfgs -> numpy array) with the separable oracle.
     Returns the "parity" object of the JSON line."""
     from oracle import separable as sep  # checker only
@@ -127,6 +129,7 @@ def verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got_by_index, pixels=None):
     core = orc.OracleCore(p["W"], p["N"], p["xM_size"], p["yN_size"])
     items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
     so = sep.SeparableOracle(core, items, vectors, pixels)
+    tol = PARITY_TOL if tol is None else tol
     rels, maxs = [], []
     for i, got in sorted(got_by_index.items()):
         c = sg_cfgs[i]
@@ -142,8 +145,8 @@ def verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got_by_index, pixels=None):
         rel_rmse=max(rels),
         rel_rmse_each=[float(f"{r:.3e}") for r in rels],
         max_abs_over_rms=max(maxs),
-        tol_rel_rmse=PARITY_TOL,
-        ok=bool(max(rels) < PARITY_TOL),
+        tol_rel_rmse=tol,
+        ok=bool(max(rels) < tol),
     )
 
 
@@ -423,7 +426,7 @@ def main():
             torch.distributed.all_gather_object(gathered, kept)
             kept = {k: v for d in gathered for k, v in d.items()}
         if rank == 0:
-            parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept)
+            parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept, tol=wl.get("parity_tol"))
 
     # per-stage HIP-event timing (separate instrumented pass, 1 GPU only)
     stages = {}
@@ -520,7 +523,7 @@ def main():
     if world > 1:
         torch.distributed.destroy_process_group()
     if parity is not None and not parity["ok"]:
-        raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {PARITY_TOL}")
+        raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {parity['tol_rel_rmse']}")
 
 
 if __name__ == "__main__":
