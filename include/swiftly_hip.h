@@ -273,6 +273,17 @@ int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* i
                                       int64_t out_row_stride, int64_t out_facet_stride, const int32_t* out_rowmap,
                                       void* stream);
 
+/* K2 for several waves at once (facet-major schedule: all waves of one facet right after its K1, on a second
+ * stream, so that this bandwidth-bound work overlaps the issue-bound K1 of the next facet): item (f, w) is written at
+ * out + f*out_facet_stride + w*out_wave_stride through the row map rowmaps + w*rowmap_stride (device int32[yN] each;
+ * NULL = all rows).  wave_off1s / facet_off0s are HOST arrays. */
+int swiftly_hip_prepare_facet_columns_waves(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
+                                            int64_t in_row_stride, int64_t in_facet_stride, int64_t nfacets,
+                                            const int64_t* facet_off0s, int64_t band_start, int64_t band_len,
+                                            int64_t nwaves, const int64_t* wave_off1s, void* out, int64_t out_row_stride,
+                                            int64_t out_facet_stride, int64_t out_wave_stride, const int32_t* rowmaps,
+                                            int64_t rowmap_stride, void* stream);
+
 /* K3 + K4a: out[f][b][k, j] = Fn[k] * cfft_m(C_{f,b}[:, j])[(k + s'0_f) mod m]  --  add_to_subgrid(axis 0)
  * (core.py:744, numpy form core.py:274-285) of the [m, m] contribution C_{f,b} WITHOUT its placement into the
  * padded subgrid (row k belongs to padded row (k + xM/2 - m/2 + s'0_f) mod xM; sum_finish_facets resolves that).
@@ -303,8 +314,9 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
 
 /* One forward wave as TWO native calls (per-wave host work = two ABI calls; what the streaming classes use):
  *
- * wave_facet_side: K2 (prepare_facet_columns into the workspace q_work[nfacets][n_rows][m]; skipped when
- *   compute_q == 0 and q_work still holds the wave's result) followed by K3 + K4a (transform_contributions, layout 1)
+ * wave_facet_side: K2 (prepare_facet_columns into the workspace q_work[nfacets][n_rows][m], facet stride
+ *   q_facet_stride elements; skipped when compute_q == 0 and q_work still holds the wave's result -- e.g. a slice
+ *   of what prepare_facet_columns_waves precomputed) followed by K3 + K4a (transform_contributions, layout 1)
  *   for the subgrids sub_off0s[nsub] of the wave.  Block (f, b) is written at
  *       g_out + g_offsets[b] + f * g_facet_strides[b]            when g_offsets != NULL
  *       g_out + f * g_facet_stride + b * g_sub_stride             otherwise
@@ -317,9 +329,9 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
 int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
                                 int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
                                 int64_t band_start, int64_t band_len, int64_t wave_off1, const int32_t* rowmap,
-                                int64_t n_rows, void* q_work, int compute_q, int64_t nsub, const int64_t* sub_off0s,
-                                void* g_out, int64_t g_facet_stride, int64_t g_sub_stride, const int64_t* g_offsets,
-                                const int64_t* g_facet_strides, void* stream);
+                                int64_t n_rows, void* q_work, int64_t q_facet_stride, int compute_q, int64_t nsub,
+                                const int64_t* sub_off0s, void* g_out, int64_t g_facet_stride, int64_t g_sub_stride,
+                                const int64_t* g_offsets, const int64_t* g_facet_strides, void* stream);
 int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
                                   int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
                                   int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,

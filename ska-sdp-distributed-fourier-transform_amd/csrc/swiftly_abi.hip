@@ -1173,23 +1173,25 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     return 0;
 }
 
-int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+} // extern "C" (helpers follow)
+// K2 for `nfacets` facets x `nwaves` waves: item (f, w) gathers the window of wave_off1s[w] from band buffer f and
+// writes out + f*out_facet_stride + w*out_wave_stride through row map  rowmaps + w*rowmap_stride  (or none).
+static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
                                       int64_t in_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
-                                      int64_t band_start, int64_t band_len, int64_t subgrid_off1, void* out,
-                                      int64_t out_row_stride, int64_t out_facet_stride, const int32_t* out_rowmap,
+                                      int64_t band_start, int64_t band_len, int64_t nwaves, const int64_t* wave_off1s,
+                                      void* out, int64_t out_row_stride, int64_t out_facet_stride,
+                                      int64_t out_wave_stride, const int32_t* rowmaps, int64_t rowmap_stride,
                                       void* stream) {
-    if (!h || !in || !out || !facet_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
+    if (!h || !in || !out || !facet_off0s || !wave_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: complex64 only");
     const int yN = (int)h->yN, m = (int)h->m;
     if (h->log_yN < 0 || h->log_m < 6) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: sizes not supported");
     if (rows <= 0 || rows >= yN) return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1]", (long long)rows);
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
-    if (nfacets <= 0) return 0;
+    if (nfacets <= 0 || nwaves <= 0) return 0;
     if ((uint64_t)yN * (uint64_t)in_row_stride >= (uint64_t(1) << 32) || (uint64_t)yN * (uint64_t)out_row_stride >= (uint64_t(1) << 32))
         return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
     const int lo = yN / 2 - (int)(rows / 2);
-    const int64_t s = floordiv(subgrid_off1 * h->yN, h->N);
     ColPassArgs c;
     std::memset(&c, 0, sizeof c);
     c.ncols = m;
@@ -1199,32 +1201,69 @@ int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* i
     c.ld_mul = c.st_mul = 1;
     c.ld_a = 0; c.ld_len = (int)rows; c.ld_c = 0; c.ld_mod = (int)rows;  // window already applied by prepare_facet_band
     c.st_a = 0; c.st_len = yN; c.st_c = 0; c.st_mod = yN;
-    c.st_rowmap = out_rowmap;
     c.scale = (float)(1.0 / yN);
     c.conj_ld = c.conj_st = 1;
     c.cg_mod = m; c.cg_full = yN;
     c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = (int)((band_len + 1) / 2);
-    c.in_bs = in_facet_stride;
-    c.out_bs = out_facet_stride;
-    // tuning knob: facets per launch group (both passes of a group run back to back; small groups keep the
-    // four-step intermediate of a group within reach of the Infinity Cache)
+    // tuning knob: facets per launch group (both passes of a group run back to back)
     static const int per_env = getenv("SWIFTLY_K2_FACETS") ? atoi(getenv("SWIFTLY_K2_FACETS")) : kColZF;
-    const int per = std::max(1, std::min(per_env, (int)kColZF));
-    for (int64_t f0 = 0; f0 < nfacets; f0 += per) {
-        const int nf = (int)std::min<int64_t>(per, nfacets - f0);
-        ColZ cz = plain_colz();
-        cz.flags = kZColGather | kZLoadAF;
-        cz.nb = 1;
-        cz.b_rot[0] = pmod(-s, m);
-        cz.b_base[0] = pmod(yN / 2 - m / 2 + s, yN);
-        for (int f = 0; f < nf; f++) cz.f_lda[f] = pmod(-(facet_off0s[f0 + f] + lo), yN);
-        c.in = (const cx<float>*)in + f0 * in_facet_stride;
-        c.out = (cx<float>*)out + f0 * out_facet_stride;
-        const int rc = col_transform(h, h->log_yN, c, cz, m, nf, (hipStream_t)stream);
-        if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: padded facet size %d not supported", yN);
-        if (rc) return rc;
+    const int per_f = std::max(1, std::min(per_env, (int)kColZF));
+    // keep the four-step scratch of one launch group below ~4 GB
+    const int64_t per_w_cap = std::max<int64_t>(1, (int64_t(4) << 30) / ((int64_t)yN * m * 8) / std::min<int64_t>(per_f, nfacets));
+    const int per_w = (int)std::min<int64_t>(kColZB, per_w_cap);
+    for (int64_t f0 = 0; f0 < nfacets; f0 += per_f) {
+        const int nf = (int)std::min<int64_t>(per_f, nfacets - f0);
+        for (int64_t w0 = 0; w0 < nwaves; w0 += per_w) {
+            const int nw = (int)std::min<int64_t>(per_w, nwaves - w0);
+            ColZ cz = plain_colz();
+            cz.flags = kZColGather | kZLoadAF;
+            cz.nb = nw;
+            for (int w = 0; w < nw; w++) {
+                const int64_t s = floordiv(wave_off1s[w0 + w] * h->yN, h->N);
+                cz.b_rot[w] = pmod(-s, m);
+                cz.b_base[w] = pmod(yN / 2 - m / 2 + s, yN);
+            }
+            for (int f = 0; f < nf; f++) cz.f_lda[f] = pmod(-(facet_off0s[f0 + f] + lo), yN);
+            // item z = f*nw + w reads band buffer f, writes out[f][w]
+            c.in = (const cx<float>*)in + f0 * in_facet_stride;
+            c.in_bdiv = nw; c.in_bs_hi = in_facet_stride; c.in_bs = 0;
+            c.out = (cx<float>*)out + f0 * out_facet_stride + w0 * out_wave_stride;
+            c.out_bdiv = nw; c.out_bs_hi = out_facet_stride; c.out_bs = out_wave_stride;
+            c.st_rowmap = rowmaps ? rowmaps + w0 * rowmap_stride : nullptr;
+            c.st_rowmap_bs = rowmaps ? rowmap_stride : 0;
+            const int rc = col_transform(h, h->log_yN, c, cz, m, nf * nw, (hipStream_t)stream);
+            if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: padded facet size %d not supported", yN);
+            if (rc) return rc;
+        }
     }
     return 0;
+}
+
+extern "C" {
+
+int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+                                      int64_t in_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
+                                      int64_t band_start, int64_t band_len, int64_t subgrid_off1, void* out,
+                                      int64_t out_row_stride, int64_t out_facet_stride, const int32_t* out_rowmap,
+                                      void* stream) {
+    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    return prepare_facet_columns_impl(h, dtype, in, rows, in_row_stride, in_facet_stride, nfacets, facet_off0s, band_start,
+                                      band_len, 1, &subgrid_off1, out, out_row_stride, out_facet_stride, 0, out_rowmap, 0,
+                                      stream);
+}
+
+int swiftly_hip_prepare_facet_columns_waves(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
+                                            int64_t in_row_stride, int64_t in_facet_stride, int64_t nfacets,
+                                            const int64_t* facet_off0s, int64_t band_start, int64_t band_len,
+                                            int64_t nwaves, const int64_t* wave_off1s, void* out, int64_t out_row_stride,
+                                            int64_t out_facet_stride, int64_t out_wave_stride, const int32_t* rowmaps,
+                                            int64_t rowmap_stride, void* stream) {
+    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    return prepare_facet_columns_impl(h, dtype, in, rows, in_row_stride, in_facet_stride, nfacets, facet_off0s, band_start,
+                                      band_len, nwaves, wave_off1s, out, out_row_stride, out_facet_stride, out_wave_stride,
+                                      rowmaps, rowmap_stride, stream);
 }
 
 } // extern "C" (helper follows)
@@ -1368,23 +1407,25 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
 int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
                                 int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
                                 int64_t band_start, int64_t band_len, int64_t wave_off1, const int32_t* rowmap,
-                                int64_t n_rows, void* q_work, int compute_q, int64_t nsub, const int64_t* sub_off0s, void* g_out,
+                                int64_t n_rows, void* q_work, int64_t q_facet_stride, int compute_q, int64_t nsub,
+                                const int64_t* sub_off0s, void* g_out,
                                 int64_t g_facet_stride, int64_t g_sub_stride, const int64_t* g_offsets,
                                 const int64_t* g_facet_strides, void* stream) {
     if (!h || (!bands && compute_q) || !q_work || !g_out || !facet_off0s || !sub_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (nfacets <= 0 || nsub <= 0) return 0;
     const int64_t m = h->m;
-    if (n_rows <= 0 || n_rows > h->yN) return fail(SWIFTLY_ERR_PARAM, "bad row count %lld", (long long)n_rows);
+    if (n_rows <= 0 || n_rows > h->yN || q_facet_stride < n_rows * m)
+        return fail(SWIFTLY_ERR_PARAM, "bad row count %lld / facet stride %lld", (long long)n_rows, (long long)q_facet_stride);
     // K2: Q[f] = [n_rows, m] (skipped when the caller still holds the wave's Q: compute_q = 0)
     if (compute_q) {
         int rc = swiftly_hip_prepare_facet_columns(h, dtype, bands, rows, band_row_stride, band_facet_stride, nfacets,
-                                                   facet_off0s, band_start, band_len, wave_off1, q_work, m, n_rows * m,
+                                                   facet_off0s, band_start, band_len, wave_off1, q_work, m, q_facet_stride,
                                                    rowmap, stream);
         if (rc) return rc;
     }
     DeviceGuard device_guard_(h->device);
     // K3 + K4a from Q (layout 1)
-    return transform_contributions_impl(h, dtype, q_work, 1, m, n_rows * m, 0, rowmap, 0, 0, nfacets, facet_off0s, nsub,
+    return transform_contributions_impl(h, dtype, q_work, 1, m, q_facet_stride, 0, rowmap, 0, 0, nfacets, facet_off0s, nsub,
                                         sub_off0s, g_out, g_facet_stride, g_sub_stride, g_offsets, g_facet_strides, stream);
 }
 

@@ -72,6 +72,7 @@ struct ColPassArgs {
     const float* st_win2;
     long long st_win_bs;   // per-batch-item stride of st_win (masks), 0 = shared
     const int* st_rowmap;  // optional: physical output row of logical row idx (negative = not stored)
+    long long st_rowmap_bs;  // per-subgrid-index stride of st_rowmap (one row map per batch item b), 0 = shared
     const float* col_win;  // optional real factor per column applied on store (see RowsArgs::row_win)
     const cx<float>* tw;       // exp(-2 pi i k / n), this pass's length
     const cx<float>* tw_full;  // exp(-2 pi i k / 2^full_logn)
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             if (st_win) out_w *= st_win[(long long)blockIdx.z * A.st_win_bs + ds];
             if (st_win2) out_w *= st_win2[ds];
             int row = idx;
-            if (st_rowmap) row = st_rowmap[ok ? idx : 0];
+            if (st_rowmap) row = st_rowmap[(long long)zb * A.st_rowmap_bs + (ok ? idx : 0)];
             out_row = ok ? row : -1;
         }
     }

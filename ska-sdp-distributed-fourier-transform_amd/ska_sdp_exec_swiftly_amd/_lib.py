@@ -89,7 +89,11 @@ def _declare(lib):
     ]
     lib.swiftly_hip_wave_facet_side.restype = c_int
     lib.swiftly_hip_wave_facet_side.argtypes = [
-        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, vp, c_int, i64, pi64, vp, i64, i64, pi64, pi64, vp,
+        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, vp, i64, c_int, i64, pi64, vp, i64, i64, pi64, pi64, vp,
+    ]
+    lib.swiftly_hip_prepare_facet_columns_waves.restype = c_int
+    lib.swiftly_hip_prepare_facet_columns_waves.argtypes = [
+        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, pi64, vp, i64, i64, i64, vp, i64, vp,
     ]
     lib.swiftly_hip_wave_subgrid_side.restype = c_int
     lib.swiftly_hip_wave_subgrid_side.argtypes = [

@@ -556,10 +556,43 @@ class SwiftlyCoreHip:
                 int(bands.shape[1]) if bands is not None else 0, bands.stride(1) if bands is not None else 0,
                 bands.stride(0) if bands is not None else 0, F, self._i64(facet_off0s), int(band[0]), int(band[1]),
                 int(wave_off1), cvp(rowmap.data_ptr()) if rowmap is not None else None, int(n_rows),
-                cvp(Q.data_ptr()), int(bool(compute_q)), S, self._i64(sub_off0s), cvp(g_out.data_ptr()), fs, ss, offs,
-                fstr, self._stream(),
+                cvp(Q.data_ptr()), Q.stride(0), int(bool(compute_q)), S, self._i64(sub_off0s), cvp(g_out.data_ptr()), fs,
+                ss, offs, fstr, self._stream(),
             )
         )
+
+    def side_stream(self):
+        """second HIP stream of this core (bandwidth-bound work issued next to an issue-bound kernel)"""
+        st = self.__dict__.get("_side_stream")
+        if st is None:
+            st = self.__dict__["_side_stream"] = _torch().cuda.Stream(device=self._device)
+        return st
+
+    def stacked_rowmaps(self, key, maps):
+        """the row maps of several waves as one device tensor ``[W, yN]`` (cached per key)"""
+        cache = self.__dict__.setdefault("_rowmap_stack_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            hit = cache[key] = _torch().stack(list(maps)).contiguous()
+        return hit
+
+    def prepare_facet_columns_waves(self, bands, facet_off0s, band, wave_off1s, out, rowmaps=None):
+        """K2 for the facets ``bands[F', yB, band columns]`` and ALL given waves at once:
+        ``out[F', W, rows, m]`` (``rows`` = the largest kept-row count), row maps ``rowmaps[W, yN]`` int32 or None."""
+        F, W = bands.shape[0], len(wave_off1s)
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_prepare_facet_columns_waves(
+                self._handle, self._code(bands), cvp(bands.data_ptr()), int(bands.shape[1]), bands.stride(1),
+                bands.stride(0), F, self._i64(facet_off0s), int(band[0]), int(band[1]), W, self._i64(wave_off1s),
+                cvp(out.data_ptr()), out.stride(2), out.stride(0), out.stride(1),
+                cvp(rowmaps.data_ptr()) if rowmaps is not None else None,
+                rowmaps.stride(0) if rowmaps is not None else 0, self._stream(),
+            )
+        )
+        return out
 
     def wave_subgrid_side(self, G, facet_off0s, facet_off1s, sub_off0s, sub_off1s, subgrid_size, mask0, mask1, tmp, out):
         """K4b + K5 of one wave natively (``swiftly_hip_wave_subgrid_side``): ``G[F, S, m, m]`` -> ``out[S, xA, xA]``
