@@ -276,13 +276,16 @@ int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* i
 /* K2 for several waves at once (facet-major schedule: all waves of one facet right after its K1, on a second
  * stream, so that this bandwidth-bound work overlaps the issue-bound K1 of the next facet): item (f, w) is written at
  * out + f*out_facet_stride + w*out_wave_stride through the row map rowmaps + w*rowmap_stride (device int32[yN] each;
- * NULL = all rows).  wave_off1s / facet_off0s are HOST arrays. */
+ * NULL = all rows).  workspace (optional, device, workspace_bytes >= 8*yN*m per (facet, wave) of a launch group):
+ * the four-step scratch; with NULL it comes from the stream-ordered pool, whose reuse across streams is only
+ * opportunistic.  wave_off1s / facet_off0s are HOST arrays. */
 int swiftly_hip_prepare_facet_columns_waves(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
                                             int64_t in_row_stride, int64_t in_facet_stride, int64_t nfacets,
                                             const int64_t* facet_off0s, int64_t band_start, int64_t band_len,
                                             int64_t nwaves, const int64_t* wave_off1s, void* out, int64_t out_row_stride,
                                             int64_t out_facet_stride, int64_t out_wave_stride, const int32_t* rowmaps,
-                                            int64_t rowmap_stride, void* stream);
+                                            int64_t rowmap_stride, void* workspace, int64_t workspace_bytes,
+                                            void* stream);
 
 /* K3 + K4a: out[f][b][k, j] = Fn[k] * cfft_m(C_{f,b}[:, j])[(k + s'0_f) mod m]  --  add_to_subgrid(axis 0)
  * (core.py:744, numpy form core.py:274-285) of the [m, m] contribution C_{f,b} WITHOUT its placement into the

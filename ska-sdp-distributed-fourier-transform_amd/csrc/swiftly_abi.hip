@@ -389,7 +389,8 @@ static int launch_col_checked(int lg, int mode, const ColPassArgs& args, const C
 // `c` carries the load / store maps, windows, conjugation flags, scale, batch strides, column gather and row
 // maps of the whole transform; in/out pitches and pointers are given separately.  Returns -1 when the length
 // is outside the column-pass range (caller falls back), else a status code.
-static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st) {
+static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st,
+                         void* ws = nullptr, size_t ws_bytes = 0) {
     const bool two = logn > kColPassMaxLog;  // single pass up to 512 points (1024 threads x 32 points)
     static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
     const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
@@ -414,8 +415,16 @@ static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const C
     const long long slab = (slab_env >= 64 && nb == 1 && !gathered) ? (slab_env / 64) * 64 : (long long)W;
     const long long Ws = std::min<long long>(slab, (long long)W);  // scratch row width
     void* scratch = nullptr;
-    hipError_t he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
-    if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
+    hipError_t he = hipSuccess;
+    // caller-provided workspace (deterministic; the stream-ordered pool reuses memory across STREAMS only
+    // opportunistically, which made the two-stream schedule fall back to fresh multi-GB allocations on some runs)
+    const bool own = !(ws && ws_bytes >= (size_t)nb * n * (size_t)Ws * sizeof(cx<float>));
+    if (own) {
+        he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
+        if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
+    } else {
+        scratch = ws;
+    }
     int rc = 0;
     // scratch accesses: a small intermediate is left cacheable so that pass B finds it in the 256 MiB Infinity
     // Cache (measured: the 160 MB of a K5b wave, K3-5 12.5 -> 11.6 ms per pass); a large one is streamed
@@ -456,8 +465,10 @@ static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const C
         if (B.col_win) B.col_win += c0;
         rc = launch_col_checked(l2, 1, B, zb, n1, nb, st);
     }
-    he = hipFreeAsync(scratch, st);
-    if (!rc && he != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(he));
+    if (own) {
+        he = hipFreeAsync(scratch, st);
+        if (!rc && he != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(he));
+    }
     return rc;
 }
 
@@ -1181,7 +1192,7 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
                                       int64_t band_start, int64_t band_len, int64_t nwaves, const int64_t* wave_off1s,
                                       void* out, int64_t out_row_stride, int64_t out_facet_stride,
                                       int64_t out_wave_stride, const int32_t* rowmaps, int64_t rowmap_stride,
-                                      void* stream) {
+                                      void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
     if (!h || !in || !out || !facet_off0s || !wave_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: complex64 only");
     const int yN = (int)h->yN, m = (int)h->m;
@@ -1209,7 +1220,8 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
     static const int per_env = getenv("SWIFTLY_K2_FACETS") ? atoi(getenv("SWIFTLY_K2_FACETS")) : kColZF;
     const int per_f = std::max(1, std::min(per_env, (int)kColZF));
     // keep the four-step scratch of one launch group below ~4 GB
-    const int64_t per_w_cap = std::max<int64_t>(1, (int64_t(4) << 30) / ((int64_t)yN * m * 8) / std::min<int64_t>(per_f, nfacets));
+    const int64_t group_cap = ws ? (int64_t)ws_bytes : (int64_t(4) << 30);
+    const int64_t per_w_cap = std::max<int64_t>(1, group_cap / ((int64_t)yN * m * 8) / std::min<int64_t>(per_f, nfacets));
     const int per_w = (int)std::min<int64_t>(kColZB, per_w_cap);
     for (int64_t f0 = 0; f0 < nfacets; f0 += per_f) {
         const int nf = (int)std::min<int64_t>(per_f, nfacets - f0);
@@ -1231,7 +1243,7 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
             c.out_bdiv = nw; c.out_bs_hi = out_facet_stride; c.out_bs = out_wave_stride;
             c.st_rowmap = rowmaps ? rowmaps + w0 * rowmap_stride : nullptr;
             c.st_rowmap_bs = rowmaps ? rowmap_stride : 0;
-            const int rc = col_transform(h, h->log_yN, c, cz, m, nf * nw, (hipStream_t)stream);
+            const int rc = col_transform(h, h->log_yN, c, cz, m, nf * nw, (hipStream_t)stream, ws, ws_bytes);
             if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: padded facet size %d not supported", yN);
             if (rc) return rc;
         }
@@ -1258,12 +1270,13 @@ int swiftly_hip_prepare_facet_columns_waves(swiftly_hip_t* h, int dtype, const v
                                             const int64_t* facet_off0s, int64_t band_start, int64_t band_len,
                                             int64_t nwaves, const int64_t* wave_off1s, void* out, int64_t out_row_stride,
                                             int64_t out_facet_stride, int64_t out_wave_stride, const int32_t* rowmaps,
-                                            int64_t rowmap_stride, void* stream) {
+                                            int64_t rowmap_stride, void* workspace, int64_t workspace_bytes,
+                                            void* stream) {
     if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
     DeviceGuard device_guard_(h->device);
     return prepare_facet_columns_impl(h, dtype, in, rows, in_row_stride, in_facet_stride, nfacets, facet_off0s, band_start,
                                       band_len, nwaves, wave_off1s, out, out_row_stride, out_facet_stride, out_wave_stride,
-                                      rowmaps, rowmap_stride, stream);
+                                      rowmaps, rowmap_stride, stream, workspace, workspace ? (size_t)workspace_bytes : 0);
 }
 
 } // extern "C" (helper follows)

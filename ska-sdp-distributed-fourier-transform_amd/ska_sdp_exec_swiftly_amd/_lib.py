@@ -93,7 +93,7 @@ def _declare(lib):
     ]
     lib.swiftly_hip_prepare_facet_columns_waves.restype = c_int
     lib.swiftly_hip_prepare_facet_columns_waves.argtypes = [
-        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, pi64, vp, i64, i64, i64, vp, i64, vp,
+        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, pi64, vp, i64, i64, i64, vp, i64, vp, i64, vp,
     ]
     lib.swiftly_hip_wave_subgrid_side.restype = c_int
     lib.swiftly_hip_wave_subgrid_side.argtypes = [

@@ -719,9 +719,13 @@ class SwiftlyForward:
                 if F * len(keys) * max_rows * m * 8 <= budget:
                     rowmaps = core.stacked_rowmaps(tuple(keys), [rm for rm, _ in maps])
                     Qall = torch.empty((F, len(keys), max_rows, m), dtype=self.dtype, device=core.device)
+                    # four-step scratch of one facet's waves (launch groups of <= 4 GB), owned here: see the ABI note
+                    n_group = max(1, min(len(keys), (4 << 30) // (core.yN_size * m * 8)))
+                    work = torch.empty((n_group, core.yN_size, m), dtype=self.dtype, device=core.device)
                     side = core.side_stream()
                     Qall.record_stream(side)
-                    pre = (keys, rowmaps, Qall, side)
+                    work.record_stream(side)
+                    pre = (keys, rowmaps, Qall, side, work)
             main = torch.cuda.current_stream(core.device)
             for j, cfg in enumerate(self.facet_configs):
                 data = self._ingest.ready(j)
@@ -730,15 +734,17 @@ class SwiftlyForward:
                 if timer is not None:
                     timer.stop("K1_full_facet_transform", t0)
                 if pre is not None:
-                    keys, rowmaps, Qall, side = pre
+                    keys, rowmaps, Qall, side, work = pre
                     ev = torch.cuda.Event()
                     ev.record(main)
                     with torch.cuda.stream(side):
                         side.wait_event(ev)
-                        core.prepare_facet_columns_waves(bands[j : j + 1], [cfg.off0], self._band, keys, Qall[j : j + 1], rowmaps)
+                        core.prepare_facet_columns_waves(
+                            bands[j : j + 1], [cfg.off0], self._band, keys, Qall[j : j + 1], rowmaps, workspace=work
+                        )
                 self._ingest.prefetch(j + 1)
             if pre is not None:
-                keys, rowmaps, Qall, side = pre
+                keys, rowmaps, Qall, side, _ = pre
                 main.wait_stream(side)
                 self._Qall = (Qall, {k: (i, maps[i][0], maps[i][1]) for i, k in enumerate(keys)})
             self.BF_Fs_persist = bands

@@ -565,7 +565,10 @@ class SwiftlyCoreHip:
         """second HIP stream of this core (bandwidth-bound work issued next to an issue-bound kernel)"""
         st = self.__dict__.get("_side_stream")
         if st is None:
-            st = self.__dict__["_side_stream"] = _torch().cuda.Stream(device=self._device)
+            import os  # pylint: disable=import-outside-toplevel
+
+            prio = int(os.environ.get("SWIFTLY_SIDE_PRIO", "0"))  # tuning knob: -1 = high priority side stream
+            st = self.__dict__["_side_stream"] = _torch().cuda.Stream(device=self._device, priority=prio)
         return st
 
     def stacked_rowmaps(self, key, maps):
@@ -578,7 +581,7 @@ class SwiftlyCoreHip:
             hit = cache[key] = _torch().stack(list(maps)).contiguous()
         return hit
 
-    def prepare_facet_columns_waves(self, bands, facet_off0s, band, wave_off1s, out, rowmaps=None):
+    def prepare_facet_columns_waves(self, bands, facet_off0s, band, wave_off1s, out, rowmaps=None, workspace=None):
         """K2 for the facets ``bands[F', yB, band columns]`` and ALL given waves at once:
         ``out[F', W, rows, m]`` (``rows`` = the largest kept-row count), row maps ``rowmaps[W, yN]`` int32 or None."""
         F, W = bands.shape[0], len(wave_off1s)
@@ -589,7 +592,9 @@ class SwiftlyCoreHip:
                 bands.stride(0), F, self._i64(facet_off0s), int(band[0]), int(band[1]), W, self._i64(wave_off1s),
                 cvp(out.data_ptr()), out.stride(2), out.stride(0), out.stride(1),
                 cvp(rowmaps.data_ptr()) if rowmaps is not None else None,
-                rowmaps.stride(0) if rowmaps is not None else 0, self._stream(),
+                rowmaps.stride(0) if rowmaps is not None else 0,
+                cvp(workspace.data_ptr()) if workspace is not None else None,
+                workspace.numel() * workspace.element_size() if workspace is not None else 0, self._stream(),
             )
         )
         return out
