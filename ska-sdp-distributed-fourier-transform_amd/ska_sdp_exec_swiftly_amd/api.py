@@ -695,11 +695,12 @@ class SwiftlyForward:
         """K1: band buffers ``[F, yB, band columns]`` -- prepare_facet along axis 1 of every facet row, only the
         columns some planned subgrid window reads, axis-0 window pre-applied.
 
-        With a plan (``subgrid_configs``) K2 of ALL planned waves is issued facet by facet on a second HIP stream
-        right behind each facet's K1 ("facet-major schedule"): K2 is bandwidth-bound, K1 issue-bound, so the K2 of
-        facet j runs in the memory bandwidth the K1 of facet j+1 leaves unused.  The per-wave results stay in HBM
-        (``[F, W, rows, m]``: 10.7 GB for the 64k-sparse workload; skipped above ``SWIFTLY_PRECOMPUTE_GB``, default
-        48, and when the stages are being timed separately)."""
+        Optional "facet-major schedule" (``SWIFTLY_PRECOMPUTE=1``, needs a plan): K2 of ALL planned waves is issued
+        facet by facet on a second HIP stream right behind each facet's K1, so that the bandwidth-bound K2 of facet j
+        can run in the memory bandwidth the issue-bound K1 of facet j+1 leaves unused; the per-wave results stay in
+        HBM (``[F, W, rows, m]``: 10.7 GB for the 64k-sparse workload; skipped above ``SWIFTLY_PRECOMPUTE_GB``,
+        default 48).  Measured on MI355X: 45.8-46.9 ms per pass against 46.1 ms for the plain wave loop -- the two
+        kernels do not overlap enough to pay for the extra memory, so it is off by default."""
         if self.BF_Fs_persist is None:
             self._check_band_pipeline()
             torch = _torch()
@@ -711,7 +712,7 @@ class SwiftlyForward:
             m = core.xM_yN_size
             bands = torch.empty((F, yB, core.band_columns(self._band)), dtype=self.dtype, device=core.device)
             pre = None
-            if self._plan is not None and timer is None and os.environ.get("SWIFTLY_NO_PRECOMPUTE") is None:
+            if self._plan is not None and timer is None and os.environ.get("SWIFTLY_PRECOMPUTE") == "1":
                 keys = list(dict.fromkeys(int(sg.off1) for sg in self._plan))
                 maps = [self._wave_rows(k) for k in keys]
                 max_rows = max(n for _, n in maps)
