@@ -195,14 +195,17 @@ def test_sum_finish_facets():
         assert rel < 3e-6, (b, rel)
 
 
-@pytest.mark.parametrize("axis", [0, 1])
-def test_forward_pipelines_match_oracle_small_rows(axis):
+@pytest.mark.parametrize("axis", [0, 1, "1-facet-major"])
+def test_forward_pipelines_match_oracle_small_rows(axis, monkeypatch):
     """Both forward pipelines through SwiftlyForward at yN = 32768 with SMALL facets (yB = 352 so that the
     2-D oracle is cheap): 4 facets, planned sparse subgrid set, complex64."""
     import torch
 
     import ska_sdp_exec_swiftly_amd as sw
 
+    if axis == "1-facet-major":  # optional schedule: K2 of all planned waves per facet on a second stream
+        monkeypatch.setenv("SWIFTLY_PRECOMPUTE", "1")
+        axis = 1
     yB, xA = 352, 928
     P = dict(W=W64, fov=1.0, N=N64, yB_size=yB, yN_size=yN64, xA_size=xA, xM_size=xM64)
     cfg = sw.SwiftlyConfig(backend="hip", **P)
