@@ -34,6 +34,8 @@
 #include "swiftly_rowpass.h"
 #include "swiftly_sumfinish.h"
 #include "swiftly_rows.h"
+#include "swiftly_bluestein.h"
+#include <complex>
 
 using namespace swf;
 
@@ -83,6 +85,15 @@ struct swiftly_hip {
     double* fn_d = nullptr;
     std::map<int, cx<float>*> tw_f;  // by log2(length)
     std::map<int, cx<double>*> tw_d;
+    // Bluestein tables for transform lengths that are not a power of two (swiftly_bluestein.h), by length
+    struct Blu {
+        int logL = 0;
+        cx<float>* chirp_f = nullptr;
+        cx<float>* spec_f = nullptr;
+        cx<double>* chirp_d = nullptr;
+        cx<double>* spec_d = nullptr;
+    };
+    std::map<int64_t, Blu> blu;
     std::vector<void*> allocs;
 };
 
@@ -146,6 +157,67 @@ static int make_twiddles(swiftly_hip* h, int logn) {
         h->tw_d[logn] = d;
     }
     return 0;
+}
+
+// Bluestein tables for length n: chirp c[j] = exp(i pi j^2 / n) and the spectrum of the wrapped chirp filter of
+// length L = 2^logL >= 2n - 1 (host radix-2 FFT in double precision; exact angles through j^2 mod 2n).
+static int make_bluestein(swiftly_hip* h, int64_t n) {
+    if (n <= 0 || ilog2_exact(n) >= 0 || h->blu.count(n)) return 0;
+    int logL = 0;
+    while ((int64_t(1) << logL) < 2 * n - 1) logL++;
+    if (logL > kMaxLogNFloat + 1) return 0;  // no kernel for the convolution length: stays unsupported
+    const int64_t L = int64_t(1) << logL;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    std::vector<std::complex<double>> c(n), f(L, 0.0);
+    for (int64_t j = 0; j < n; j++) {
+        const long double ang = pi * (long double)((j * j) % (2 * n)) / (long double)n;
+        c[j] = {(double)cosl(ang), (double)sinl(ang)};
+    }
+    f[0] = c[0];
+    for (int64_t j = 1; j < n; j++) f[j] = f[L - j] = c[j];
+    // iterative radix-2 decimation-in-time FFT (forward, exp(-2 pi i jk / L))
+    for (int64_t i = 1, j = 0; i < L; i++) {
+        int64_t bit = L >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(f[i], f[j]);
+    }
+    for (int64_t len = 2; len <= L; len <<= 1) {
+        for (int64_t i = 0; i < L; i += len)
+            for (int64_t k = 0; k < len / 2; k++) {
+                const long double ang = -2.0L * pi * (long double)k / (long double)len;
+                const std::complex<double> w((double)cosl(ang), (double)sinl(ang));
+                const std::complex<double> u = f[i + k], v = f[i + k + len / 2] * w;
+                f[i + k] = u + v;
+                f[i + k + len / 2] = u - v;
+            }
+    }
+    swiftly_hip::Blu t;
+    t.logL = logL;
+    std::vector<cx<float>> cf(n), sf(L);
+    std::vector<cx<double>> cd(n), sd(L);
+    for (int64_t j = 0; j < n; j++) {
+        cd[j] = {c[j].real(), c[j].imag()};
+        cf[j] = {(float)c[j].real(), (float)c[j].imag()};
+    }
+    for (int64_t j = 0; j < L; j++) {
+        sd[j] = {f[j].real(), f[j].imag()};
+        sf[j] = {(float)f[j].real(), (float)f[j].imag()};
+    }
+    int rc = upload(h, &t.chirp_f, cf);
+    if (!rc) rc = upload(h, &t.spec_f, sf);
+    if (!rc && logL <= kMaxLogNDouble) {
+        rc = upload(h, &t.chirp_d, cd);
+        if (!rc) rc = upload(h, &t.spec_d, sd);
+    }
+    if (!rc) rc = make_twiddles(h, logL);
+    if (!rc && logL == 16) rc = make_twiddles(h, 15);
+    if (!rc && logL == 15) {
+        rc = make_twiddles(h, 14);
+        if (!rc) rc = make_twiddles(h, 13);
+    }
+    if (!rc) h->blu[n] = t;
+    return rc;
 }
 
 // Kernel attributes (max dynamic LDS) and the memory-pool release threshold are per DEVICE state: they are set
@@ -257,6 +329,8 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             if (!rc && l == 15) rc = make_twiddles(h, 13);
             if (!rc && (l == 16 || l == 14)) rc = make_twiddles(h, l - 1);  // band row kernel halves
         }
+    for (int64_t len : {yN, xM, h->m})
+        if (!rc) rc = make_bluestein(h, len);
     if (rc) {
         swiftly_hip_destroy(h);
         return rc;
@@ -676,18 +750,95 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     return rc;
 }
 
+// Transform length n that is NOT a power of two: Bluestein through two power-of-two transforms of length
+// L >= 2n - 1 on a stream-ordered work buffer (swiftly_bluestein.h).
+template <typename R>
+static int run_rows_bluestein(swiftly_hip* h, int64_t n, RowsArgs<R>& a, const OffTab& tab, hipStream_t st) {
+    auto it = h->blu.find(n);
+    const cx<R>* chirp = nullptr;
+    const cx<R>* spec = nullptr;
+    int logL = 0;
+    if (it != h->blu.end()) {
+        logL = it->second.logL;
+        if constexpr (sizeof(R) == 4) {
+            chirp = it->second.chirp_f;
+            spec = it->second.spec_f;
+        } else {
+            chirp = it->second.chirp_d;
+            spec = it->second.spec_d;
+        }
+    }
+    if (!chirp || !spec)
+        return fail(SWIFTLY_ERR_UNSUPPORTED,
+                    "transform length %lld (not a power of two) needs a convolution of length >= %lld, beyond the %s kernels",
+                    (long long)n, (long long)(2 * n - 1), sizeof(R) == 8 ? "complex128 (8192)" : "complex64 (65536)");
+    const int64_t L = int64_t(1) << logL;
+    const int nb = a.nbatch > 0 ? a.nbatch : 1;
+    const int64_t rows_total = (int64_t)nb * a.nrows;
+    if (rows_total > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "too many rows");
+    void *w1 = nullptr, *w2 = nullptr;
+    const size_t bytes = (size_t)rows_total * (size_t)L * sizeof(cx<R>);
+    HIP_TRY(hipMallocAsync(&w1, bytes, st));
+    hipError_t e2 = hipMallocAsync(&w2, bytes, st);
+    if (e2 != hipSuccess) {
+        (void)hipFreeAsync(w1, st);
+        return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(Bluestein work): %s", hipGetErrorString(e2));
+    }
+    BluArgs<R> B;
+    B.a = a;
+    B.n = (int)n;
+    B.L = (int)L;
+    B.chirp = chirp;
+    B.work = (cx<R>*)w1;
+    const unsigned gy = (unsigned)std::min<int64_t>(a.nrows, 65535);
+    hipLaunchKernelGGL((blu_load_kernel<R>), dim3((unsigned)((L + 255) / 256), gy, (unsigned)nb), dim3(256), 0, st, B, tab);
+    int rc = (int)hipGetLastError() ? fail(SWIFTLY_ERR_HIP, "kernel launch failed (blu_load)") : 0;
+    RowsArgs<R> f;
+    OffTab none;
+    none.use = 0;
+    auto fft_L = [&](const void* src, void* dst, bool inverse) -> int {
+        std::memset(&f, 0, sizeof f);
+        f.in = (const cx<R>*)src;
+        f.out = (cx<R>*)dst;
+        f.in_rs = f.out_rs = L;
+        f.in_cs = f.out_cs = 1;
+        f.nrows = (int)rows_total;
+        f.ld = identity_map<R>((int)L);
+        f.st = identity_map<R>((int)L);
+        f.scale = inverse ? (R)(1.0 / (double)L) : (R)1;
+        f.conj_ld = f.conj_st = inverse ? 1 : 0;
+        f.nbatch = 1;
+        return run_rows_chunk(h, logL, f, none, st);
+    };
+    if (!rc) rc = fft_L(w1, w2, false);
+    if (!rc) {
+        const unsigned gy2 = (unsigned)std::min<int64_t>(rows_total, 65535);
+        hipLaunchKernelGGL((blu_mul_kernel<R>), dim3((unsigned)((L + 255) / 256), gy2), dim3(256), 0, st, (cx<R>*)w2, spec,
+                           (long long)rows_total, (int)L);
+        if (hipGetLastError() != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "kernel launch failed (blu_mul)");
+    }
+    if (!rc) rc = fft_L(w2, w1, true);
+    if (!rc) {
+        hipLaunchKernelGGL((blu_store_kernel<R>), dim3((unsigned)((n + 255) / 256), gy, (unsigned)nb), dim3(256), 0, st, B, tab);
+        if (hipGetLastError() != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "kernel launch failed (blu_store)");
+    }
+    (void)hipFreeAsync(w1, st);
+    (void)hipFreeAsync(w2, st);
+    return rc;
+}
+
 // `fill(b, tab_index)` sets the per-item offsets of batch item b into the
-// OffTab; called once per item per chunk.
+// OffTab; called once per item per chunk.  `nlen` = transform length, `logn` = its log2 or -1.
 template <typename R, class Fill>
-static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, const Batch& bt, int use_bits, Fill&& fill,
+static int run_rows(swiftly_hip* h, int64_t nlen, int logn, RowsArgs<R>& a, const Batch& bt, int use_bits, Fill&& fill,
                     hipStream_t st) {
     constexpr int maxlog = sizeof(R) == 8 ? kMaxLogNDouble : kMaxLogNFloat + 1;  // 2^16: lean complex64 kernels only
-    if (logn < kMinLogN || logn > maxlog)
+    if (logn >= 0 && (logn < kMinLogN || logn > maxlog))
         return fail(SWIFTLY_ERR_UNSUPPORTED,
-                    "transform length %s is not supported by the HIP backend (power of two in [8, %d] required for %s)",
-                    logn < 0 ? "(not a power of two)" : std::to_string(1 << logn).c_str(), 1 << maxlog,
-                    sizeof(R) == 8 ? "complex128" : "complex64");
-    const uint64_t n = uint64_t(1) << logn;
+                    "transform length %lld is not supported by the HIP backend (power of two in [8, %d], or a length "
+                    "whose Bluestein convolution fits, for %s)",
+                    (long long)nlen, 1 << maxlog, sizeof(R) == 8 ? "complex128" : "complex64");
+    const uint64_t n = (uint64_t)nlen;
     if (n * (uint64_t)a.in_cs >= (uint64_t(1) << 32) || n * (uint64_t)a.out_cs >= (uint64_t(1) << 32))
         return fail(SWIFTLY_ERR_PARAM, "transform length * column stride must be < 2^32");
     if (a.nrows <= 0 || bt.n <= 0) return 0;
@@ -708,7 +859,7 @@ static int run_rows(swiftly_hip* h, int logn, RowsArgs<R>& a, const Batch& bt, i
         c.nbatch = nb;
         c.st_win_bs = bt.mask_bs;
         if (win0) c.st.win = win0 + b0 * bt.mask_bs;
-        if (int rc = run_rows_chunk(h, logn, c, tab, st)) return rc;
+        if (int rc = logn < 0 ? run_rows_bluestein(h, nlen, c, tab, st) : run_rows_chunk(h, logn, c, tab, st)) return rc;
     }
     return 0;
 }
@@ -775,7 +926,7 @@ static int do_prepare_facet(swiftly_hip* h, const void* in, int64_t rows, int64_
         a.rm_outer = pmod(yN / 2 - m / 2 + s, yN);
         a.rm_full = yN;
     }
-    return run_rows(h, h->log_yN, a, Batch{}, 0, kNoFill, st);
+    return run_rows(h, h->yN, h->log_yN, a, Batch{}, 0, kNoFill, st);
 }
 
 template <typename R>
@@ -794,7 +945,7 @@ static int do_add_to_subgrid(swiftly_hip* h, const void* in, int64_t rows, int64
     maps(off, a0, c0);
     a.st = AxisMap<R>{a0, m, c0, xM, fnwin<R>(h), nullptr};
     a.accumulate = 1;
-    return run_rows(h, h->log_m, a, bt, 4 | 8,
+    return run_rows(h, h->m, h->log_m, a, bt, 4 | 8,
                     [&](int64_t gb, int b, OffTab& t) { maps(bt.offs[gb], t.st_a[b], t.st_c[b]); }, st);
 }
 
@@ -809,7 +960,7 @@ static int do_finish_subgrid(swiftly_hip* h, const void* in, int64_t rows, int64
     a.st = AxisMap<R>{pmod(-(xM / 2 - xA / 2 + off), xM), (int)xA, 0, (int)xA, (const R*)mask, nullptr};
     a.conj_ld = a.conj_st = 1;
     a.scale = (R)(1.0 / xM);
-    return run_rows(h, h->log_xM, a, bt, 4,
+    return run_rows(h, h->xM, h->log_xM, a, bt, 4,
                     [&](int64_t gb, int b, OffTab& t) { t.st_a[b] = pmod(-(xM / 2 - xA / 2 + bt.offs[gb]), xM); }, st);
 }
 
@@ -822,7 +973,7 @@ static int do_prepare_subgrid(swiftly_hip* h, const void* in, int64_t rows, int6
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
     a.ld = AxisMap<R>{pmod(-(xM / 2 - xA / 2 + off), xM), (int)xA, 0, (int)xA, nullptr, nullptr};
     a.st = identity_map<R>(xM);
-    return run_rows(h, h->log_xM, a, bt, 1,
+    return run_rows(h, h->xM, h->log_xM, a, bt, 1,
                     [&](int64_t gb, int b, OffTab& t) { t.ld_a[b] = pmod(-(xM / 2 - xA / 2 + bt.offs[gb]), xM); }, st);
 }
 
@@ -844,7 +995,7 @@ static int do_extract_from_subgrid(swiftly_hip* h, const void* in, int64_t rows,
     a.st = identity_map<R>(m);
     a.conj_ld = a.conj_st = 1;
     a.scale = (R)(1.0 / m);
-    return run_rows(h, h->log_m, a, bt, 1 | 2,
+    return run_rows(h, h->m, h->log_m, a, bt, 1 | 2,
                     [&](int64_t gb, int b, OffTab& t) { maps(bt.offs[gb], t.ld_a[b], t.ld_c[b]); }, st);
 }
 
@@ -859,7 +1010,7 @@ static int do_finish_facet(swiftly_hip* h, const void* in, int64_t rows, int64_t
     a.ld = identity_map<R>(yN);
     // mask goes to `win` (it is the per-item one), the PSWF window to `win2`
     a.st = AxisMap<R>{pmod(-(lo + off), yN), (int)yB, 0, (int)yB, (const R*)mask, invp<R>(h) + lo};
-    return run_rows(h, h->log_yN, a, bt, 4,
+    return run_rows(h, h->yN, h->log_yN, a, bt, 4,
                     [&](int64_t gb, int b, OffTab& t) { t.st_a[b] = pmod(-(lo + bt.offs[gb]), yN); }, st);
 }
 
