@@ -341,6 +341,33 @@ int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, in
                                   const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
                                   void* tmp_work, void* out, void* stream);
 
+/* Backward pass with the contiguous-axis transform LAST (mirror of prepare_facet_band / prepare_facet_columns;
+ * waves = subgrids sharing off1).  Replaces, for all facets of a wave, api_helper.accumulate_column +
+ * accumulate_facet (api_helper.py:142-179) with the two axes swapped (they commute):
+ *
+ * accumulate_facet_columns: for every facet f
+ *     bands[f][r, d] += mask0_f[r] * finish_facet_axis0( sum_b add_to_facet_axis0( C[f][b], sub_off0[b] ), facet_off0s[f] )[r, j]
+ *   where column j < m of the wave lands at band column d = (col(j, subgrid_off1) - band_start) mod yN of the padded
+ *   facet (add_to_facet along axis 1, core.py:441-478).  The sum over the wave's subgrids is taken while LOADING:
+ *   row_sources (device int32 [2][yN]) names for every padded row up to two source rows (negative = none), each
+ *   encoded  chunk << 20 | row : read at parts + chunk_offsets[chunk] + f * chunk_facet_strides[chunk] + row *
+ *   part_row_stride (elements; row = b*m + k for contiguous [m, m] blocks).  Chunks (<= 16) are the pieces of a
+ *   multi-GPU receive buffer; a single-process caller passes one chunk.  masks: device float [nfacets][facet_size]
+ *   or NULL.  bands[f] = [facet_size rows][band_len] plain column order, read-modify-written (zero it first).
+ *   workspace: optional device scratch (nfacets*yN*m*8 bytes used when large enough), else stream-ordered allocation.
+ * finish_facet_band: finish_facet (core.py:481-510) along the contiguous axis of a band accumulator row:
+ *     out[r, :] = mask * Fb * crop( FFT_yN( band row r placed at columns band_start + d, zero elsewhere ) ). */
+int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void* parts, int64_t part_row_stride,
+                                         int64_t nchunks, const int64_t* chunk_offsets,
+                                         const int64_t* chunk_facet_strides, const int32_t* row_sources,
+                                         int64_t nfacets, const int64_t* facet_off0s, int64_t facet_size,
+                                         const float* masks, int64_t subgrid_off1, void* bands, int64_t band_row_stride,
+                                         int64_t band_facet_stride, int64_t band_start, int64_t band_len,
+                                         void* workspace, int64_t workspace_bytes, void* stream);
+int swiftly_hip_finish_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+                                  int64_t band_start, int64_t band_len, void* out, int64_t out_row_stride,
+                                  int64_t facet_off, int64_t facet_size, const void* mask, void* stream);
+
 /* -- device memory helpers for callers that do not bring their own allocator
  *    (the Python mirror uses torch for device memory and never calls these) -- */
 int swiftly_hip_malloc(void** ptr, size_t bytes);

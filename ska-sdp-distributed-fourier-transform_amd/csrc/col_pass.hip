@@ -16,6 +16,13 @@ template <int LOGN, int MODE>
 static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     using G = typename CGeoFor<LOGN>::type;
     dim3 grid((unsigned)((a.ncols + 63) / 64), (unsigned)outer, (unsigned)nbatch);
+    if constexpr (MODE != 1) {
+        if (a.gs) {  // gather-sum load (backward pass); the source contributions are small and re-read: cacheable
+            hipLaunchKernelGGL((col_pass_kernel<G, MODE, true, true>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out,
+                               a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
+            return (int)hipGetLastError();
+        }
+    }
     if (MODE == 2 || a.scratch_nt)
         hipLaunchKernelGGL((col_pass_kernel<G, MODE, true>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
                            a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
@@ -39,6 +46,11 @@ static int init_mode() {
     if (!rc && MODE != 2)
         rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, (MODE == 2 ? 0 : MODE), false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if constexpr (MODE != 1) {
+        if (!rc)
+            rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    }
     return rc;
 }
 template <int LOGN>

@@ -520,7 +520,9 @@ static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const C
         A.tw = tw1; A.tw_full = twf;
         A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
         A.col_win = nullptr; A.st_rowmap = nullptr; A.st_win = nullptr; A.st_win2 = nullptr;
-        rc = launch_col_checked(l1, 0, A, cz, n2, nb, st);
+        ColZ za = cz;
+        za.flags &= ~kZColScatter;  // the scratch is written plainly
+        rc = launch_col_checked(l1, 0, A, za, n2, nb, st);
         if (rc) break;
         // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
         ColPassArgs B = c;
@@ -531,7 +533,7 @@ static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const C
         B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)Ws; B.in_bs = (long long)(n * Ws);
         B.in_bdiv = 0; B.in_bs_hi = 0;
         B.in_i_rows = 1; B.in_o_rows = n2;
-        B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr;
+        B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr; B.gs = 0;
         B.out = c.out + c0;
         B.st_mul = n1;
         B.tw = tw2; B.tw_full = twf;
@@ -645,7 +647,7 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
             return true;
         }
     }
-    if (logn == 15 && mode == 1 && fin_st && !legacy && !no_half) {  // finish_* along the contiguous axis
+    if (logn == 15 && mode != 0 && fin_st && prep_ld && !r.ld_win && !legacy && !no_half) {  // finish_* along the contiguous axis
         const cx<float>* tw14 = twiddles<float>(h, 14);
         if (tw14) {
             r.band_len = -1;  // selects the mapped-store variant
@@ -656,7 +658,7 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     }
     if (logn == 16) {  // 65536-point rows: only the two-workgroup kernel exists (prepare_* loads / finish_* stores)
         const cx<float>* tw15 = twiddles<float>(h, 15);
-        const bool ok0 = mode == 0 && prep_ld && !a.accumulate, ok1 = mode == 1 && fin_st;
+        const bool ok0 = mode == 0 && prep_ld && !a.accumulate, ok1 = mode != 0 && fin_st && prep_ld && !r.ld_win;
         if (!tw15 || !(ok0 || ok1)) return false;
         if (ok1) r.band_len = -1;
         int e2 = launch_row_pass_band_n(16, r, tw15, r.tw, st);
@@ -1002,12 +1004,14 @@ static int do_extract_from_subgrid(swiftly_hip* h, const void* in, int64_t rows,
 template <typename R>
 static int do_finish_facet(swiftly_hip* h, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
                            int64_t out_rs, int64_t out_cs, int64_t off, int64_t yB, const void* mask, const Batch& bt,
-                           hipStream_t st) {
+                           hipStream_t st, int64_t band_start = 0, int64_t band_len = -1) {
     const int yN = (int)h->yN;
     const int lo = yN / 2 - (int)(yB / 2);
     RowsArgs<R> a;
     fill_io(a, in, rows, in_rs, in_cs, out, out_rs, out_cs);
     a.ld = identity_map<R>(yN);
+    // band input: element d of a row is column (band_start + d) mod yN of the padded facet, the rest is zero
+    if (band_len >= 0) a.ld = AxisMap<R>{pmod(-band_start, yN), (int)band_len, 0, (int)band_len, nullptr, nullptr};
     // mask goes to `win` (it is the per-item one), the PSWF window to `win2`
     a.st = AxisMap<R>{pmod(-(lo + off), yN), (int)yB, 0, (int)yB, (const R*)mask, invp<R>(h) + lo};
     return run_rows(h, h->yN, h->log_yN, a, bt, 4,
@@ -1608,6 +1612,85 @@ int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, in
     // K5b: finish_subgrid along axis 0 (strided): rows of the op = xA columns
     return swiftly_hip_finish_subgrid_batch(h, dtype, tmp_work, xA, 1, xA, out, 1, xA, 0, subgrid_size, mask0, nsub,
                                             xM * xA, xA * xA, sub_off0s, mask0 ? mask0_bs : 0, stream);
+}
+
+int swiftly_hip_finish_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
+                                  int64_t band_start, int64_t band_len, void* out, int64_t out_row_stride,
+                                  int64_t facet_off, int64_t facet_size, const void* mask, void* stream) {
+    const int64_t in_cs = 1, out_cs = 1;
+    CHECK_COMMON();
+    CHECK_FACET_SIZE();
+    if (band_len <= 0 || band_len > h->yN || band_start < 0 || band_start >= h->yN)
+        return fail(SWIFTLY_ERR_PARAM, "band [%lld, +%lld) is not a cyclic range of [0, %lld)", (long long)band_start,
+                    (long long)band_len, (long long)h->yN);
+    Batch bt{1, 0, 0, nullptr, 0};
+    return DISPATCH(do_finish_facet, h, in, rows, in_row_stride, in_cs, out, out_row_stride, out_cs, facet_off, facet_size,
+                    mask, bt, (hipStream_t)stream, band_start, band_len);
+}
+
+int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void* parts, int64_t part_row_stride,
+                                         int64_t nchunks, const int64_t* chunk_offsets,
+                                         const int64_t* chunk_facet_strides, const int32_t* row_sources,
+                                         int64_t nfacets, const int64_t* facet_off0s, int64_t facet_size,
+                                         const float* masks, int64_t subgrid_off1, void* bands, int64_t band_row_stride,
+                                         int64_t band_facet_stride, int64_t band_start, int64_t band_len,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!h || !parts || !bands || !chunk_offsets || !chunk_facet_strides || !row_sources || !facet_off0s)
+        return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: complex64 only");
+    CHECK_FACET_SIZE();
+    const int yN = (int)h->yN, m = (int)h->m;
+    if (h->log_yN < 0 || h->log_m < 0 || h->log_yN > 18)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: sizes not supported (powers of two)");
+    if (nchunks <= 0 || nchunks > kColZC) return fail(SWIFTLY_ERR_PARAM, "1..%d source chunks", kColZC);
+    if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
+    if (nfacets <= 0) return 0;
+    if ((uint64_t)facet_size * (uint64_t)band_row_stride >= (uint64_t(1) << 32) ||
+        (uint64_t)part_row_stride << kGsRowBits >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
+    const int lo = yN / 2 - (int)(facet_size / 2);
+    ColPassArgs c;
+    std::memset(&c, 0, sizeof c);
+    c.ncols = m;
+    c.full_logn = h->log_yN;
+    c.in = (const cx<float>*)parts;
+    c.in_pitch = (unsigned)part_row_stride;
+    c.out_pitch = (unsigned)band_row_stride;
+    c.ld_mul = c.st_mul = 1;
+    c.ld_a = 0; c.ld_len = yN; c.ld_c = 0; c.ld_mod = yN;
+    c.ld_rowmap = row_sources; c.gs = 1;
+    c.st_a = 0; c.st_len = (int)facet_size; c.st_c = 0; c.st_mod = (int)facet_size;
+    c.st_win = masks; c.st_win_bs = masks ? facet_size : 0;
+    c.st_win2 = h->invp_f + lo;
+    c.scale = 1.f;
+    c.accumulate = 1;
+    c.cg_mod = m; c.cg_full = yN;
+    c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = 0;
+    const int64_t cap = workspace ? workspace_bytes : (int64_t(4) << 30);
+    const int per_f = (int)std::max<int64_t>(1, std::min<int64_t>(kColZF, cap / ((int64_t)yN * m * 8)));
+    const int64_t s1 = floordiv(subgrid_off1 * h->yN, h->N);
+    for (int64_t f0 = 0; f0 < nfacets; f0 += per_f) {
+        const int nf = (int)std::min<int64_t>(per_f, nfacets - f0);
+        ColZ cz = plain_colz();
+        cz.flags = kZColScatter | kZStoreAF;
+        cz.nb = 1;
+        cz.b_rot[0] = pmod(-s1, m);
+        cz.b_base[0] = pmod(yN / 2 - m / 2 + s1, yN);
+        for (int f = 0; f < nf; f++) cz.f_sta[f] = pmod(-(lo + facet_off0s[f0 + f]), yN);
+        for (int k = 0; k < nchunks; k++) {
+            cz.c_base[k] = chunk_offsets[k] + f0 * chunk_facet_strides[k];
+            cz.c_fs[k] = chunk_facet_strides[k];
+        }
+        c.out = (cx<float>*)bands + f0 * band_facet_stride;
+        c.out_bs = band_facet_stride;
+        if (masks) c.st_win = masks + f0 * facet_size;
+        const int rc = col_transform(h, h->log_yN, c, cz, m, nf, (hipStream_t)stream, workspace,
+                                     workspace ? (size_t)workspace_bytes : 0);
+        if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: padded facet size %d not supported", yN);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int swiftly_hip_debug_row_band_occupancy(void) { return swf::row_pass_band_occupancy(); }

@@ -56,6 +56,11 @@ struct ColPassArgs {
     int cg_mod, cg_full;
     int cg_band_start, cg_band_len, cg_band_half;
     const int* ld_rowmap;  // optional (mapped load): physical input row of logical row idx (must be >= 0 for valid rows)
+    // gather-sum load (template GS, backward pass: add_to_facet fused into the load of finish_facet, api_helper.py:142-179):
+    // ld_rowmap is a table [2][2^full_logn]; logical row idx is the SUM of up to two source rows  ld_rowmap[idx],
+    // ld_rowmap[2^full_logn + idx]  (negative = none), each encoded  chunk << 20 | row  and read at
+    // in + cz.c_base[chunk] + facet * cz.c_fs[chunk] + row * in_pitch  (chunks = pieces of a multi-GPU receive buffer)
+    int gs;
     int ncols;                      // columns (= rows of the primitive)
     int full_logn;                  // log2 of the full transform length the maps refer to
     // load: raw -> row = o*in_o_rows + i*in_i_rows ; mapped -> plain index i*ld_mul + o through the map
@@ -88,7 +93,11 @@ struct ColPassArgs {
 // wave); what varies with the SUBGRID lives in the b_* tables, what varies with the FACET in the f_* tables.
 constexpr int kColZB = 64;   // subgrids per launch
 constexpr int kColZF = 32;   // facets per launch
-enum { kZColGather = 1, kZLoadB = 2, kZLoadAF = 4, kZStoreAF = 8, kZStoreAB = 16, kZOutB = 32 };
+constexpr int kColZC = 16;   // source chunks of a gather-sum load
+constexpr int kGsRowBits = 20;
+// kZColScatter: the column map of kZColGather applied to the OUTPUT column (add_to_facet along the contiguous axis
+// fused into the store; cg_band_half = 0 selects a plain band: column d = (scol - cg_band_start) mod cg_full)
+enum { kZColGather = 1, kZLoadB = 2, kZLoadAF = 4, kZStoreAF = 8, kZStoreAB = 16, kZOutB = 32, kZColScatter = 64 };
 struct ColZ {
     int flags;
     int nb;                            // z = f*nb + b ; nb >= 1
@@ -100,6 +109,7 @@ struct ColZ {
     long long b_out_off[kColZB], b_out_fs[kColZB];
     int f_lda[kColZF];                  // kZLoadAF: load-map offset ld_a per facet
     int f_sta[kColZF];                  // kZStoreAF: store-map offset st_a per facet
+    long long c_base[kColZC], c_fs[kColZC];  // gather-sum load: element offset / facet stride of source chunk c
 };
 
 template <int LOGN_, int LOGP_, bool SPLIT_>
@@ -127,7 +137,7 @@ struct CGeo {
 // coalesced vector load per table instead of P dependent scalar loads), and
 // the main loops fetch the values with v_readlane.  The output-side
 // bookkeeping is issued before the butterflies so its latency hides under them.
-template <class G, int MODE, bool SNT>
+template <class G, int MODE, bool SNT, bool GS = false>
 __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassArgs A, const cx<float>* __restrict__ gin,
                                                          cx<float>* __restrict__ gout,
                                                          const float* __restrict__ ld_win,
@@ -154,15 +164,17 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     const int z = blockIdx.z;
     const int zf = z / cz.nb, zb = z - zf * cz.nb;  // uniform
     int scol = col;
-    if (cz.flags & kZColGather) {  // uniform
+    if (cz.flags & (kZColGather | kZColScatter)) {  // uniform
         const int i = (col + cz.b_rot[zb]) & (A.cg_mod - 1);
         scol = (cz.b_base[zb] + i) & (A.cg_full - 1);
         if (A.cg_band_len > 0) {
             int d = (scol - A.cg_band_start) & (A.cg_full - 1);
             if (d >= A.cg_band_len) d = 0;  // cannot happen for a window of the plan; keeps the access in bounds
-            scol = (d & 1) * A.cg_band_half + (d >> 1);
+            scol = A.cg_band_half > 0 ? (d & 1) * A.cg_band_half + (d >> 1) : d;
         }
     }
+    const int lcol = (cz.flags & kZColGather) ? scol : col;    // column read
+    const int ocol = (cz.flags & kZColScatter) ? scol : col;   // column written
     int ld_a = A.ld_a, ld_c = A.ld_c, st_a = A.st_a;
     if (cz.flags & kZLoadB) {
         ld_a = cz.b_lda[zb];
@@ -173,12 +185,12 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     if (cz.flags & kZStoreAB) st_a = cz.b_sta[zb];
     const long long in_off =
         A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs : (long long)z * A.in_bs;
-    const cx<float>* __restrict__ in = gin + in_off + scol;
+    const cx<float>* __restrict__ in = gin + (GS ? 0ll : in_off) + lcol;
     const long long out_off =
         (cz.flags & kZOutB) ? cz.b_out_off[zb] + (long long)zf * cz.b_out_fs[zb]
         : A.out_bdiv > 0 ? (long long)(z / A.out_bdiv) * A.out_bs_hi + (long long)(z % A.out_bdiv) * A.out_bs
                          : (long long)z * A.out_bs;
-    cx<float>* __restrict__ out = gout + out_off + col;
+    cx<float>* __restrict__ out = gout + out_off + ocol;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
     const float col_w = (A.col_win && live) ? A.col_win[col] : 1.f;
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
 
     // ---- input rows: lane `slot` describes row i = t + slot*T
     int in_row;         // element offset row*pitch is formed later; -1 = zero (padding)
+    int in_row2 = -1;   // GS: second source row
     float in_w = 1.f;
     {
         const int i = t + slot * T;
@@ -198,8 +211,13 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             int idx = q + ld_c;
             if (idx >= A.ld_mod) idx -= A.ld_mod;
             const bool ok = q < A.ld_len;
-            if (A.ld_rowmap) idx = A.ld_rowmap[ok ? idx : 0];
-            in_row = ok ? idx : -1;
+            if constexpr (GS) {
+                in_row2 = ok ? A.ld_rowmap[FN + idx] : -1;
+                in_row = ok ? A.ld_rowmap[idx] : -1;
+            } else {
+                if (A.ld_rowmap) idx = A.ld_rowmap[ok ? idx : 0];
+                in_row = ok ? idx : -1;
+            }
             const int qs = ok ? q : 0;
             if (ld_win) in_w *= ld_win[qs];
             if (ld_win2) in_w *= ld_win2[qs];
@@ -240,8 +258,25 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         constexpr int v = decltype(vI)::value;
         const int row = __builtin_amdgcn_readlane(in_row, v);
         cx<float> val = {0.f, 0.f};
-        if (row >= 0) {  // uniform
-            if (live) val = cp_load<NT_LD>(in + (unsigned)row * A.in_pitch);
+        if constexpr (GS) {
+            constexpr int RM = (1 << kGsRowBits) - 1;
+            if (row >= 0) {  // uniform
+                const int c = row >> kGsRowBits;
+                if (live) val = cp_load<NT_LD>(in + cz.c_base[c] + (long long)zf * cz.c_fs[c] + (unsigned)(row & RM) * A.in_pitch);
+            }
+            const int row2 = __builtin_amdgcn_readlane(in_row2, v);
+            if (row2 >= 0) {  // uniform
+                const int c = row2 >> kGsRowBits;
+                if (live) {
+                    const cx<float> w2 = cp_load<NT_LD>(in + cz.c_base[c] + (long long)zf * cz.c_fs[c] + (unsigned)(row2 & RM) * A.in_pitch);
+                    val.x += w2.x;
+                    val.y += w2.y;
+                }
+            }
+        } else {
+            if (row >= 0) {  // uniform
+                if (live) val = cp_load<NT_LD>(in + (unsigned)row * A.in_pitch);
+            }
         }
         x[v] = val;
     });

@@ -955,10 +955,26 @@ class SwiftlyBackward:
         folded into the facet accumulators
     :param queue_size: bound on unfinished subgrid tasks (reference
         ``TaskQueue``, api.py:466-522)
+    :param wave_axis: 0 (default) = the reference's schedule: partial sums per subgrid ``off0`` column, facet
+        accumulators ``[yN, yB]``, strided-axis transform at the end.  1 (complex64, power-of-two sizes) = the
+        mirror of the forward ``wave_axis=1`` pipeline: subgrids sharing ``off1`` form a wave, the strided-axis
+        ``finish_facet`` runs per wave on ``m`` columns with ``add_to_facet`` fused into its load and its store
+        (no column accumulator in HBM), the facet accumulators are bands ``[yB, band]`` and the full-facet
+        transform at the end runs along the contiguous axis in one kernel.  Any request order is correct.
+    :param subgrid_configs: (wave_axis=1) the subgrids that will be added: sizes the band accumulators to the
+        columns they touch; without it the band is the whole padded axis
     """
 
     # pylint: disable=too-many-arguments,too-many-instance-attributes
-    def __init__(self, swiftly_config, facets_config_list, lru_backward=1, queue_size=20, client=None):
+    def __init__(self, swiftly_config, facets_config_list, lru_backward=1, queue_size=20, client=None,
+                 subgrid_configs=None, wave_axis=None):
+        self.wave_axis = 0 if wave_axis is None else int(wave_axis)
+        if self.wave_axis not in (0, 1):
+            raise ValueError("wave_axis must be 0 or 1")
+        self._plan = list(subgrid_configs) if subgrid_configs is not None else None
+        self._band = None
+        self._bands = None
+        self._work = None
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facets_config_list = facets_config_list
@@ -981,11 +997,12 @@ class SwiftlyBackward:
         batched launches; a single subgrid is a wave of one)."""
         col = None
         i = 0
+        key = "off1" if self.wave_axis == 1 else "off0"
         while i < len(subgrid_configs):
             j = i + 1
             while (
                 j < len(subgrid_configs)
-                and subgrid_configs[j].off0 == subgrid_configs[i].off0
+                and getattr(subgrid_configs[j], key) == getattr(subgrid_configs[i], key)
                 and subgrid_configs[j].size == subgrid_configs[i].size
             ):
                 j += 1
@@ -1044,6 +1061,8 @@ class SwiftlyBackward:
         core = self.core
         m, yN = core.xM_yN_size, core.yN_size
         F = len(self.facets_config_list)
+        if self.wave_axis == 1:
+            return self._accumulate_band(sgs[0].off1, [(sgs, parts)])
         off0 = sgs[0].off0
         col = self.lru.get(off0)
         if col is None:
@@ -1065,6 +1084,8 @@ class SwiftlyBackward:
         core = self.core
         m, yN = core.xM_yN_size, core.yN_size
         F = len(self.facets_config_list)
+        if self.wave_axis == 1:  # ``off0`` is the wave key: the subgrids' off1
+            return self._accumulate_band(off0, chunks)
         col = self.lru.get(off0)
         for sgs, parts in chunks:
             if self.dtype is None:
@@ -1086,6 +1107,75 @@ class SwiftlyBackward:
         col = self.accumulate_wave(sgs, parts)
         self.task_queue.process([col])
         return col
+
+    # ---- wave_axis = 1: band accumulators
+    def _band_state(self, dtype):
+        """Band, accumulators ``[F, yB, band length]`` (zeros) and the facet mask table, created at first use."""
+        torch = _torch()
+        core = self.core
+        if self._bands is None:
+            if dtype != torch.complex64 or not core.supports_backward_band(dtype):
+                raise ValueError("SwiftlyBackward(wave_axis=1) needs complex64 data and power-of-two yN_size / xM_yN_size")
+            sizes = {cfg.size for cfg in self.facets_config_list}
+            if len(sizes) != 1:
+                raise ValueError("SwiftlyBackward(wave_axis=1) needs facets of one size")
+            yB = sizes.pop()
+            self._band = core.band_for_offsets([sg.off1 for sg in self._plan]) if self._plan else (0, core.yN_size)
+            self._planned = {sg.off1 for sg in self._plan} if self._plan else None
+            F = len(self.facets_config_list)
+            self._bands = torch.zeros((F, yB, self._band[1]), dtype=dtype, device=core.device)
+            self._masks0 = _mask_table(core, self.facets_config_list, "mask0", yB, dtype)
+            self._facet_off0s = [cfg.off0 for cfg in self.facets_config_list]
+            self._work = torch.empty((F, core.yN_size, core.xM_yN_size), dtype=dtype, device=core.device)
+        return self._bands
+
+    def _accumulate_band(self, off1, chunks):
+        """accumulate_column + accumulate_facet (reference api_helper.py:142-179) with the axes swapped, for the
+        contributions ``chunks = [(subgrid configs, parts[F, S_c, m, m]), ...]`` of subgrids sharing ``off1``."""
+        core = self.core
+        m = core.xM_yN_size
+        chunks = [(sgs, parts) for sgs, parts in chunks if len(sgs)]
+        if not chunks:
+            return None
+        if self.dtype is None:
+            self.dtype = chunks[0][1].dtype
+        bands = self._band_state(chunks[0][1].dtype)
+        if self._planned is not None and off1 not in self._planned:
+            raise ValueError(f"subgrid off1={off1} is not in the subgrid_configs this SwiftlyBackward was planned for")
+        F = len(self.facets_config_list)
+        base = chunks[0][1]
+        offs, fstr, off0s, locs = [], [], [], []
+        fixed = []
+        for c, (sgs, parts) in enumerate(chunks):
+            if parts.shape[0] != F or parts.dtype != base.dtype:
+                raise ValueError("contribution chunk does not match the facet list / dtype")
+            if parts.stride(3) != 1 or parts.stride(2) != m or (parts.shape[1] > 1 and parts.stride(1) != m * m):
+                parts = parts.contiguous()
+            fixed.append(parts)  # keeps a contiguous copy alive until the launch is queued
+            offs.append((parts.data_ptr() - base.data_ptr()) // base.element_size())
+            fstr.append(parts.stride(0) if F > 1 else 0)
+            for b, sg in enumerate(sgs):
+                off0s.append(sg.off0)
+                locs.append((c, b))
+        if len(chunks) > core.GS_MAX_CHUNKS:
+            raise ValueError(f"at most {core.GS_MAX_CHUNKS} contribution chunks per wave")
+        for _members, table in core.column_row_sources(off0s, locs):
+            core.accumulate_facet_columns(base, m, offs, fstr, table, self._facet_off0s, bands.shape[1], self._masks0,
+                                          off1, bands, self._band, workspace=self._work)
+        return bands
+
+    def _finish_bands(self):
+        torch = _torch()
+        core = self.core
+        out = []
+        if self._bands is None:
+            dt = self.dtype or torch.complex64
+            return [torch.zeros((cfg.size, cfg.size), dtype=dt, device=core.device) for cfg in self.facets_config_list]
+        for j, cfg in enumerate(self.facets_config_list):
+            out.append(core.finish_facet_band(self._bands[j], self._band, cfg.off1, cfg.size, mask=cfg.mask1))
+        self._bands = None
+        self._work = None
+        return out
 
     def update_MNAF_BMNAFs(self, off0, NAF_MNAFs):
         """accumulate_facet for every facet (reference api.py:440-463,
@@ -1109,6 +1199,10 @@ class SwiftlyBackward:
         api_helper.py:184-187)."""
         torch = _torch()
         core = self.core
+        if self.wave_axis == 1:
+            out = self._finish_bands()
+            self.task_queue.wait_all_done()
+            return out
         for old_off0, old_col in self.lru.pop_all():
             self.update_MNAF_BMNAFs(old_off0, old_col)
         out = []

@@ -441,6 +441,12 @@ class SwiftlyCoreHip:
         """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
         return self.supports_fused_subgrid(dtype) and self._logs()["yN"] in (14, 15, 16) and self._logs()["m"] >= 6
 
+    def supports_backward_band(self, dtype=None):
+        """True when accumulate_facet_columns / finish_facet_band (include/swiftly_hip.h) exist for these sizes."""
+        torch = _torch()
+        logs = self._logs()
+        return logs is not None and (dtype is None or dtype == torch.complex64) and 2 <= logs["yN"] <= 18
+
     def band_for_offsets(self, subgrid_offs):
         """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains
         the ``xM_yN_size`` window of every given subgrid offset (core.py:243-253); ``(0, yN_size)`` = all."""
@@ -628,6 +634,86 @@ class SwiftlyCoreHip:
                 f0, f1, ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1), so, int(subgrid_size),
                 ctypes.c_void_p(mask.data_ptr()) if mask is not None else None,
                 mask.stride(0) if mask is not None else 0, S, self._stream(),
+            )
+        )
+        return out
+
+    # ------------------------------------------------------------------ backward, contiguous axis last
+    GS_MAX_CHUNKS = 16
+
+    def column_row_sources(self, sub_off0s, locations=None):
+        """Row tables of the gather-sum load of :py:meth:`accumulate_facet_columns` for a wave of subgrids with
+        axis-0 offsets ``sub_off0s`` (``add_to_facet`` along axis 0, core.py:441-478, as a gather): a list of
+        ``(subgrid indices, table)`` -- normally one entry; subgrids are split into several groups when more than
+        two of them overlap in a padded row.  ``locations[b] = (chunk, block index inside the chunk)`` says where
+        the ``[m, m]`` block of subgrid ``b`` sits (default: chunk 0, block ``b``).  Tables are cached on device."""
+        torch = _torch()
+        offs = tuple(int(o) for o in sub_off0s)
+        locs = tuple((0, b) for b in range(len(offs))) if locations is None else tuple((int(c), int(i)) for c, i in locations)
+        key = (offs, locs)
+        cache = self.__dict__.setdefault("_row_source_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        yN, m = self.yN_size, self.xM_yN_size
+        k = numpy.arange(m)
+        groups = []
+        tab = cnt = members = None
+        for b, off in enumerate(offs):
+            s = off * yN // self.N
+            big = (yN // 2 - m // 2 + s + ((k - s) % m)) % yN
+            chunk, blk = locs[b]
+            if blk * m + m > (1 << 20) or chunk >= self.GS_MAX_CHUNKS:
+                raise ValueError("too many contribution rows / chunks for one accumulate_facet_columns call")
+            if tab is None or (cnt[big] >= 2).any():
+                tab = numpy.full((2, yN), -1, dtype=numpy.int32)
+                cnt = numpy.zeros(yN, dtype=numpy.int64)
+                members = []
+                groups.append((members, tab))
+            tab[cnt[big], big] = (chunk << 20) | (blk * m + k)
+            cnt[big] += 1
+            members.append(b)
+        out = [(list(mem), torch.from_numpy(t).to(self._device)) for mem, t in groups]
+        if len(cache) >= 512:
+            cache.clear()
+        cache[key] = out
+        return out
+
+    def accumulate_facet_columns(self, parts, part_row_stride, chunk_offsets, chunk_facet_strides, table, facet_off0s,
+                                 facet_size, masks, subgrid_off1, bands, band, workspace=None):
+        """``bands[f] += mask0_f * finish_facet_axis0(sum_b add_to_facet_axis0(C[f][b]))`` placed at the band columns
+        of ``subgrid_off1`` (``swiftly_hip_accumulate_facet_columns``, include/swiftly_hip.h).  ``parts``: device
+        tensor holding the contribution blocks (chunk offsets / facet strides in elements relative to its start),
+        ``bands``: ``[F, facet_size, band length]``, ``masks``: float32 ``[F, facet_size]`` or None."""
+        F = bands.shape[0]
+        nch = len(chunk_offsets)
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_accumulate_facet_columns(
+                self._handle, self._code(bands), cvp(parts.data_ptr()), int(part_row_stride), nch,
+                self._i64(chunk_offsets), self._i64(chunk_facet_strides), cvp(table.data_ptr()), F,
+                self._i64(facet_off0s), int(facet_size), cvp(masks.data_ptr()) if masks is not None else None,
+                int(subgrid_off1), cvp(bands.data_ptr()), bands.stride(1), bands.stride(0), int(band[0]), int(band[1]),
+                cvp(workspace.data_ptr()) if workspace is not None else None,
+                workspace.numel() * workspace.element_size() if workspace is not None else 0, self._stream(),
+            )
+        )
+        return bands
+
+    def finish_facet_band(self, band_acc, band, facet_off, facet_size, mask=None, out=None):
+        """``finish_facet`` (core.py:481-510) along the contiguous axis for a band accumulator ``[rows, band
+        length]`` (``swiftly_hip_finish_facet_band``)."""
+        torch = _torch()
+        rows = band_acc.shape[0]
+        if out is None:
+            out = torch.empty((rows, int(facet_size)), dtype=band_acc.dtype, device=self._device)
+        mvec = self._real_vec(mask, band_acc.dtype, int(facet_size)) if mask is not None else None
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_finish_facet_band(
+                self._handle, self._code(band_acc), cvp(band_acc.data_ptr()), rows, band_acc.stride(0), int(band[0]),
+                int(band[1]), cvp(out.data_ptr()), out.stride(0), int(facet_off), int(facet_size),
+                cvp(mvec.data_ptr()) if mvec is not None else None, self._stream(),
             )
         )
         return out

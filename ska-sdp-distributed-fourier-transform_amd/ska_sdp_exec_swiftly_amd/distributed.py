@@ -297,10 +297,13 @@ class DistributedBackward:
     owners, who accumulate (api_helper.py:142-179) and finally finish their
     facets (api_helper.py:182-197)."""
 
-    def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None, rank_world=None):
+    # pylint: disable=too-many-arguments
+    def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None, rank_world=None, wave_axis=0,
+                 subgrid_configs=None):
         from .api import SwiftlyBackward  # pylint: disable=import-outside-toplevel
 
         self.group = group
+        self.wave_axis = int(wave_axis)
         self.rank, self.world = rank_world if rank_world is not None else _dist_info(group)
         self.config = swiftly_config
         self.core = swiftly_config.core
@@ -308,7 +311,8 @@ class DistributedBackward:
         self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world)
         # facet owner side: accumulators of the local facets
         self.local = SwiftlyBackward(
-            swiftly_config, [self.facet_configs[j] for j in self.sharding.local_facets], lru_backward=lru_backward
+            swiftly_config, [self.facet_configs[j] for j in self.sharding.local_facets], lru_backward=lru_backward,
+            wave_axis=self.wave_axis, subgrid_configs=subgrid_configs,
         )
         # subgrid holder side: contributions to ALL facets, owner-major order
         self.splitter = SwiftlyBackward(
@@ -316,7 +320,9 @@ class DistributedBackward:
         )
 
     def pack_wave(self, sgs, subgrids_mine):
-        """``sgs``: all subgrid configs of the wave (same ``off0`` and size, identical on every rank);
+        """``sgs``: all subgrid configs of the wave (same size and same ``off0`` -- ``off1`` with ``wave_axis=1``,
+        where the facet owners take the strided-axis transform per wave and the contiguous one at the end --
+        identical on every rank);
         ``subgrids_mine``: data of the subgrids this rank holds, in the order of
         ``sharding.subgrids_of(len(sgs))``.  Returns ``(send, in_counts, out_counts)``: the contributions of my
         subgrids to all facets, owner-major, flat."""
@@ -352,7 +358,7 @@ class DistributedBackward:
             if cnt:
                 chunks.append(([sgs[i] for i in idx], recv[pos : pos + cnt].view(F_local, len(idx), m, m)))
             pos += cnt
-        self.local.accumulate_chunks(sgs[0].off0, chunks)
+        self.local.accumulate_chunks(sgs[0].off1 if self.wave_axis == 1 else sgs[0].off0, chunks)
 
     def start_wave(self, sgs, subgrids_mine):
         """:py:meth:`pack_wave` + start of the mirror all-to-all; returns a handle for :py:meth:`finish_wave`."""

@@ -84,6 +84,61 @@ def test_forward_backward_golden(golden_dir, gfile, params, seed, dtype, ftol, b
     e4 = relrms(out[g["facet_full_idx"]], g["facets_out_full"])
     print(f"backward relRMSE {dtype.__name__}: sample {e3:.3e} full {e4:.3e}")
     assert e3 < btol and e4 < btol, (e3, e4)
+    if dtype == numpy.complex64:
+        # band schedule (wave_axis=1: strided-axis finish per off1 wave, contiguous-axis transform at the end):
+        # subgrid by subgrid in the reference's order, wave-batched with a plan, and shuffled
+        order = list(range(len(sg_cfgs)))
+        random.Random(5).shuffle(order)
+        runs = []
+        for mode in ("single", "waves+plan", "shuffled"):
+            plan = sg_cfgs if mode == "waves+plan" else None
+            b1 = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=plan)
+            if mode == "single":
+                for sg_cfg, data in zip(sg_cfgs, sgs):
+                    b1.add_new_subgrid_task(sg_cfg, data)
+            elif mode == "waves+plan":
+                by1 = sorted(range(len(sg_cfgs)), key=lambda i: (sg_cfgs[i].off1, sg_cfgs[i].off0))
+                b1.add_new_subgrid_tasks([sg_cfgs[i] for i in by1], [sgs[i] for i in by1])
+            else:
+                for i in order:
+                    b1.add_new_subgrid_task(sg_cfgs[i], sgs[i])
+            o1 = numpy.array([f.cpu().numpy() for f in b1.finish()])
+            e5 = relrms(o1[:, ::9, ::7], g["facets_out_sample"])
+            e6 = relrms(o1[g["facet_full_idx"]], g["facets_out_full"])
+            print(f"backward (band, {mode}) relRMSE: sample {e5:.3e} full {e6:.3e}")
+            assert e5 < btol and e6 < btol, (mode, e5, e6)
+            runs.append(o1)
+        assert relrms(runs[1], runs[0]) < 3e-6 and relrms(runs[2], runs[0]) < 3e-6
+
+
+def test_backward_band_sparse_plan_and_overlaps():
+    """wave_axis=1 backward with a sparse subgrid set (band shorter than the padded axis, wrapped offsets) and
+    with more than two subgrids overlapping in a row (duplicates: the row tables split into groups): equal to the
+    reference schedule (wave_axis=0) on the same inputs."""
+    import torch
+
+    params = dict(W=11.0, fov=1.0, N=1024, yB_size=352, yN_size=512, xA_size=192, xM_size=256)
+    sw, cfg, facet_cfgs, sg_cfgs, _ = small_problem(params, numpy.complex64, 3)
+    keep = [c for c in sg_cfgs if c.off1 in (0, 192, 960) or c.off0 == 384][:14]
+    keep = keep + keep[:3] + keep[:2]  # duplicates: up to three sources per padded row
+    assert len({c.off1 for c in keep}) < len({c.off1 for c in sg_cfgs})
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    data = [torch.randn((192, 192), dtype=torch.complex64, generator=gen).cuda() for _ in keep]
+    b0 = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=0)
+    b1 = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=keep)
+    by1 = sorted(range(len(keep)), key=lambda i: keep[i].off1)
+    b0.add_new_subgrid_tasks(keep, data)
+    b1.add_new_subgrid_tasks([keep[i] for i in by1], [data[i] for i in by1])
+    assert b1._band[1] < cfg.core.yN_size  # pylint: disable=protected-access
+    for a, b in zip(b1.finish(), b0.finish()):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    with pytest.raises(ValueError):
+        b2 = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=keep[:1])
+        other = next(c for c in sg_cfgs if c.off1 != keep[0].off1)
+        b2.add_new_subgrid_task(other, data[0])
+    with pytest.raises(ValueError):
+        b3 = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1)
+        b3.add_new_subgrid_task(keep[0], data[0].to(torch.complex128))
 
 
 @pytest.mark.parametrize(
@@ -297,6 +352,23 @@ def test_distributed_virtual_ranks(world):
             b.unpack_wave(wave, recvs[r])
     ref = ref_bwd.finish()
     for b in bwds:
+        idx, out = b.finish()
+        for j, o in zip(idx, out):
+            assert float((o - ref[j]).abs().max()) <= 2e-5 * float(ref[j].abs().max())
+    # the band schedule of the backward pass (waves keyed by off1) through the same exchange layouts
+    bwds1 = [DistributedBackward(cfg, facet_cfgs, rank_world=(r, world), wave_axis=1, subgrid_configs=sg_cfgs)
+             for r in range(world)]
+    full = {(c.off0, c.off1): ref_fwd.get_subgrid_task(c) for c in sg_cfgs}
+    waves1 = {}
+    for c in sg_cfgs:
+        waves1.setdefault(c.off1, []).append(c)
+    for wave in waves1.values():
+        packed = [b.pack_wave(wave, [full[(wave[i].off0, wave[i].off1)] for i in b.sharding.subgrids_of(len(wave))])
+                  for b in bwds1]
+        recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+        for r, b in enumerate(bwds1):
+            b.unpack_wave(wave, recvs[r])
+    for b in bwds1:
         idx, out = b.finish()
         for j, o in zip(idx, out):
             assert float((o - ref[j]).abs().max()) <= 2e-5 * float(ref[j].abs().max())
