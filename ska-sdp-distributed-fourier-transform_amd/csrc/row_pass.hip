@@ -107,7 +107,8 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
     // tuning knob SWIFTLY_ROW_GEO: 5 (512 threads x 32 points, two workgroups per CU) | 4 (1024 x 16, one per CU);
     // default: 5 for the band store (1 spilled VGPR), 4 for the plain store (the 512-thread form spills ~49 there)
     static const int geo_env = getenv("SWIFTLY_ROW_GEO") ? atoi(getenv("SWIFTLY_ROW_GEO")) : 0;
-    const int geo = geo_env ? geo_env : (a.band_len > 0 ? 5 : 4);
+    static const int geo_fin = getenv("SWIFTLY_ROW_GEO_FIN") ? atoi(getenv("SWIFTLY_ROW_GEO_FIN")) : 5;
+    const int geo = geo_env ? geo_env : (a.band_len > 0 ? 5 : a.band_len < 0 ? geo_fin : 4);
     if (geo == 4) return launch_band_geo<BandGeo4>(a, tw14, tw_full, s);
     return launch_band_geo<BandGeo5>(a, tw14, tw_full, s);
 }

@@ -600,6 +600,28 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
 }
 
 
+__global__ void mul_windows_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
+// The mapped-store form of the band row kernel takes ONE output window: fold st_win * st_win2 into a
+// stream-ordered temporary (freed by the caller with hipFreeAsync after the launch is queued).
+static int single_store_window(RowPassArgs& r, hipStream_t st, void** tmp) {
+    *tmp = nullptr;
+    if (r.st_win && r.st_win2) {
+        HIP_TRY(hipMallocAsync(tmp, (size_t)r.st_len * sizeof(float), st));
+        hipLaunchKernelGGL(mul_windows_kernel, dim3((unsigned)((r.st_len + 255) / 256)), dim3(256), 0, st, (float*)*tmp,
+                           r.st_win, r.st_win2, r.st_len);
+        HIP_TRY(hipGetLastError());
+        r.st_win = (const float*)*tmp;
+    } else if (r.st_win2) {
+        r.st_win = r.st_win2;
+    }
+    r.st_win2 = nullptr;
+    return 0;
+}
+
 // Lean path for long complex64 transforms along the contiguous axis (one
 // workgroup per row): swiftly_rowpass.h.  Returns false when the call does not
 // fit (generic kernel handles it).
@@ -651,7 +673,13 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
         const cx<float>* tw14 = twiddles<float>(h, 14);
         if (tw14) {
             r.band_len = -1;  // selects the mapped-store variant
+            void* tmp = nullptr;
+            if (int rc = single_store_window(r, st, &tmp)) {
+                *rc_out = rc;
+                return true;
+            }
             int e2 = launch_row_pass_band(r, tw14, r.tw, st);
+            if (tmp) (void)hipFreeAsync(tmp, st);
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
             return true;
         }
@@ -660,8 +688,16 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
         const cx<float>* tw15 = twiddles<float>(h, 15);
         const bool ok0 = mode == 0 && prep_ld && !a.accumulate, ok1 = mode != 0 && fin_st && prep_ld && !r.ld_win;
         if (!tw15 || !(ok0 || ok1)) return false;
-        if (ok1) r.band_len = -1;
+        void* tmp = nullptr;
+        if (ok1) {
+            r.band_len = -1;
+            if (int rc = single_store_window(r, st, &tmp)) {
+                *rc_out = rc;
+                return true;
+            }
+        }
         int e2 = launch_row_pass_band_n(16, r, tw15, r.tw, st);
+        if (tmp) (void)hipFreeAsync(tmp, st);
         *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
         return true;
     }

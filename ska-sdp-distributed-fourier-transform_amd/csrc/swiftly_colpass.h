@@ -198,7 +198,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
 
     // ---- input rows: lane `slot` describes row i = t + slot*T
     int in_row;         // element offset row*pitch is formed later; -1 = zero (padding)
-    int in_row2 = -1;   // GS: second source row
+    long long gs_off1 = -1, gs_off2 = -1;  // GS: element offsets of the (up to) two source rows, -1 = none
     float in_w = 1.f;
     {
         const int i = t + slot * T;
@@ -212,8 +212,20 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             if (idx >= A.ld_mod) idx -= A.ld_mod;
             const bool ok = q < A.ld_len;
             if constexpr (GS) {
-                in_row2 = ok ? A.ld_rowmap[FN + idx] : -1;
-                in_row = ok ? A.ld_rowmap[idx] : -1;
+                // (resolved here, outside the load loop's lambda: a by-reference capture of `cz` with a dynamic
+                // index would make the compiler copy the whole table to scratch)
+                constexpr int RM = (1 << kGsRowBits) - 1;
+                const int r1 = ok ? A.ld_rowmap[idx] : -1;
+                const int r2 = ok ? A.ld_rowmap[FN + idx] : -1;
+                if (r1 >= 0) {
+                    const int c = r1 >> kGsRowBits;
+                    gs_off1 = cz.c_base[c] + (long long)zf * cz.c_fs[c] + (long long)(r1 & RM) * A.in_pitch;
+                }
+                if (r2 >= 0) {
+                    const int c = r2 >> kGsRowBits;
+                    gs_off2 = cz.c_base[c] + (long long)zf * cz.c_fs[c] + (long long)(r2 & RM) * A.in_pitch;
+                }
+                in_row = r1;
             } else {
                 if (A.ld_rowmap) idx = A.ld_rowmap[ok ? idx : 0];
                 in_row = ok ? idx : -1;
@@ -259,16 +271,16 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         const int row = __builtin_amdgcn_readlane(in_row, v);
         cx<float> val = {0.f, 0.f};
         if constexpr (GS) {
-            constexpr int RM = (1 << kGsRowBits) - 1;
-            if (row >= 0) {  // uniform
-                const int c = row >> kGsRowBits;
-                if (live) val = cp_load<NT_LD>(in + cz.c_base[c] + (long long)zf * cz.c_fs[c] + (unsigned)(row & RM) * A.in_pitch);
+            const int lo1 = __builtin_amdgcn_readlane((int)gs_off1, v), hi1 = __builtin_amdgcn_readlane((int)(gs_off1 >> 32), v);
+            if (hi1 >= 0) {  // uniform
+                const long long o1 = ((long long)hi1 << 32) | (unsigned)lo1;
+                if (live) val = cp_load<NT_LD>(in + o1);
             }
-            const int row2 = __builtin_amdgcn_readlane(in_row2, v);
-            if (row2 >= 0) {  // uniform
-                const int c = row2 >> kGsRowBits;
+            const int lo2 = __builtin_amdgcn_readlane((int)gs_off2, v), hi2 = __builtin_amdgcn_readlane((int)(gs_off2 >> 32), v);
+            if (hi2 >= 0) {  // uniform
+                const long long o2 = ((long long)hi2 << 32) | (unsigned)lo2;
                 if (live) {
-                    const cx<float> w2 = cp_load<NT_LD>(in + cz.c_base[c] + (long long)zf * cz.c_fs[c] + (unsigned)(row2 & RM) * A.in_pitch);
+                    const cx<float> w2 = cp_load<NT_LD>(in + o2);
                     val.x += w2.x;
                     val.y += w2.y;
                 }

@@ -423,16 +423,30 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb, (short)0, (int)out_bytes, 0x00020000);
 #endif
     if constexpr (ST == 2) {
+        // ONE output window (the host combines mask and 1/PSWF), fetched for all P outputs of the lane before the
+        // last butterflies: a load per output inside the store loop costs a full memory latency per element
+        // (measured: 4.4 ms per 22528^2 facet with two dependent window loads per output)
         const unsigned vlen = (unsigned)A.st_len;
         const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.st_win), (short)0, (int)(A.st_win ? vlen << 2 : 0u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.st_win2), (short)0, (int)(A.st_win2 ? vlen << 2 : 0u), 0x00020000);
-        const bool has1 = A.st_win != nullptr, has2 = A.st_win2 != nullptr;  // uniform
-        fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
+        const bool has1 = A.st_win != nullptr;  // uniform
+        // outputs of a lane come in runs of CH slots whose indices differ by q << LNS (phase_scatter): the windows of
+        // a run are fetched together right before its stores
+        constexpr int LR = G::LOGN % G::LOGP == 0 ? G::LOGP : G::LOGN % G::LOGP, LNS = G::LOGN - LR;
+        constexpr int CH = (1 << LR) < 16 ? (1 << LR) : 16;
+        float wv[CH];
+        fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v, auto sI) {
+            constexpr int s = decltype(sI)::value;
+            if constexpr (s % CH == 0) {
+                static_for<0, CH>([&](auto qI) {
+                    constexpr int q = decltype(qI)::value;
+                    const int ckq = (2 * (e + (q << LNS)) + h) ^ (N >> 1);
+                    const int dq = (ckq + A.st_a) & (N - 1);
+                    wv[q] = has1 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w1, dq << 2, 0, 0)) : 1.f;
+                });
+            }
             const int ck = (2 * e + h) ^ (N >> 1);
             const int d = (ck + A.st_a) & (N - 1);
-            float w = scale;
-            if (has1) w *= __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w1, d << 2, 0, 0));
-            if (has2) w *= __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w2, d << 2, 0, 0));
+            const float w = scale * wv[s % CH];
             if (d < A.st_len) {
                 f32x2 val = {v.x * w, v.y * w * sg_st};
                 if (A.accumulate) {
