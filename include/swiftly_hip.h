@@ -354,6 +354,10 @@ int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, in
  *   part_row_stride (elements; row = b*m + k for contiguous [m, m] blocks).  Chunks (<= 16) are the pieces of a
  *   multi-GPU receive buffer; a single-process caller passes one chunk.  masks: device float [nfacets][facet_size]
  *   or NULL.  bands[f] = [facet_size rows][band_len] plain column order, read-modify-written (zero it first).
+ *   touched: optional device bytes [band_len], zero before the first call: band columns whose byte is 0 have not
+ *   been written yet and are stored plainly (bands need no zero fill, no read of the old value); the call then marks
+ *   its columns.  band_zero_untouched clears the columns no call has written (bands[rows][band_len], rows = all
+ *   facets' rows when the facets are contiguous) -- call it before finish_facet_band.  NULL: always read-modify-write.
  *   workspace: optional device scratch (nfacets*yN*m*8 bytes used when large enough), else stream-ordered allocation.
  * finish_facet_band: finish_facet (core.py:481-510) along the contiguous axis of a band accumulator row:
  *     out[r, :] = mask * Fb * crop( FFT_yN( band row r placed at columns band_start + d, zero elsewhere ) ). */
@@ -363,7 +367,10 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
                                          int64_t nfacets, const int64_t* facet_off0s, int64_t facet_size,
                                          const float* masks, int64_t subgrid_off1, void* bands, int64_t band_row_stride,
                                          int64_t band_facet_stride, int64_t band_start, int64_t band_len,
-                                         void* workspace, int64_t workspace_bytes, void* stream);
+                                         unsigned char* touched, void* workspace, int64_t workspace_bytes,
+                                         void* stream);
+int swiftly_hip_band_zero_untouched(swiftly_hip_t* h, int dtype, void* bands, int64_t rows, int64_t band_row_stride,
+                                    int64_t band_len, const unsigned char* touched, void* stream);
 int swiftly_hip_finish_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
                                   int64_t band_start, int64_t band_len, void* out, int64_t out_row_stride,
                                   int64_t facet_off, int64_t facet_size, const void* mask, void* stream);

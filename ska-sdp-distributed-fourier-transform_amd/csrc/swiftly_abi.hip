@@ -600,6 +600,23 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
 }
 
 
+// touched[d] = 1 for the band columns d of one wave's window (see accumulate_facet_columns)
+__global__ void mark_columns_kernel(unsigned char* __restrict__ touched, int m, int rot, int base, int yN, int band_start,
+                                    int band_len) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= m) return;
+    const int scol = (base + ((col + rot) & (m - 1))) & (yN - 1);
+    const int d = (scol - band_start) & (yN - 1);
+    if (d < band_len) touched[d] = 1;
+}
+// zero the band columns no wave has written (rows x band_len, row stride `pitch`)
+__global__ void zero_untouched_kernel(cx<float>* __restrict__ band, const unsigned char* __restrict__ touched, long long rows,
+                                      long long pitch, int band_len) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= band_len || touched[d]) return;
+    for (long long r = blockIdx.y; r < rows; r += gridDim.y) band[r * pitch + d] = cx<float>{0.f, 0.f};
+}
+
 __global__ void mul_windows_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] * b[i];
@@ -1670,7 +1687,8 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
                                          int64_t nfacets, const int64_t* facet_off0s, int64_t facet_size,
                                          const float* masks, int64_t subgrid_off1, void* bands, int64_t band_row_stride,
                                          int64_t band_facet_stride, int64_t band_start, int64_t band_len,
-                                         void* workspace, int64_t workspace_bytes, void* stream) {
+                                         unsigned char* touched, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
     if (!h || !parts || !bands || !chunk_offsets || !chunk_facet_strides || !row_sources || !facet_off0s)
         return fail(SWIFTLY_ERR_PARAM, "null argument");
     DeviceGuard device_guard_(h->device);
@@ -1701,6 +1719,7 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
     c.st_win2 = h->invp_f + lo;
     c.scale = 1.f;
     c.accumulate = 1;
+    c.touched = touched;
     c.cg_mod = m; c.cg_full = yN;
     c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = 0;
     const int64_t cap = workspace ? workspace_bytes : (int64_t(4) << 30);
@@ -1726,6 +1745,24 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
         if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: padded facet size %d not supported", yN);
         if (rc) return rc;
     }
+    if (touched) {
+        hipLaunchKernelGGL(mark_columns_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, touched,
+                           m, pmod(-s1, m), pmod(yN / 2 - m / 2 + s1, yN), yN, (int)band_start, (int)band_len);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int swiftly_hip_band_zero_untouched(swiftly_hip_t* h, int dtype, void* bands, int64_t rows, int64_t band_row_stride,
+                                    int64_t band_len, const unsigned char* touched, void* stream) {
+    if (!h || !bands || !touched) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "band_zero_untouched: complex64 only");
+    if (rows <= 0 || band_len <= 0) return 0;
+    dim3 grid((unsigned)((band_len + 63) / 64), (unsigned)std::min<int64_t>(rows, 1024));
+    hipLaunchKernelGGL(zero_untouched_kernel, grid, dim3(64), 0, (hipStream_t)stream, (cx<float>*)bands, touched,
+                       (long long)rows, (long long)band_row_stride, (int)band_len);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -61,6 +61,9 @@ struct ColPassArgs {
     // ld_rowmap[2^full_logn + idx]  (negative = none), each encoded  chunk << 20 | row  and read at
     // in + cz.c_base[chunk] + facet * cz.c_fs[chunk] + row * in_pitch  (chunks = pieces of a multi-GPU receive buffer)
     int gs;
+    // accumulate only: optional per-OUTPUT-column flags (device bytes, indexed by the column written); a column whose
+    // flag is 0 has not been written yet and is stored plainly (no read-modify-write, no zero fill needed)
+    const unsigned char* touched;
     int ncols;                      // columns (= rows of the primitive)
     int full_logn;                  // log2 of the full transform length the maps refer to
     // load: raw -> row = o*in_o_rows + i*in_i_rows ; mapped -> plain index i*ld_mul + o through the map
@@ -194,6 +197,8 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
     const float sg_st = A.conj_st ? -1.f : 1.f;
     const float col_w = (A.col_win && live) ? A.col_win[col] : 1.f;
+    bool rmw = A.accumulate != 0;
+    if (!RAW_ST && A.accumulate && A.touched && live) rmw = A.touched[ocol] != 0;
     const int slot = lane & (P - 1);
 
     // ---- input rows: lane `slot` describes row i = t + slot*T
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             v.y *= w * sg_st;
             cx<float>* p = out + (unsigned)row * A.out_pitch;
             if (A.accumulate) {
-                if (live) {
+                if (live && rmw) {
                     const cx<float> old = *p;
                     v.x += old.x;
                     v.y += old.y;

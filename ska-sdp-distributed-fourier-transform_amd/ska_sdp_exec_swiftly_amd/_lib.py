@@ -101,8 +101,10 @@ def _declare(lib):
     ]
     lib.swiftly_hip_accumulate_facet_columns.restype = c_int
     lib.swiftly_hip_accumulate_facet_columns.argtypes = [
-        vp, c_int, vp, i64, i64, pi64, pi64, vp, i64, pi64, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp,
+        vp, c_int, vp, i64, i64, pi64, pi64, vp, i64, pi64, i64, vp, i64, vp, i64, i64, i64, i64, vp, vp, i64, vp,
     ]
+    lib.swiftly_hip_band_zero_untouched.restype = c_int
+    lib.swiftly_hip_band_zero_untouched.argtypes = [vp, c_int, vp, i64, i64, i64, vp, vp]
     lib.swiftly_hip_finish_facet_band.restype = c_int
     lib.swiftly_hip_finish_facet_band.argtypes = [vp, c_int, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp]
     lib.swiftly_hip_malloc.restype = c_int

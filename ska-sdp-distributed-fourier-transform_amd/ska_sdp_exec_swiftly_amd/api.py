@@ -1123,7 +1123,9 @@ class SwiftlyBackward:
             self._band = core.band_for_offsets([sg.off1 for sg in self._plan]) if self._plan else (0, core.yN_size)
             self._planned = {sg.off1 for sg in self._plan} if self._plan else None
             F = len(self.facets_config_list)
-            self._bands = torch.zeros((F, yB, self._band[1]), dtype=dtype, device=core.device)
+            # uninitialised: first-write flags per band column replace the zero fill
+            self._bands = torch.empty((F, yB, self._band[1]), dtype=dtype, device=core.device)
+            self._touched = torch.zeros((self._band[1],), dtype=torch.uint8, device=core.device)
             self._masks0 = _mask_table(core, self.facets_config_list, "mask0", yB, dtype)
             self._facet_off0s = [cfg.off0 for cfg in self.facets_config_list]
             self._work = torch.empty((F, core.yN_size, core.xM_yN_size), dtype=dtype, device=core.device)
@@ -1161,7 +1163,7 @@ class SwiftlyBackward:
             raise ValueError(f"at most {core.GS_MAX_CHUNKS} contribution chunks per wave")
         for _members, table in core.column_row_sources(off0s, locs):
             core.accumulate_facet_columns(base, m, offs, fstr, table, self._facet_off0s, bands.shape[1], self._masks0,
-                                          off1, bands, self._band, workspace=self._work)
+                                          off1, bands, self._band, workspace=self._work, touched=self._touched)
         return bands
 
     def _finish_bands(self):
@@ -1171,6 +1173,7 @@ class SwiftlyBackward:
         if self._bands is None:
             dt = self.dtype or torch.complex64
             return [torch.zeros((cfg.size, cfg.size), dtype=dt, device=core.device) for cfg in self.facets_config_list]
+        core.band_zero_untouched(self._bands, self._touched)
         for j, cfg in enumerate(self.facets_config_list):
             out.append(core.finish_facet_band(self._bands[j], self._band, cfg.off1, cfg.size, mask=cfg.mask1))
         self._bands = None

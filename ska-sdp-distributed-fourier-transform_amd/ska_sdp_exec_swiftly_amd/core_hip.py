@@ -680,11 +680,12 @@ class SwiftlyCoreHip:
         return out
 
     def accumulate_facet_columns(self, parts, part_row_stride, chunk_offsets, chunk_facet_strides, table, facet_off0s,
-                                 facet_size, masks, subgrid_off1, bands, band, workspace=None):
+                                 facet_size, masks, subgrid_off1, bands, band, workspace=None, touched=None):
         """``bands[f] += mask0_f * finish_facet_axis0(sum_b add_to_facet_axis0(C[f][b]))`` placed at the band columns
         of ``subgrid_off1`` (``swiftly_hip_accumulate_facet_columns``, include/swiftly_hip.h).  ``parts``: device
         tensor holding the contribution blocks (chunk offsets / facet strides in elements relative to its start),
-        ``bands``: ``[F, facet_size, band length]``, ``masks``: float32 ``[F, facet_size]`` or None."""
+        ``bands``: ``[F, facet_size, band length]``, ``masks``: float32 ``[F, facet_size]`` or None, ``touched``: uint8
+        ``[band length]`` first-write flags (then ``bands`` may start uninitialised; :py:meth:`band_zero_untouched`)."""
         F = bands.shape[0]
         nch = len(chunk_offsets)
         cvp = ctypes.c_void_p
@@ -694,11 +695,24 @@ class SwiftlyCoreHip:
                 self._i64(chunk_offsets), self._i64(chunk_facet_strides), cvp(table.data_ptr()), F,
                 self._i64(facet_off0s), int(facet_size), cvp(masks.data_ptr()) if masks is not None else None,
                 int(subgrid_off1), cvp(bands.data_ptr()), bands.stride(1), bands.stride(0), int(band[0]), int(band[1]),
+                cvp(touched.data_ptr()) if touched is not None else None,
                 cvp(workspace.data_ptr()) if workspace is not None else None,
                 workspace.numel() * workspace.element_size() if workspace is not None else 0, self._stream(),
             )
         )
         return bands
+
+    def band_zero_untouched(self, bands, touched):
+        """Clear the band columns no :py:meth:`accumulate_facet_columns` call has written."""
+        if not bands.is_contiguous():
+            raise ValueError("band accumulators must be contiguous")
+        rows = bands.numel() // bands.shape[-1]
+        _lib.check(
+            self._lib.swiftly_hip_band_zero_untouched(
+                self._handle, self._code(bands), ctypes.c_void_p(bands.data_ptr()), rows, bands.shape[-1],
+                bands.shape[-1], ctypes.c_void_p(touched.data_ptr()), self._stream(),
+            )
+        )
 
     def finish_facet_band(self, band_acc, band, facet_off, facet_size, mask=None, out=None):
         """``finish_facet`` (core.py:481-510) along the contiguous axis for a band accumulator ``[rows, band
