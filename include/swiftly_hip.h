@@ -328,18 +328,41 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
  *   (finish_subgrid along axis 0 with mask0) -> out[nsub][subgrid_size][subgrid_size] for the blocks g[f][b] of ALL
  *   facets (facet order = order of facet_off0s / facet_off1s, e.g. arrival order of the exchange).
  * Host arrays: facet / subgrid offsets, g_offsets, g_facet_strides.  masks: device, real, [nsub][subgrid_size] with
- * batch strides (0 = shared), or NULL. */
+ * batch strides (0 = shared), or NULL.  scratch / scratch_bytes: optional device scratch for the four-step
+ * intermediates (facet side: nfacets*yN*m*8 bytes, subgrid side: min(nsub, 64)*xM*subgrid_size*8 bytes); NULL or too
+ * small = stream-ordered allocation, which costs ~2 ms of host time per call when the size changes between calls. */
 int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
                                 int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
                                 int64_t band_start, int64_t band_len, int64_t wave_off1, const int32_t* rowmap,
                                 int64_t n_rows, void* q_work, int64_t q_facet_stride, int compute_q, int64_t nsub,
                                 const int64_t* sub_off0s, void* g_out, int64_t g_facet_stride, int64_t g_sub_stride,
-                                const int64_t* g_offsets, const int64_t* g_facet_strides, void* stream);
+                                const int64_t* g_offsets, const int64_t* g_facet_strides, void* scratch,
+                                int64_t scratch_bytes, void* stream);
 int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
                                   int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
                                   int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
                                   const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
-                                  void* tmp_work, void* out, void* stream);
+                                  void* tmp_work, void* out, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* Backward subgrid side for all facets at once (mirror of sum_finish_facets): in[b] = [xM, subgrid_size] =
+ * prepare_subgrid of subgrid b along axis 0 ONLY (core.py:328-368); out[f][b] = [m, m] contiguous = the contribution
+ * of subgrid b to facet f, i.e. api_helper.prepare_and_split_subgrid (api_helper.py:115-139): prepare_subgrid along
+ * axis 1 and both extract_from_subgrid (core.py:396-439).  The prepared [xM, xM] subgrid and the per-off0
+ * intermediates never reach HBM.  (m, xM) pairs of sum_finish_facets; up to 64 facets. */
+int swiftly_hip_split_prepare_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t in_sub_stride,
+                                     int64_t in_row_stride, int64_t subgrid_size, int64_t nsub,
+                                     const int64_t* subgrid_off1s, int64_t nfacets, const int64_t* facet_off0s,
+                                     const int64_t* facet_off1s, void* out, int64_t out_facet_stride,
+                                     int64_t out_sub_stride, void* stream);
+
+/* The subgrid side of one backward wave in ONE native call without stream-ordered allocations: prepare_subgrid along
+ * axis 0 of subgrids[nsub][subgrid_size][subgrid_size] (contiguous) followed by split_prepare_facets.  work: device
+ * scratch of work_elems >= 2 * nsub * xM * subgrid_size complex64 elements. */
+int swiftly_hip_wave_split_subgrids(swiftly_hip_t* h, int dtype, const void* subgrids, int64_t subgrid_size, int64_t nsub,
+                                    const int64_t* subgrid_off0s, const int64_t* subgrid_off1s, int64_t nfacets,
+                                    const int64_t* facet_off0s, const int64_t* facet_off1s, void* work,
+                                    int64_t work_elems, void* out, int64_t out_facet_stride, int64_t out_sub_stride,
+                                    void* stream);
 
 /* Backward pass with the contiguous-axis transform LAST (mirror of prepare_facet_band / prepare_facet_columns;
  * waves = subgrids sharing off1).  Replaces, for all facets of a wave, api_helper.accumulate_column +

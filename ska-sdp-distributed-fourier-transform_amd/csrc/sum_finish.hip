@@ -31,6 +31,20 @@ static int init_one_f() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
 }
 
+template <int LOGM, int LOGX>
+static int launch_one_s(const SplitFacetArgs& a, int nbatch, hipStream_t s) {
+    using S = SFGeo<LOGM, LOGX>;
+    dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
+    hipLaunchKernelGGL((split_prepare_facets_kernel<LOGM, LOGX>), grid, dim3(256), S::LDS_BYTES, s, a);
+    return (int)hipGetLastError();
+}
+template <int LOGM, int LOGX>
+static int init_one_s() {
+    using S = SFGeo<LOGM, LOGX>;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_prepare_facets_kernel<LOGM, LOGX>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+}
+
 #define SF_PAIRS(X) X(7, 8) X(7, 10) X(8, 9) X(8, 10) X(9, 10) X(9, 11) X(10, 11)
 
 int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s) {
@@ -47,11 +61,19 @@ int launch_sum_finish_facets(int logm, int logx, const SumFinishFacetArgs& a, in
 #undef SF_CASE_F
     return -1;
 }
+int launch_split_prepare_facets(int logm, int logx, const SplitFacetArgs& a, int nbatch, hipStream_t s) {
+#define SF_CASE_S(M, XX) \
+    if (logm == M && logx == XX) return launch_one_s<M, XX>(a, nbatch, s);
+    SF_PAIRS(SF_CASE_S)
+#undef SF_CASE_S
+    return -1;
+}
 int init_sum_finish_rows() {
     int rc = 0;
 #define SF_INIT(M, XX)               \
     if (!rc) rc = init_one<M, XX>(); \
-    if (!rc) rc = init_one_f<M, XX>();
+    if (!rc) rc = init_one_f<M, XX>(); \
+    if (!rc) rc = init_one_s<M, XX>();
     SF_PAIRS(SF_INIT)
 #undef SF_INIT
     return rc;

@@ -463,8 +463,23 @@ static int launch_col_checked(int lg, int mode, const ColPassArgs& args, const C
 // `c` carries the load / store maps, windows, conjugation flags, scale, batch strides, column gather and row
 // maps of the whole transform; in/out pitches and pointers are given separately.  Returns -1 when the length
 // is outside the column-pass range (caller falls back), else a status code.
+// Scratch handed down by an entry point for the duration of one ABI call on this host thread (the batch entry
+// points have no workspace parameter): col_transform prefers it to a stream-ordered allocation.  Measured on
+// MI355X: hipMallocAsync with a size that changes from call to call costs ~2 ms of HOST time per call (the pool
+// does not reuse a smaller free block), which made a 25-wave pass host-bound.
+static thread_local void* t_call_ws = nullptr;
+static thread_local size_t t_call_ws_bytes = 0;
+struct CallWorkspace {
+    CallWorkspace(void* p, size_t bytes) { t_call_ws = p; t_call_ws_bytes = p ? bytes : 0; }
+    ~CallWorkspace() { t_call_ws = nullptr; t_call_ws_bytes = 0; }
+};
+
 static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st,
                          void* ws = nullptr, size_t ws_bytes = 0) {
+    if (!ws && t_call_ws) {
+        ws = t_call_ws;
+        ws_bytes = t_call_ws_bytes;
+    }
     const bool two = logn > kColPassMaxLog;  // single pass up to 512 points (1024 threads x 32 points)
     static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
     const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
@@ -1623,6 +1638,127 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
     return 0;
 }
 
+/* Backward subgrid side, contiguous-axis half + axis-0 remainder (see swiftly_sumfinish.h): in[b] = [xM, xA] =
+ * prepare_subgrid(axis 0) of subgrid b; out[f][b] = [m, m] = the contribution of subgrid b to facet f
+ * (api_helper.prepare_and_split_subgrid, api_helper.py:115-139). */
+int swiftly_hip_split_prepare_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t in_sub_stride,
+                                     int64_t in_row_stride, int64_t subgrid_size, int64_t nsub,
+                                     const int64_t* subgrid_off1s, int64_t nfacets, const int64_t* facet_off0s,
+                                     const int64_t* facet_off1s, void* out, int64_t out_facet_stride,
+                                     int64_t out_sub_stride, void* stream) {
+    if (!h || !in || !out || !facet_off0s || !facet_off1s || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    CHECK_SUBGRID_SIZE();
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "split_prepare_facets: complex64 only");
+    if (nfacets <= 0 || nfacets > kSumFinishMaxFacets)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "split_prepare_facets: 1..%d facets supported", kSumFinishMaxFacets);
+    if (!sum_finish_supported(h->log_m, h->log_xM) || h->log_m > kColPassMaxLog)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "split_prepare_facets: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
+                    (long long)h->xM);
+    if (nsub <= 0) return 0;
+    const int xM = (int)h->xM, xA = (int)subgrid_size, m = (int)h->m;
+    SplitFacetArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in_bs = in_sub_stride; a.in_rs = in_row_stride;
+    a.out_fs = out_facet_stride; a.out_bs = out_sub_stride; a.out_rs = m;
+    a.nrows = xM;
+    a.nfacets = (int)nfacets;
+    a.xA = xA;
+    for (int f = 0; f < nfacets; f++) {
+        const int sp0 = (int)floordiv(facet_off0s[f] * h->xM, h->N);
+        a.base0[f] = pmod(xM / 2 - m / 2 + sp0, xM);
+        a.sp1[f] = (int)floordiv(facet_off1s[f] * h->xM, h->N);
+    }
+    a.fn = h->fn_f;
+    a.tw_m = twiddles<float>(h, h->log_m);
+    a.tw_x = twiddles<float>(h, h->log_xM);
+    if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
+    for (int64_t b0 = 0; b0 < nsub; b0 += kSumFinishMaxBatch) {
+        const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nsub - b0);
+        a.in = (const cx<float>*)in + b0 * in_sub_stride;
+        a.out = (cx<float>*)out + b0 * out_sub_stride;
+        for (int b = 0; b < nb; b++) a.ld_a[b] = pmod(-(xM / 2 - xA / 2 + subgrid_off1s[b0 + b]), xM);
+        int e = launch_split_prepare_facets(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
+        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    // axis-0 remainder of extract_from_subgrid, in place: out[f][b][:, j] = cifft_m( Fn[k] * E[f][b][(k - s'0_f) ..., j] )
+    ColPassArgs c;
+    std::memset(&c, 0, sizeof c);
+    c.ncols = m;
+    c.full_logn = h->log_m;
+    c.in_pitch = c.out_pitch = (unsigned)m;
+    c.ld_mul = c.st_mul = 1;
+    c.ld_a = 0; c.ld_len = m; c.ld_c = 0; c.ld_mod = m;
+    c.ld_win = h->fn_f;
+    c.st_a = 0; c.st_len = m; c.st_c = 0; c.st_mod = m;
+    c.conj_ld = c.conj_st = 1;
+    c.scale = 1.f / (float)m;
+    c.tw = a.tw_m;
+    for (int64_t f0 = 0; f0 < nfacets; f0 += kColZF) {
+        const int nf = (int)std::min<int64_t>(kColZF, nfacets - f0);
+        for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
+            const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
+            ColZ cz = plain_colz();
+            cz.nb = nb;
+            cz.flags = kZLoadAF;
+            for (int f = 0; f < nf; f++) cz.f_lda[f] = pmod(-floordiv(facet_off0s[f0 + f] * h->xM, h->N), m);
+            c.in = (const cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
+            c.in_bdiv = nb; c.in_bs_hi = out_facet_stride; c.in_bs = out_sub_stride;
+            c.out = (cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
+            c.out_bdiv = nb; c.out_bs_hi = out_facet_stride; c.out_bs = out_sub_stride;
+            if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, nf * nb, (hipStream_t)stream)) return rc;
+        }
+    }
+    return 0;
+}
+
+/* The whole subgrid side of one backward wave natively, without stream-ordered allocations: prepare_subgrid along
+ * axis 0 (four-step through `work`) + split_prepare_facets.  work: device scratch of >= 2 * nsub * xM * subgrid_size
+ * complex64 elements (first half: tmp[nsub][xM][subgrid_size], second half: four-step scratch). */
+int swiftly_hip_wave_split_subgrids(swiftly_hip_t* h, int dtype, const void* subgrids, int64_t subgrid_size, int64_t nsub,
+                                    const int64_t* subgrid_off0s, const int64_t* subgrid_off1s, int64_t nfacets,
+                                    const int64_t* facet_off0s, const int64_t* facet_off1s, void* work,
+                                    int64_t work_elems, void* out, int64_t out_facet_stride, int64_t out_sub_stride,
+                                    void* stream) {
+    if (!h || !subgrids || !work || !out || !subgrid_off0s || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    CHECK_SUBGRID_SIZE();
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_split_subgrids: complex64 only");
+    if (nsub <= 0 || nfacets <= 0) return 0;
+    const int xM = (int)h->xM, xA = (int)subgrid_size;
+    const int64_t half = nsub * (int64_t)xM * xA;
+    if (work_elems < 2 * half) return fail(SWIFTLY_ERR_PARAM, "work holds %lld elements, %lld needed", (long long)work_elems, (long long)(2 * half));
+    cx<float>* tmp = (cx<float>*)work;
+    ColPassArgs c;
+    std::memset(&c, 0, sizeof c);
+    c.ncols = xA;
+    c.full_logn = h->log_xM;
+    c.in_pitch = c.out_pitch = (unsigned)xA;
+    c.ld_mul = c.st_mul = 1;
+    c.ld_a = 0; c.ld_len = xA; c.ld_c = 0; c.ld_mod = xA;
+    c.st_a = 0; c.st_len = xM; c.st_c = 0; c.st_mod = xM;
+    c.scale = 1.f;
+    for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
+        const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
+        ColZ cz = plain_colz();
+        cz.nb = nb;
+        cz.flags = kZLoadB;
+        for (int b = 0; b < nb; b++) {
+            cz.b_lda[b] = pmod(-(xM / 2 - xA / 2 + subgrid_off0s[b0 + b]), xM);
+            cz.b_ldc[b] = 0;
+        }
+        c.in = (const cx<float>*)subgrids + b0 * (int64_t)xA * xA;
+        c.in_bs = (long long)xA * xA;
+        c.out = tmp + b0 * (int64_t)xM * xA;
+        c.out_bs = (long long)xM * xA;
+        const int rc = col_transform(h, h->log_xM, c, cz, xA, nb, (hipStream_t)stream, tmp + half, (size_t)half * sizeof(cx<float>));
+        if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_split_subgrids: padded subgrid size %d not supported", xM);
+        if (rc) return rc;
+    }
+    return swiftly_hip_split_prepare_facets(h, dtype, tmp, (int64_t)xM * xA, xA, subgrid_size, nsub, subgrid_off1s, nfacets,
+                                            facet_off0s, facet_off1s, out, out_facet_stride, out_sub_stride, stream);
+}
+
 
 /* One forward wave in two calls (the whole launch sequence runs natively: per-wave host work is two ABI calls). */
 int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
@@ -1631,20 +1767,20 @@ int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, 
                                 int64_t n_rows, void* q_work, int64_t q_facet_stride, int compute_q, int64_t nsub,
                                 const int64_t* sub_off0s, void* g_out,
                                 int64_t g_facet_stride, int64_t g_sub_stride, const int64_t* g_offsets,
-                                const int64_t* g_facet_strides, void* stream) {
+                                const int64_t* g_facet_strides, void* scratch, int64_t scratch_bytes, void* stream) {
     if (!h || (!bands && compute_q) || !q_work || !g_out || !facet_off0s || !sub_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (nfacets <= 0 || nsub <= 0) return 0;
     const int64_t m = h->m;
     if (n_rows <= 0 || n_rows > h->yN || q_facet_stride < n_rows * m)
         return fail(SWIFTLY_ERR_PARAM, "bad row count %lld / facet stride %lld", (long long)n_rows, (long long)q_facet_stride);
     // K2: Q[f] = [n_rows, m] (skipped when the caller still holds the wave's Q: compute_q = 0)
+    DeviceGuard device_guard_(h->device);
     if (compute_q) {
-        int rc = swiftly_hip_prepare_facet_columns(h, dtype, bands, rows, band_row_stride, band_facet_stride, nfacets,
-                                                   facet_off0s, band_start, band_len, wave_off1, q_work, m, q_facet_stride,
-                                                   rowmap, stream);
+        int rc = prepare_facet_columns_impl(h, dtype, bands, rows, band_row_stride, band_facet_stride, nfacets, facet_off0s,
+                                            band_start, band_len, 1, &wave_off1, q_work, m, q_facet_stride, 0, rowmap, 0,
+                                            stream, scratch, scratch ? (size_t)scratch_bytes : 0);
         if (rc) return rc;
     }
-    DeviceGuard device_guard_(h->device);
     // K3 + K4a from Q (layout 1)
     return transform_contributions_impl(h, dtype, q_work, 1, m, q_facet_stride, 0, rowmap, 0, 0, nfacets, facet_off0s, nsub,
                                         sub_off0s, g_out, g_facet_stride, g_sub_stride, g_offsets, g_facet_strides, stream);
@@ -1654,7 +1790,7 @@ int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, in
                                   int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
                                   int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
                                   const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
-                                  void* tmp_work, void* out, void* stream) {
+                                  void* tmp_work, void* out, void* scratch, int64_t scratch_bytes, void* stream) {
     if (!h || !g || !tmp_work || !out || !sub_off0s || !sub_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (nsub <= 0) return 0;
     const int64_t m = h->m, xM = h->xM, xA = subgrid_size;
@@ -1663,6 +1799,7 @@ int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, in
                                            tmp_work, xM * xA, xA, sub_off1s, subgrid_size, mask1, mask1_bs, nsub, stream);
     if (rc) return rc;
     // K5b: finish_subgrid along axis 0 (strided): rows of the op = xA columns
+    CallWorkspace call_ws(scratch, scratch ? (size_t)scratch_bytes : 0);
     return swiftly_hip_finish_subgrid_batch(h, dtype, tmp_work, xA, 1, xA, out, 1, xA, 0, subgrid_size, mask0, nsub,
                                             xM * xA, xA * xA, sub_off0s, mask0 ? mask0_bs : 0, stream);
 }

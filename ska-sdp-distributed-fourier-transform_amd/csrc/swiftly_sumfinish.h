@@ -223,6 +223,89 @@ __global__ __launch_bounds__(256) void sum_finish_facets_kernel(const SumFinishF
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "prepare + split over FACETS": the mirror of sum_finish_facets_kernel for the backward pass -- the contiguous-axis
+// half of api_helper.prepare_and_split_subgrid (api_helper.py:115-139) for all facets at once.
+//
+// Input: tmp[b] = [xM, xA] = prepare_subgrid along axis 0 of subgrid b (core.py:328-368).  For every padded row r:
+//     P    = cfft_xM( pad(tmp[b][r, :], off1_b) )                          prepare_subgrid(axis 1), kept in LDS
+//     E[f][b][k_f(r), :] = cifft_m( Fn * P[window of facet f's off1] )      extract_from_subgrid(axis 1), core.py:396-439
+// for every facet f whose axis-0 band covers r (k_f(r) = (r - base0_f) mod xM < m).  The [xM, xM] prepared subgrid
+// and the per-off0 intermediates [m, xM] never exist in HBM; the remaining axis-0 half of extract_from_subgrid
+// (window Fn over k, inverse transform of length m) is one column pass over E (swiftly_hip_split_prepare_facets).
+struct SplitFacetArgs {
+    const cx<float>* in;   // tmp[b][r][xA]
+    cx<float>* out;        // E[f][b][k][m]
+    long long in_bs, in_rs;
+    long long out_fs, out_bs, out_rs;
+    int nrows;             // padded rows per subgrid (xM)
+    int nfacets, xA;
+    int base0[kSumFinishMaxFacets];  // (xM/2 - m/2 + s'0_f) mod xM
+    int sp1[kSumFinishMaxFacets];    // s'1_f
+    int ld_a[kSumFinishMaxBatch];    // (-(xM/2 - xA//2 + off1_b)) mod xM per subgrid
+    const float* fn;
+    const cx<float>* tw_m;
+    const cx<float>* tw_x;
+};
+
+template <int LOGM, int LOGX>
+__global__ __launch_bounds__(256) void split_prepare_facets_kernel(const SplitFacetArgs A) {
+    using S = SFGeo<LOGM, LOGX>;
+    using GM = typename S::GM;
+    using GX = typename S::GX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cx<float>* ex_m = reinterpret_cast<cx<float>*>(smem);
+    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + S::LDS_M);
+    constexpr int M = GM::N, X = GX::N, PM = GM::P, PX = GX::P, TR = S::TR;
+    const int t = threadIdx.x % TR, rb = threadIdx.x / TR;
+    const int b = blockIdx.y;
+    const int row0 = blockIdx.x * S::RB;
+    const int row = row0 + rb;
+    const bool live = row < A.nrows;
+
+    {   // prepare_subgrid along the row: zero-pad + shift on load, forward transform, result kept in LDS (array order)
+        const cx<float>* __restrict__ in = A.in + (long long)b * A.in_bs + (long long)(live ? row : 0) * A.in_rs;
+        const int lda = A.ld_a[b];
+        cx<float> y[PX];
+        static_for<0, PX>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            const int q = (((t + v * TR) ^ (X >> 1)) + lda) & (X - 1);
+            const bool ok = live && q < A.xA;
+            const cx<float> val = in[ok ? q : 0];
+            y[v] = ok ? val : cx<float>{0.f, 0.f};
+        });
+        fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
+            acc[lds_pos<GX>(rb, e ^ (X >> 1), false)] = v;
+        });
+        __syncthreads();
+    }
+    const float scale = 1.f / (float)M;
+    for (int f = 0; f < A.nfacets; f++) {
+        const int base = A.base0[f];
+        bool any = false;  // workgroup-uniform skip
+        for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
+        if (!any) continue;
+        const int k = (row - base) & (X - 1);
+        const bool on = live && k < M;
+        const int sp = A.sp1[f];
+        const int c1 = ((X >> 1) - (M >> 1) + sp) & (X - 1);
+        cx<float> x[PM];
+        static_for<0, PM>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            const int q = (((t + v * TR) ^ (M >> 1)) - sp) & (M - 1);
+            const cx<float> val = acc[lds_pos<GX>(rb, (q + c1) & (X - 1), false)];
+            const float w = A.fn[q];
+            x[v] = cx<float>{val.x * w, -val.y * w};  // inverse transform = conj(FFT(conj(.)))
+        });
+        cx<float>* __restrict__ out = A.out + (long long)f * A.out_fs + (long long)b * A.out_bs + (long long)(on ? k : 0) * A.out_rs;
+        fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+            if (on) out[e ^ (M >> 1)] = cx<float>{v.x * scale, -v.y * scale};
+        });
+        __syncthreads();  // ex_m is reused by the next facet
+    }
+}
+
+int launch_split_prepare_facets(int logm, int logx, const SplitFacetArgs& a, int nbatch, hipStream_t s);
 int launch_sum_finish_facets(int logm, int logx, const SumFinishFacetArgs& a, int nbatch, hipStream_t s);
 int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s);
 int init_sum_finish_rows();

@@ -89,7 +89,8 @@ def _declare(lib):
     ]
     lib.swiftly_hip_wave_facet_side.restype = c_int
     lib.swiftly_hip_wave_facet_side.argtypes = [
-        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, vp, i64, c_int, i64, pi64, vp, i64, i64, pi64, pi64, vp,
+        vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, vp, i64, c_int, i64, pi64, vp, i64, i64, pi64, pi64,
+        vp, i64, vp,
     ]
     lib.swiftly_hip_prepare_facet_columns_waves.restype = c_int
     lib.swiftly_hip_prepare_facet_columns_waves.argtypes = [
@@ -97,12 +98,16 @@ def _declare(lib):
     ]
     lib.swiftly_hip_wave_subgrid_side.restype = c_int
     lib.swiftly_hip_wave_subgrid_side.argtypes = [
-        vp, c_int, vp, i64, i64, i64, pi64, pi64, i64, pi64, pi64, i64, vp, i64, vp, i64, vp, vp, vp,
+        vp, c_int, vp, i64, i64, i64, pi64, pi64, i64, pi64, pi64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp,
     ]
     lib.swiftly_hip_accumulate_facet_columns.restype = c_int
     lib.swiftly_hip_accumulate_facet_columns.argtypes = [
         vp, c_int, vp, i64, i64, pi64, pi64, vp, i64, pi64, i64, vp, i64, vp, i64, i64, i64, i64, vp, vp, i64, vp,
     ]
+    lib.swiftly_hip_split_prepare_facets.restype = c_int
+    lib.swiftly_hip_split_prepare_facets.argtypes = [vp, c_int, vp, i64, i64, i64, i64, pi64, i64, pi64, pi64, vp, i64, i64, vp]
+    lib.swiftly_hip_wave_split_subgrids.restype = c_int
+    lib.swiftly_hip_wave_split_subgrids.argtypes = [vp, c_int, vp, i64, i64, pi64, pi64, i64, pi64, pi64, vp, i64, vp, i64, i64, vp]
     lib.swiftly_hip_band_zero_untouched.restype = c_int
     lib.swiftly_hip_band_zero_untouched.argtypes = [vp, c_int, vp, i64, i64, i64, vp, vp]
     lib.swiftly_hip_finish_facet_band.restype = c_int

@@ -972,6 +972,8 @@ class SwiftlyBackward:
         if self.wave_axis not in (0, 1):
             raise ValueError("wave_axis must be 0 or 1")
         self._plan = list(subgrid_configs) if subgrid_configs is not None else None
+        self._wsbuf = {}
+        self._ring = 0
         self._band = None
         self._bands = None
         self._work = None
@@ -1010,11 +1012,24 @@ class SwiftlyBackward:
             i = j
         return col
 
+    def _ws(self, name, shape, dtype):
+        """Grow-only persistent workspace (per-wave allocations of changing size are kept away from the caching
+        allocator: its misses are synchronous hipMallocs)."""
+        torch = _torch()
+        n = 1
+        for d in shape:
+            n *= int(d)
+        buf = self._wsbuf.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = self._wsbuf[name] = torch.empty((n,), dtype=dtype, device=self.core.device)
+        return buf[:n].view(*shape)
+
     def wave_contributions(self, sgs, subgrids):
         """``prepare_and_split_subgrid`` (reference api_helper.py:115-139) for a
         wave: contributions ``[F, S, m, m]`` of the subgrids ``sgs`` (same size)
         to every facet -- what the reference ships from the subgrid's worker to
-        the facets' workers (api.py:357-364)."""
+        the facets' workers (api.py:357-364).  On the fused route the result lives in one of two alternating
+        workspaces of this object: it stays valid until the second-next call."""
         torch = _torch()
         core = self.core
         m, xM = core.xM_yN_size, core.xM_size
@@ -1031,6 +1046,17 @@ class SwiftlyBackward:
                 raise ValueError(f"subgrid has shape {tuple(ten.shape)}, expected {(xA, xA)}")
             subs.append(ten)
         dev, dt = core.device, self.dtype
+        if core.supports_fused_subgrid(dt) and F <= 64:
+            # prepare_subgrid along axis 0 on the xA columns, then ONE kernel per padded row for the contiguous-axis
+            # half (prepare axis 1 + extract axis 1 for every facet, on chip) and one column pass for the rest
+            sub = self._ws("stack", (S, xA, xA), dt)
+            torch.stack(subs, out=sub)
+            work = self._ws("work", (2 * S * xM * xA,), dt)
+            self._ring ^= 1
+            parts = self._ws(f"parts{self._ring}", (F, S, m, m), dt)
+            return core.wave_split_subgrids(sub, [sg.off0 for sg in sgs], [sg.off1 for sg in sgs],
+                                            [c.off0 for c in self.facets_config_list],
+                                            [c.off1 for c in self.facets_config_list], work, parts)
         sub = subs[0].unsqueeze(0) if S == 1 else torch.stack(subs)
         sub = sub.contiguous()
         # prepare_subgrid (core.py:328-368): axis 1 on the xA rows, then axis 0 on all xM columns

@@ -545,6 +545,19 @@ class SwiftlyCoreHip:
     def _i64(values):
         return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
 
+    def scratch(self, name, nbytes):
+        """Grow-only persistent device scratch of this core, by name (four-step intermediates of the native wave
+        calls; stream-ordered allocations of changing size cost ~2 ms of host time each)."""
+        torch = _torch()
+        pool = self.__dict__.setdefault("_scratch_pool", {})
+        # one buffer per HIP stream: calls on one stream are ordered, calls on different streams (other host
+        # threads, side streams) must not share a scratch
+        key = (name, torch.cuda.current_stream(self._device).cuda_stream)
+        buf = pool.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = pool[key] = torch.empty((int(nbytes),), dtype=torch.uint8, device=self._device)
+        return buf
+
     def wave_facet_side(self, bands, facet_off0s, band, wave_off1, rowmap, n_rows, Q, compute_q, sub_off0s, g_out,
                         g_layout=None):
         """K2 + K3 + K4a of one wave natively (``swiftly_hip_wave_facet_side``): ``bands[F, yB, band columns]`` ->
@@ -552,6 +565,7 @@ class SwiftlyCoreHip:
         ``[F, S, m, m]`` tensor, or a flat send buffer with ``g_layout = (offsets[S], facet_strides[S])``."""
         F, S = Q.shape[0], len(sub_off0s)
         cvp = ctypes.c_void_p
+        scr = self.scratch("k2", F * self.yN_size * self.xM_yN_size * 8) if compute_q else None
         if g_layout is None:
             fs, ss, offs, fstr = g_out.stride(0), g_out.stride(1), None, None
         else:
@@ -563,7 +577,8 @@ class SwiftlyCoreHip:
                 bands.stride(0) if bands is not None else 0, F, self._i64(facet_off0s), int(band[0]), int(band[1]),
                 int(wave_off1), cvp(rowmap.data_ptr()) if rowmap is not None else None, int(n_rows),
                 cvp(Q.data_ptr()), Q.stride(0), int(bool(compute_q)), S, self._i64(sub_off0s), cvp(g_out.data_ptr()), fs,
-                ss, offs, fstr, self._stream(),
+                ss, offs, fstr, cvp(scr.data_ptr()) if scr is not None else None, scr.numel() if scr is not None else 0,
+                self._stream(),
             )
         )
 
@@ -610,13 +625,14 @@ class SwiftlyCoreHip:
         through the workspace ``tmp[S, xM, xA]``."""
         F, S = G.shape[0], G.shape[1]
         cvp = ctypes.c_void_p
+        scr = self.scratch("k5b", min(S, 64) * self.xM_size * int(subgrid_size) * 8)
         _lib.check(
             self._lib.swiftly_hip_wave_subgrid_side(
                 self._handle, self._code(G), cvp(G.data_ptr()), F, G.stride(0), G.stride(1), self._i64(facet_off0s),
                 self._i64(facet_off1s), S, self._i64(sub_off0s), self._i64(sub_off1s), int(subgrid_size),
                 cvp(mask0.data_ptr()) if mask0 is not None else None, mask0.stride(0) if mask0 is not None else 0,
                 cvp(mask1.data_ptr()) if mask1 is not None else None, mask1.stride(0) if mask1 is not None else 0,
-                cvp(tmp.data_ptr()), cvp(out.data_ptr()), self._stream(),
+                cvp(tmp.data_ptr()), cvp(out.data_ptr()), cvp(scr.data_ptr()), scr.numel(), self._stream(),
             )
         )
         return out
@@ -634,6 +650,34 @@ class SwiftlyCoreHip:
                 f0, f1, ctypes.c_void_p(out.data_ptr()), out.stride(0), out.stride(1), so, int(subgrid_size),
                 ctypes.c_void_p(mask.data_ptr()) if mask is not None else None,
                 mask.stride(0) if mask is not None else 0, S, self._stream(),
+            )
+        )
+        return out
+
+    def split_prepare_facets(self, tmp, subgrid_off1s, facet_off0s, facet_off1s, out):
+        """``tmp[S, xM, xA]`` (prepare_subgrid along axis 0) -> contributions ``out[F, S, m, m]`` to every facet
+        (``swiftly_hip_split_prepare_facets``: the rest of api_helper.prepare_and_split_subgrid)."""
+        S, F = tmp.shape[0], out.shape[0]
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_split_prepare_facets(
+                self._handle, self._code(tmp), cvp(tmp.data_ptr()), tmp.stride(0), tmp.stride(1), int(tmp.shape[2]), S,
+                self._i64(subgrid_off1s), F, self._i64(facet_off0s), self._i64(facet_off1s), cvp(out.data_ptr()),
+                out.stride(0), out.stride(1), self._stream(),
+            )
+        )
+        return out
+
+    def wave_split_subgrids(self, sub, sub_off0s, sub_off1s, facet_off0s, facet_off1s, work, out):
+        """``sub[S, xA, xA]`` (contiguous) -> contributions ``out[F, S, m, m]`` to every facet in one native call
+        (``swiftly_hip_wave_split_subgrids``); ``work``: complex workspace of >= ``2 * S * xM * xA`` elements."""
+        S, F = sub.shape[0], out.shape[0]
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_wave_split_subgrids(
+                self._handle, self._code(sub), cvp(sub.data_ptr()), int(sub.shape[1]), S, self._i64(sub_off0s),
+                self._i64(sub_off1s), F, self._i64(facet_off0s), self._i64(facet_off1s), cvp(work.data_ptr()),
+                work.numel(), cvp(out.data_ptr()), out.stride(0), out.stride(1), self._stream(),
             )
         )
         return out

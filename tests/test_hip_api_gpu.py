@@ -383,3 +383,29 @@ def test_distributed_virtual_ranks(world):
         for j, o in zip(idx, out):
             # different kernels and summation order than `ref`: two float32 results, each ~1e-5 from the truth
             assert float((o - ref[j]).abs().pow(2).mean().sqrt()) <= 3e-5 * float(ref[j].abs().pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("params", [TEST_PARAMS, dict(W=11.0, fov=1.0, N=1024, yB_size=352, yN_size=512, xA_size=192, xM_size=256)])
+def test_backward_fused_split_matches_primitives(params):
+    """The fused subgrid side of the backward pass (prepare_subgrid axis 0 + split_prepare_facets) against the
+    primitive-by-primitive route (reference api_helper.py:115-139) in complex128 on the same subgrids, including
+    wrapped offsets and odd subgrid sizes."""
+    import torch
+
+    sw, cfg, facet_cfgs, sg_cfgs, _ = small_problem(params, numpy.complex64, 5)
+    core = cfg.core
+    assert core.supports_fused_subgrid(torch.complex64)
+    xA = params["xA_size"]
+    wave = [c for c in sg_cfgs if c.off0 == sg_cfgs[-1].off0]
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    data = [torch.randn((xA, xA), dtype=torch.complex64, generator=gen).cuda() for _ in wave]
+    b32 = sw.SwiftlyBackward(cfg, facet_cfgs)
+    got = b32.wave_contributions(wave, data).to(torch.complex128)
+    b64 = sw.SwiftlyBackward(cfg, facet_cfgs)
+    want = b64.wave_contributions(wave, [d.to(torch.complex128) for d in data])  # complex128: primitive route
+    assert want.dtype == torch.complex128 and got.shape == want.shape
+    err = float((got - want).abs().pow(2).mean().sqrt() / want.abs().pow(2).mean().sqrt())
+    print(f"fused split relRMSE vs complex128 primitives: {err:.3e}")
+    assert err < 2e-6
+    for f in range(len(facet_cfgs)):
+        assert float((got[f] - want[f]).abs().max()) <= 2e-5 * float(want[f].abs().max())

@@ -49,5 +49,32 @@ def main(path):
         )
 
 
+def timeline(path, pattern, count):
+    """print `count` consecutive dispatches starting at the LAST-but-`count`... simple view: the dispatches around the
+    last occurrence of a kernel whose name contains `pattern` (start offset, duration, gap to the previous end)"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    disp = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch"))
+    sym = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
+    rows = cur.execute(
+        f"select s.kernel_name, d.start, d.end from '{disp}' d join '{sym}' s on d.kernel_id = s.id order by d.start"
+    ).fetchall()
+    hits = [i for i, r in enumerate(rows) if pattern in r[0]]
+    if not hits:
+        print("no dispatch matches", pattern)
+        return
+    i0 = max(0, hits[len(hits) // 2] - count // 2)
+    t0 = rows[i0][1]
+    prev_end = None
+    for name, st, en in rows[i0 : i0 + count]:
+        gap = (st - prev_end) / 1e3 if prev_end is not None else 0.0
+        print(f"{(st - t0) / 1e3:10.1f} us  dur {(en - st) / 1e3:8.1f} us  gap {gap:8.1f} us  {demangle_short(name)[:90]}")
+        prev_end = en
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) >= 4:
+        timeline(sys.argv[1], sys.argv[2], int(sys.argv[3]))
+    else:
+        main(sys.argv[1])

@@ -46,13 +46,20 @@ for axis in AXES:
         bwd = sw.SwiftlyBackward(cfg, fcs, lru_backward=1, wave_axis=axis, subgrid_configs=sgs)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        host = [0.0, 0.0]
         for k, w in waves.items():
             e = timer.start()
+            h0 = time.perf_counter()
             parts = bwd.wave_contributions(w, [subgrids[(c.off0, c.off1)] for c in w])
+            h1 = time.perf_counter()
             timer.stop(f"axis{axis}_rep{rep}_B1-4_prepare_split", e)
             e = timer.start()
+            h2 = time.perf_counter()
             bwd.accumulate_wave(w, parts)
+            host[1] += time.perf_counter() - h2
+            host[0] += h1 - h0
             timer.stop(f"axis{axis}_rep{rep}_B5-7_accumulate", e)
+        print(f"  host ms: contributions {host[0] * 1e3:.2f}, accumulate {host[1] * 1e3:.2f}")
         e = timer.start()
         out = bwd.finish()
         timer.stop(f"axis{axis}_rep{rep}_B8_finish", e)
