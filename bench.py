@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle parity check of the timed objects")
     ap.add_argument("--verify", action="store_true", help="(default) kept for explicitness")
+    ap.add_argument("--no-backward", action="store_true",
+                    help="skip the subgrid -> facet leg (reported beside the headline metric, outside its timed region)")
     ap.add_argument("--wave-axis", type=int, default=None, choices=[0, 1],
                     help="force the forward pipeline: 0 = strided axis first (waves by off0), 1 = contiguous axis first")
     args = ap.parse_args()
@@ -487,6 +489,42 @@ def main():
         )
         del buf
 
+    # subgrid -> facet direction on the subgrids this workload produced: reported beside
+    # the headline metric, never part of `value`
+    backward = None
+    if single and not args.no_backward:
+        fwd = factory()
+        fwd.prepare_all_facets()
+        produced = [fwd.get_wave(wave).clone() for wave in waves]
+        del fwd
+        torch.cuda.synchronize()
+
+        def backward_pass():
+            bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=sg_cfgs, wave_axis=wave_axis)
+            for wave, data in zip(waves, produced):
+                bwd.add_new_subgrid_tasks(wave, [data[k] for k in range(len(wave))])
+            return bwd.finish()
+
+        try:
+            backward_pass()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            nb = 3
+            for _ in range(nb):
+                out = backward_pass()
+            torch.cuda.synchronize()
+            b_ms = 1e3 * (time.perf_counter() - tb) / nb
+            finite = all(bool(torch.isfinite(torch.view_as_real(o)).all()) for o in out)
+            backward = dict(
+                ms_per_pass=round(b_ms, 3), passes=nb, ratio_to_forward=round(b_ms / ms_per_step, 3),
+                schedule="band accumulators, waves by off1" if wave_axis == 1 else "reference schedule, waves by off0",
+                subgrids=S, facets=F, finite=finite,
+            )
+            del out
+        except (ValueError, NotImplementedError) as err:  # sizes without the band kernels
+            backward = dict(skipped=str(err))
+        del produced
+
     line = dict(
         metric="facet_to_subgrid_contributions_per_s",
         value=round(F * S / (ms_per_step * 1e-3), 1),
@@ -513,6 +551,7 @@ def main():
         stages=stages,
         roofline=roofline,
         parity=parity,
+        backward=backward,
     )
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
