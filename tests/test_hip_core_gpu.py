@@ -56,8 +56,18 @@ def close(got, want, dtype, rounded=None):
         wrms = max(numpy.sqrt(numpy.mean(numpy.abs(want) ** 2)), 1e-30)
         floor = 0.0 if rounded is None else numpy.sqrt(numpy.mean(numpy.abs(rounded - want) ** 2))
         rms = numpy.sqrt(numpy.mean(err**2))
-        assert rms <= max(2e-6 * wrms, 6 * floor), (rms / wrms, floor / wrms)
-        assert err.max() <= max(2e-5 * scale, 80 * floor), err.max() / scale
+        # complex64 bounds: 5e-7 relative RMS / 2e-6 of the largest value where the result is well conditioned
+        # (measured over this module: 1.6e-7 / 2.2e-7), a small multiple of the input-storage floor where the
+        # primitive cancels heavily (measured: 4.3x RMS, 57x maximum)
+        rms_bound, max_bound = max(5e-7 * wrms, 6 * floor), max(2e-6 * scale, 80 * floor)
+        HEADROOM["rms / bound"] = max(HEADROOM["rms / bound"], rms / rms_bound)
+        HEADROOM["max / bound"] = max(HEADROOM["max / bound"], err.max() / max_bound)
+        assert rms <= rms_bound, (rms / wrms, floor / wrms)
+        assert err.max() <= max_bound, err.max() / scale
+
+
+HEADROOM = {"rms / bound": 0.0, "max / bound": 0.0}
+
 
 
 @pytest.mark.parametrize("dtype", [numpy.complex128, numpy.complex64])
@@ -364,3 +374,8 @@ def test_long_rows_yN65536_c64():
     # refused loudly where no 65536-point kernel exists (complex128)
     with pytest.raises(NotImplementedError):
         core.prepare_facet(rows.astype(complex), 0, axis=1)
+
+
+def test_zz_complex64_headroom():
+    """Runs last in this module: how close the complex64 results of all tests above came to their bounds."""
+    print("complex64 headroom:", {k: float(f"{v:.3g}") for k, v in HEADROOM.items()})
