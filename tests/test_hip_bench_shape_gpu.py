@@ -122,3 +122,54 @@ def test_forward_64k_sparse_point_sources_match_dft():
                 assert rel < 3e-5, (axis, c.off0, c.off1, rel)
         del fwd
         torch.cuda.empty_cache()
+
+
+def test_backward_64k_sparse_is_adjoint_of_checked_forward():
+    """Full-size parity of the subgrid -> facet direction through a size-independent property: backward = N^2 x the
+    adjoint of forward (tests/test_adjoint_cpu.py proves it on the oracle).  The forward pass of this workload is
+    checked against the oracle above, so
+
+        sum conj(y) * forward(M_f x)  ==  N**-2 * sum conj(backward(M_s y)) * x
+
+    with the benchmark's facets x, and y = forward(x) + noise (so that the left side is ~|forward(x)|^2, not a
+    cancellation), ties BOTH backward schedules (reference order and band accumulators) at N = 65536 to it."""
+    torch, sw, p, cfg, facet_cfgs, sg_cfgs = _setup()
+    N, yB, xA = p["N"], p["yB_size"], p["xA_size"]
+    vectors = [sep.facet_vectors(1234 + j, yB, rank=2) for j in range(len(facet_cfgs))]
+    facets = [bench.separable_facet(torch, vectors[j], c) for j, c in enumerate(facet_cfgs)]  # already masked
+    axis = sw.api.preferred_wave_axis(cfg, torch.complex64)
+    key = (lambda c: c.off1) if axis == 1 else (lambda c: c.off0)
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(key(c), []).append(c)
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=axis)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    ys, lhs, nrm = {}, 0.0, 0.0
+    for k, wave in waves.items():
+        fx = fwd.get_wave(wave)
+        noise = torch.randn(fx.shape, dtype=torch.complex64, device="cuda", generator=gen)
+        y = fx + noise * float(fx.abs().pow(2).mean().sqrt())
+        masks = torch.stack([
+            torch.outer(torch.as_tensor(c.mask0, dtype=torch.float32), torch.as_tensor(c.mask1, dtype=torch.float32))
+            for c in wave
+        ]).cuda()
+        ys[k] = y * masks  # backward does not apply subgrid masks: y := M_s y
+        lhs = lhs + torch.sum(y.to(torch.complex128).conj() * fx.to(torch.complex128)).item()
+        nrm += float(fx.abs().pow(2).sum()) ** 0.5 * float(y.abs().pow(2).sum()) ** 0.5
+    del fwd
+    torch.cuda.empty_cache()
+    for baxis in (1, 0):
+        bkey = (lambda c: c.off1) if baxis == 1 else (lambda c: c.off0)
+        lookup = {(c.off0, c.off1): ys[key(c)][i] for wave in waves.values() for i, c in enumerate(wave)}
+        order = sorted(sg_cfgs, key=lambda c: (bkey(c), c.off0, c.off1))
+        bwd = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=baxis, subgrid_configs=sg_cfgs)
+        bwd.add_new_subgrid_tasks(order, [lookup[(c.off0, c.off1)] for c in order])
+        out = bwd.finish()
+        rhs = sum(torch.sum(b.to(torch.complex128).conj() * x.to(torch.complex128)).item() for b, x in zip(out, facets))
+        rhs /= float(N) ** 2
+        rel = abs(lhs - rhs) / abs(lhs)
+        print(f"backward wave_axis={baxis}: <F x, y> = {lhs:.6e}, N^-2 <x, B y> = {rhs:.6e}, relative difference {rel:.2e}")
+        assert abs(lhs) > 0.3 * nrm / len(waves) ** 0.5  # the left side is not a cancellation
+        assert rel < 1e-6, (baxis, lhs, rhs)  # measured 2e-9 .. 3e-9: rounding errors average out in the sums
+        del bwd, out
+        torch.cuda.empty_cache()
