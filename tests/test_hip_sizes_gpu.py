@@ -38,7 +38,22 @@ def _run(P, facet_cfgs, sg_cfgs, wave_axis, tol, plan=True, seed=900):
     ordered = sorted(sg_cfgs, key=lambda c: (key(c), c.off0, c.off1))
     fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs if plan else None,
                             wave_axis=wave_axis)
-    got = [t.cpu().numpy() for t in fwd.get_subgrid_tasks(ordered)]
+    dev = fwd.get_subgrid_tasks(ordered)
+    got = [t.cpu().numpy() for t in dev]
+    # the subgrid -> facet direction at the same sizes, tied to the forward pass (checked against the oracle below)
+    # by the adjoint identity of tests/test_adjoint_cpu.py with y = forward(x): sum |F x|^2 == N^-2 sum conj(B y) x
+    lhs = sum(float(t.to(torch.complex128).abs().pow(2).sum()) for t in dev)
+    for baxis in (0, 1):
+        bkey = (lambda c: c.off1) if baxis == 1 else (lambda c: c.off0)
+        order = sorted(range(len(ordered)), key=lambda i: (bkey(ordered[i]), ordered[i].off0, ordered[i].off1))
+        bwd = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=baxis, subgrid_configs=sg_cfgs if plan else None)
+        bwd.add_new_subgrid_tasks([ordered[i] for i in order], [dev[i] for i in order])
+        out = bwd.finish()
+        rhs = sum(torch.sum(b.to(torch.complex128).conj() * x.to(torch.complex128)).item() for b, x in zip(out, facets))
+        rhs /= float(P["N"]) ** 2
+        print(f"N={P['N']} backward wave_axis={baxis}: |F x|^2 = {lhs:.6e}, N^-2 <B F x, x> = {rhs:.6e}")
+        assert abs(lhs - rhs) <= 1e-5 * lhs, (baxis, lhs, rhs)
+        del bwd, out
     ref = orc.OracleCore(P["W"], P["N"], P["xM_size"], P["yN_size"])
     items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
     so = sep.SeparableOracle(ref, items, vectors)
