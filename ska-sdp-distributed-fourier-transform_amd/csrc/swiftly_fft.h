@@ -216,6 +216,13 @@ constexpr int lds_delta(int d, bool rowfast) {
 #ifndef SWF_TW_TWO_FACTOR
 #define SWF_TW_TWO_FACTOR 0
 #endif
+// SWF_TW_TABLE=1: every inter-phase twiddle w^r loaded from the table instead of LOGR loads + products (saves ~330
+// of the row kernel's ~3200 VALU instructions per wave, costs 48 more 8-byte loads per lane).  Measured on MI355X
+// (r2, same-box A/B): K1 2.06 -> 3.30 ms per facet, whole pass 47.8 -> 58.1 ms -- the dependent loads sit in the
+// critical path of every phase; the kernel is VALU-issue-bound only because its memory latency is already hidden.
+#ifndef SWF_TW_TABLE
+#define SWF_TW_TABLE 0
+#endif
 template <typename R, int LOGR, int NB, int U, int PTOT, int N>
 __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx) {
     constexpr int RAD = 1 << LOGR;
@@ -244,6 +251,13 @@ __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __
                     x[U + r * NB] = cmul(x[U + r * NB], w);
                 }
             });
+        });
+    } else if constexpr (SWF_TW_TABLE && std::is_same<R, float>::value) {
+        // every w^r straight from the table: RAD-1 loads (L1/L2-resident table) instead of LOGR loads and
+        // sum(popcount(r) - 1) complex products -- trades VALU issue slots for vector-memory ones
+        static_for<1, RAD>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            x[U + r * NB] = cmul(x[U + r * NB], tw[(kidx * r) & (N - 1)]);
         });
     } else if constexpr (LOGR >= 5) {
         // register-lean form: keep only the LOGR table values alive and build
