@@ -71,6 +71,68 @@ __device__ __forceinline__ cx<float> cmul<float>(cx<float> a, cx<float> b) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------
+// SWF_PK: hand-packed complex64 arithmetic.  A complex value is one 64-bit VGPR pair; add / subtract are one
+// v_pk_add_f32, a general product is v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers doing the swaps and
+// sign changes (the compiler's own lowering of the same expressions needs a v_xor per product because it does not
+// fold a one-lane negation into neg_lo), and the (a - c) * {-i, W8, W8^3} butterflies fold their rotation into the
+// subtraction.  VOP3P modifiers: op_sel[i] / op_sel_hi[i] pick the half of source i that feeds the low / high
+// result lane, neg_lo / neg_hi negate source i for that lane.
+// Measured on MI355X (r2, same-box A/B, -DSWF_PK=0 vs 1): the band row kernel 1675 instead of 2416 VALU instructions
+// per wave, 117 instead of 128 VGPRs and no spills in any geometry (the 65536-point one spilled 100 B/lane), K1 2.03
+// -> 1.93 ms per facet; column passes and the subgrid-side kernels unchanged (bandwidth / LDS bound).  With the
+// VALU share at ~58 % of the kernel's cycles the row kernel is now bound by its LDS exchanges and by how well the
+// two resident workgroups' load and compute phases interleave.
+#ifndef SWF_PK
+#define SWF_PK 1
+#endif
+__device__ __forceinline__ f32x2 pkv(cx<float> a) { return f32x2{a.x, a.y}; }
+__device__ __forceinline__ cx<float> pkc(f32x2 v) { return {v.x, v.y}; }
+#if SWF_PK
+#if !SWF_PACKED_ADD
+__device__ __forceinline__ cx<float> operator+(cx<float> a, cx<float> b) { return pkc(pkv(a) + pkv(b)); }
+__device__ __forceinline__ cx<float> operator-(cx<float> a, cx<float> b) { return pkc(pkv(a) - pkv(b)); }
+#endif
+#if !SWF_PACKED_CMUL
+template <>
+__device__ __forceinline__ cx<float> cmul<float>(cx<float> a, cx<float> b) {
+    f32x2 t, r;
+    const f32x2 av = pkv(a), bv = pkv(b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));  // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"  // (t.x - a.y b.y, t.y + a.y b.x)
+        : "=v"(r)
+        : "v"(av), "v"(bv), "v"(t));
+    return pkc(r);
+}
+#endif
+#endif  // SWF_PK
+// (a - c) * (-i) = (a.y - c.y, c.x - a.x)
+__device__ __forceinline__ cx<float> pk_sub_mi(cx<float> a, cx<float> c) {
+    f32x2 r;
+    const f32x2 av = pkv(a), cv = pkv(c);
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(av), "v"(cv));
+    return pkc(r);
+}
+// (a - c) * (+i) = (c.y - a.y, a.x - c.x)
+__device__ __forceinline__ cx<float> pk_sub_pi(cx<float> a, cx<float> c) {
+    f32x2 r;
+    const f32x2 av = pkv(a), cv = pkv(c);
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(cv));
+    return pkc(r);
+}
+// (d.x + d.y, d.y - d.x)
+__device__ __forceinline__ f32x2 pk_rot8(f32x2 d) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(d));
+    return r;
+}
+// (d.y - d.x, -d.x - d.y)
+__device__ __forceinline__ f32x2 pk_rot24(f32x2 d) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(d));
+    return r;
+}
+
 // compile-time loop: f(std::integral_constant<int, i>) for i in [I0, I1)
 template <int I0, int I1, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -125,6 +187,12 @@ __device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
         return {-d.x, -d.y};
     } else if constexpr (n == 48) {  // +i
         return {-d.y, d.x};
+    } else if constexpr (n == 8 && std::is_same<R, float>::value && SWF_PK) {
+        constexpr float c = 0.70710678118654752f;
+        return pkc(pk_rot8(pkv(d)) * f32x2{c, c});
+    } else if constexpr (n == 24 && std::is_same<R, float>::value && SWF_PK) {
+        constexpr float c = 0.70710678118654752f;
+        return pkc(pk_rot24(pkv(d)) * f32x2{c, c});
     } else if constexpr (n == 8) {  // (1 - i)/sqrt2
         constexpr R c = (R)0.7071067811865476;
         return {(d.x + d.y) * c, (d.y - d.x) * c};
@@ -133,7 +201,7 @@ __device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
         return {(d.y - d.x) * c, -(d.x + d.y) * c};
     } else {
         constexpr R c = (R)cos64(n), s = (R)(-sin64(n));
-        if constexpr (std::is_same<R, float>::value && SWF_PACKED_CMUL) {
+        if constexpr (std::is_same<R, float>::value && (SWF_PACKED_CMUL || SWF_PK)) {
             // (d.x, d.x)*(c, s) + (d.y, d.y)*(-s, c) as two packed instructions
             const f32x2 dx = {d.x, d.x}, dy = {d.y, d.y};
             const f32x2 k0 = {c, s}, k1 = {-s, c};
@@ -142,6 +210,18 @@ __device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
         } else {
             return {d.x * c - d.y * s, d.x * s + d.y * c};
         }
+    }
+}
+
+// (a - c) * exp(-2 pi i NUM / 64): the lower output of a DIF butterfly
+template <typename R, int NUM>
+__device__ __forceinline__ cx<R> sub_mul_w64(cx<R> a, cx<R> c) {
+    if constexpr (std::is_same<R, float>::value && SWF_PK && (NUM & 63) == 16) {
+        return pk_sub_mi(a, c);
+    } else if constexpr (std::is_same<R, float>::value && SWF_PK && (NUM & 63) == 48) {
+        return pk_sub_pi(a, c);
+    } else {
+        return mul_w64<R, NUM>(a - c);
     }
 }
 
@@ -161,7 +241,7 @@ __device__ __forceinline__ void fft_reg(cx<R> (&x)[PTOT]) {
             constexpr int i1 = i0 + half * STR;
             cx<R> a = x[i0], c = x[i1];
             x[i0] = a + c;
-            x[i1] = mul_w64<R, k*(32 / half)>(a - c);
+            x[i1] = sub_mul_w64<R, k*(32 / half)>(a, c);
         });
     });
 }
