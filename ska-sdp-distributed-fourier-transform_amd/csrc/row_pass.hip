@@ -73,12 +73,12 @@ int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<
 }
 using BandGeo5 = RGeo<14, 5, true>;  // 2 x 16384 points, 512 threads x 32, 66 KB LDS: two workgroups per CU
 using BandGeo4 = RGeo<14, 4, true>;  // 2 x 16384 points, 1024 threads x 16, one workgroup per CU
-template <class G>
+template <class G, bool PAIR = false>
 static int launch_band_geo(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
     const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
     const bool band = a.band_len > 0;
-#define SWF_LAUNCH_BAND(WIN, ST)                                                                                  \
-    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, \
+#define SWF_LAUNCH_BAND(WIN, ST)                                                                                        \
+    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, \
                        a.out, a.ld_win, tw14, tw_full)
     if (a.band_len < 0) {  // mapped (crop + window) store: finish_* primitives
         SWF_LAUNCH_BAND(false, 2);
@@ -110,6 +110,11 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
     static const int geo_fin = getenv("SWIFTLY_ROW_GEO_FIN") ? atoi(getenv("SWIFTLY_ROW_GEO_FIN")) : 5;
     const int geo = geo_env ? geo_env : (a.band_len > 0 ? 5 : a.band_len < 0 ? geo_fin : 4);
     if (geo == 4) return launch_band_geo<BandGeo4>(a, tw14, tw_full, s);
+    // adjacent-point (16-byte) loads need even shifts / lengths / pitches; tuning knob SWIFTLY_ROW_PAIR=0 turns them off
+    static const bool pair_env = !(getenv("SWIFTLY_ROW_PAIR") && atoi(getenv("SWIFTLY_ROW_PAIR")) == 0);
+    const bool pair_ok = pair_env && !(a.ld_a & 1) && !(a.ld_len & 1) && !(a.in_pitch & 1) &&
+                         (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
+    if (pair_ok) return launch_band_geo<BandGeo5, true>(a, tw14, tw_full, s);
     return launch_band_geo<BandGeo5>(a, tw14, tw_full, s);
 }
 int row_pass_band_occupancy() {
@@ -121,6 +126,11 @@ int row_pass_band_occupancy() {
 template <class G, bool WIN, int ST>
 static int init_band() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+}
+template <class G, bool WIN, int ST>
+static int init_band_pair() {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 template <class G>
@@ -150,6 +160,11 @@ static int init_split() {
 int init_row_pass() {
     {
         int rcb = init_band_geo<BandGeo5>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 0>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, false, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, false, 0>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, false, 2>();
         if (!rcb) rcb = init_band_geo<BandGeo4>();
         if (!rcb) rcb = init_band_geo<BandGeo64k>();
         if (!rcb) rcb = init_band_geo<BandGeo16k>();

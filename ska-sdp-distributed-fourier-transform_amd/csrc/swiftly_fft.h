@@ -414,14 +414,16 @@ __device__ __forceinline__ void phase_scatter(const cx<R> (&x)[G::P], int t, F&&
 // plus compile-time offsets, so each LDS access is a single instruction with
 // an immediate offset (the padded index e + (e >> LOGPAD) is affine in the
 // radix digit because the digit only fills bits that are zero in the base).
-template <class G, typename R, int LOGNS, int LOGR, class T_, class Pick>
+// PAIRJ: the thread's blocks are the ADJACENT virtual threads j = t*NB + u (first phase only: lets the kernel load
+// the NB adjacent input points of a lane with one wide access) instead of j = t + u*T.
+template <class G, typename R, int LOGNS, int LOGR, bool PAIRJ = false, class T_, class Pick>
 __device__ __forceinline__ void exchange_pass(cx<R> (&x)[G::P], int t, int rb, bool rowfast, T_* buf, Pick&& pick,
                                               bool write_x_component) {
     constexpr int RAD = 1 << LOGR, NB = G::P / RAD;
     (void)write_x_component;
     static_for<0, NB>([&](auto uI) {
         constexpr int u = decltype(uI)::value;
-        const int j = t + u * G::T;
+        const int j = PAIRJ ? t * NB + u : t + u * G::T;
         const int k = j & ((1 << LOGNS) - 1);
         const int e0 = ((j - k) << LOGR) + k;
         const int p0 = lds_pos<G>(rb, e0, rowfast);
@@ -447,23 +449,23 @@ __device__ __forceinline__ void gather_pass(int t, int rb, bool rowfast, const T
     });
 }
 
-template <class G, typename R, int LOGNS, int LOGR>
+template <class G, typename R, int LOGNS, int LOGR, bool PAIRJ = false>
 __device__ __forceinline__ void phase_exchange(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds) {
     if constexpr (!G::SPLIT) {
         cx<R>* buf = reinterpret_cast<cx<R>*>(lds);
-        exchange_pass<G, R, LOGNS, LOGR>(x, t, rb, rowfast, buf, [](cx<R> v) { return v; }, true);
+        exchange_pass<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, buf, [](cx<R> v) { return v; }, true);
         __syncthreads();
         gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, cx<R> val) { x[decltype(vI)::value] = val; });
         __syncthreads();
     } else {
         // re and im separately: halves the LDS footprint
         R* buf = reinterpret_cast<R*>(lds);
-        exchange_pass<G, R, LOGNS, LOGR>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.x; }, true);
+        exchange_pass<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.x; }, true);
         __syncthreads();
         // every old real part is in LDS now, so x[].x can take the new ones
         gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, R val) { x[decltype(vI)::value].x = val; });
         __syncthreads();
-        exchange_pass<G, R, LOGNS, LOGR>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.y; }, false);
+        exchange_pass<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.y; }, false);
         __syncthreads();
         gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, R val) { x[decltype(vI)::value].y = val; });
         __syncthreads();
@@ -477,13 +479,27 @@ __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool
                                            const cx<R>* __restrict__ tw, F&& fin) {
     constexpr int REM = G::LOGN - LOGNS;
     constexpr int LOGR = REM < G::LOGP ? REM : G::LOGP;
-    phase_compute<G, R, LOGNS, LOGR>(x, t, tw);
+#ifndef SWF_EXP  // timing experiments only (wrong results): 1 = no LDS exchange, 2 = no butterflies
+#define SWF_EXP 0
+#endif
+    if constexpr (!(SWF_EXP & 2)) phase_compute<G, R, LOGNS, LOGR>(x, t, tw);
     if constexpr (LOGNS + LOGR == G::LOGN) {
         phase_scatter<G, R, LOGNS, LOGR>(x, t, fin);
     } else {
-        phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
+        if constexpr (!(SWF_EXP & 1)) phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
         fft_phases<G, R, LOGNS + LOGR>(x, t, rb, rowfast, lds, tw, fin);
     }
+}
+
+// Schedule with the SHORT radix first (2^LOGR1 = N / P^k, two blocks per lane) and adjacent virtual threads per
+// lane: on entry x[u + NB*r] = input[(t*NB + u) + r * N / 2^LOGR1]  (u < NB = P / 2^LOGR1).
+template <class G, typename R, class F>
+__device__ __forceinline__ void fft_phases_pair(cx<R> (&x)[G::P], int t, void* lds, const cx<R>* __restrict__ tw, F&& fin) {
+    constexpr int LOGR1 = G::LOGN % G::LOGP;
+    static_assert(LOGR1 > 0 && LOGR1 < G::LOGP, "needs a short first phase");
+    phase_compute<G, R, 0, LOGR1>(x, t, tw);
+    phase_exchange<G, R, 0, LOGR1, true>(x, t, 0, false, lds);
+    fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin);
 }
 
 }  // namespace swf

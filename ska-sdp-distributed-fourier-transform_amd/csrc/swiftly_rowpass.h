@@ -14,6 +14,7 @@
 namespace swf {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // buffer (range-checked) accesses in the band row kernel: A/B switches.  Measured (r2, same box, K1 per pass):
 // global loads + exec-masked stores 20.2 ms (at 86 spilled VGPRs in some variants: 51 ms -- the kernel sits at the
@@ -311,7 +312,11 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // the compile-time constant W_64^(v 64 T / N).
 // ST: 0 = plain row store, 1 = band store (parity-split), 2 = mapped store of a finish_* primitive (shift, crop to
 // st_len, windows st_win * st_win2; st_c = 0, st_mod = st_len host-checked) -- finish_facet along the contiguous axis.
-template <class G, bool HAS_WIN, int ST>
+// PAIR (G = 512 x 32 only, host-checked: ld_a, ld_len and the input pitch even): the lane owns the ADJACENT points
+// 2t, 2t+1 (+ 1024 r) and fetches them with ONE 16-byte load (8-byte for the window), the transform starts with the
+// radix-16 phase.  The kernel without its butterflies and exchanges still took 1.73 of 1.93 ms: it is bound by the
+// number of vector-memory INSTRUCTIONS (128 loads per lane: 0.42 ms for the window loads alone), not by bytes.
+template <class G, bool HAS_WIN, int ST, bool PAIR = false>
 __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                  cx<float>* __restrict__ gout,
                                                                  const float* __restrict__ ld_win,
@@ -356,21 +361,64 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     // element, no memory access for the padding), and a row that is absent from a compacted input gets an empty
     // descriptor.  No control flow: the compiler keeps as many of the 2 P loads of a lane in flight as the
     // 128-VGPR budget (two workgroups per CU) allows.
+    cx<float> x[P];
+    if constexpr (PAIR) {
+        static_assert(P == 32 && G::LOGN == 14, "pair loads: 512 threads x 32 points of a 16384-point half");
+        constexpr int R1 = 16, SEG = H / R1;  // radix-16 first phase: points j + r*SEG, j = 2t + u
+        const unsigned valid = dead ? 0u : (unsigned)A.ld_len;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
+        const unsigned base8 = (unsigned)((2 * t + A.ld_a + (N >> 1)) & (N - 1)) << 3;
+        static_for<0, R1>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            cx<float> a[2][2];  // [q][u]
+            static_for<0, 2>([&](auto qI) {
+                constexpr int q = decltype(qI)::value;
+                const unsigned off8 = (base8 + (unsigned)((r * SEG + q * H) << 3)) & (unsigned)((N << 3) - 1);
+                const f32x4 val = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off8, 0, 0));
+                if constexpr (HAS_WIN) {
+                    const f32x2 w = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(off8 >> 1), 0, 0));
+                    a[q][0] = cx<float>{val.x * w.x, val.y * w.x};
+                    a[q][1] = cx<float>{val.z * w.y, val.w * w.y};
+                } else {
+                    a[q][0] = cx<float>{val.x, val.y};
+                    a[q][1] = cx<float>{val.z, val.w};
+                }
+            });
+            static_for<0, 2>([&](auto uI) {
+                constexpr int u = decltype(uI)::value;
+                x[u + 2 * r] = cx<float>{a[0][u].x + sgn * a[1][u].x, (a[0][u].y + sgn * a[1][u].y) * sg_ld};
+            });
+        });
+        if (h) {  // uniform: odd outputs need W_N^j, j = 2t + u + SEG r:  W_N^(2t+u) * W_64^(2r)
+            const f32x4 wt = *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
+            const cx<float> w0 = {wt.x, wt.y}, w1 = {wt.z, wt.w};
+            static_for<0, R1>([&](auto rI) {
+                constexpr int r = decltype(rI)::value;
+                x[2 * r] = mul_w64<float, 64 * SEG / N * r>(cmul(x[2 * r], w0));
+                x[2 * r + 1] = mul_w64<float, 64 * SEG / N * r>(cmul(x[2 * r + 1], w1));
+            });
+        }
+    } else {
 #if SWF_ROW_BUFFER
     const unsigned valid = dead ? 0u : (unsigned)A.ld_len;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
     // byte offset of plain index j = t (centred index j ^ N/2 = j + N/2 mod N), then + (v T + q H) * 8 mod 8 N
     const unsigned base8 = (unsigned)((t + A.ld_a + (N >> 1)) & (N - 1)) << 3;
-    cx<float> x[P];
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         cx<float> a[2];
         static_for<0, 2>([&](auto qI) {
             constexpr int q = decltype(qI)::value;
             const unsigned off8 = (base8 + (unsigned)((v * T + q * H) << 3)) & (unsigned)((N << 3) - 1);
-            const f32x2 val = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)off8, 0, 0));
-            if constexpr (HAS_WIN) {
+#ifndef SWF_EXP
+#define SWF_EXP 0
+#endif
+            f32x2 val = {1.f, 0.f};
+            if constexpr (!((SWF_EXP & 16) && q == 1))  // timing experiment: drop the second half's loads
+                val = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)off8, 0, 0));
+            if constexpr (HAS_WIN && !(SWF_EXP & 4)) {
                 const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, (int)(off8 >> 1), 0, 0));
                 a[q] = cx<float>{val.x * w, val.y * w};
             } else {
@@ -382,7 +430,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
 #else
     const int base = (t + A.ld_a + (N >> 1)) & (N - 1);  // q of plain index j = t (centred index j ^ N/2 = j + N/2 mod N)
     const float alive = dead ? 0.f : 1.f;
-    cx<float> x[P];
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         cx<float> a[2];
@@ -410,6 +457,13 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         });
     }
 
+    }
+    auto run_phases = [&](auto&& fin) {
+        if constexpr (PAIR)
+            fft_phases_pair<G, float>(x, t, smem, tw, fin);
+        else
+            fft_phases<G, float, 0>(x, t, 0, false, smem, tw, fin);
+    };
     float scale = A.scale;
     if (A.row_win) scale *= A.row_win[row];
     const float scale_im = scale * sg_st;
@@ -431,10 +485,11 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         const bool has1 = A.st_win != nullptr;  // uniform
         // outputs of a lane come in runs of CH slots whose indices differ by q << LNS (phase_scatter): the windows of
         // a run are fetched together right before its stores
-        constexpr int LR = G::LOGN % G::LOGP == 0 ? G::LOGP : G::LOGN % G::LOGP, LNS = G::LOGN - LR;
+        // (last phase: the remainder radix in the greedy schedule, the full radix when the short phase runs first)
+        constexpr int LR = (PAIR || G::LOGN % G::LOGP == 0) ? G::LOGP : G::LOGN % G::LOGP, LNS = G::LOGN - LR;
         constexpr int CH = (1 << LR) < 16 ? (1 << LR) : 16;
         float wv[CH];
-        fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v, auto sI) {
+        run_phases([&](int e, cx<float> v, auto sI) {
             constexpr int s = decltype(sI)::value;
             if constexpr (s % CH == 0) {
                 static_for<0, CH>([&](auto qI) {
@@ -458,7 +513,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         });
         return;
     }
-    fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
+    run_phases([&](int e, cx<float> v) {
         const int ck = (2 * e + h) ^ (N >> 1);
         const f32x2 val = {v.x * scale, v.y * scale_im};
 #if SWF_ROW_BUFFER_ST
@@ -473,7 +528,8 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
 #else
         if constexpr (BAND) {
             const int d = (ck - A.band_start) & (N - 1);
-            if (d < A.band_len) *reinterpret_cast<f32x2*>(outb + region + ((unsigned)(d >> 1) << 3)) = val;
+            if ((SWF_EXP & 8) ? (d < A.band_len && val.x == 12345.f) : (d < A.band_len))  // experiment 8: (almost) no stores
+                *reinterpret_cast<f32x2*>(outb + region + ((unsigned)(d >> 1) << 3)) = val;
         } else {
             *reinterpret_cast<f32x2*>(outb + ((unsigned)ck << 3)) = val;
         }

@@ -1,0 +1,30 @@
+"""K1 of the contiguous-axis-first pipeline (prepare_facet_band of one 22528^2 facet of the 64k-sparse workload) timed
+back to back with one HIP-event pair; used for A/B runs of build variants (SWIFTLY_HIP_LIB)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd"))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import ska_sdp_exec_swiftly_amd as sw  # noqa: E402
+
+wl = bench.WORKLOADS["64k-sparse"]
+p = wl["params"]
+cfg = sw.SwiftlyConfig(backend="hip", **p)
+core = cfg.core
+sgs = bench.select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
+band = core.band_for_offsets([c.off1 for c in sgs])
+facet = torch.randn((p["yB_size"], p["yB_size"]), device="cuda", dtype=torch.complex64)
+out = core.prepare_facet_band(facet, 22528, band)
+n = 9
+for rep in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        core.prepare_facet_band(facet, 22528, band, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+print(os.environ.get("SWIFTLY_HIP_LIB", "default"), f"K1 {e0.elapsed_time(e1) / n:.4f} ms per facet")
