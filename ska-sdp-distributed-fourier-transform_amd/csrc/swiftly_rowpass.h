@@ -316,6 +316,9 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // 2t, 2t+1 (+ 1024 r) and fetches them with ONE 16-byte load (8-byte for the window), the transform starts with the
 // radix-16 phase.  The kernel without its butterflies and exchanges still took 1.73 of 1.93 ms: it is bound by the
 // number of vector-memory INSTRUCTIONS (128 loads per lane: 0.42 ms for the window loads alone), not by bytes.
+// (Skipping the loads whose 64 lanes are all padding -- 31 % of prepare_facet's, 64 % of finish_facet's band loads --
+// with a wave-uniform branch was tried: the branches make the compiler hoist every load above the first use and wait
+// at every join, 280 B/lane of spills; not kept.)
 template <class G, bool HAS_WIN, int ST, bool PAIR = false>
 __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                  cx<float>* __restrict__ gout,
