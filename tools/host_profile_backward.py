@@ -1,3 +1,5 @@
+"""cProfile of the host side of one backward pass (band schedule) on the 64k-sparse workload: shows which call the
+host thread spends its time in (how the ~2 ms per-call cost of size-changing hipMallocAsync was found).  GPU only."""
 import os, sys, time, cProfile, pstats
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd"))
