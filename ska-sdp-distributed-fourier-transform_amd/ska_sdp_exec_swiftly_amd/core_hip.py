@@ -47,6 +47,32 @@ def calculate_pswf(W, yN_size):
     return vals
 
 
+def build_row_sources(N, yN, m, sub_off0s, locations, max_chunks=16):
+    """Host tables of the gather-sum load (see :py:meth:`SwiftlyCoreHip.column_row_sources`; pure numpy, unit-tested
+    on CPU against the oracle's ``add_to_facet``): list of ``(subgrid indices, int32 table [2, yN])``.  Row ``big``
+    of the padded axis is the sum of the contribution rows named by ``table[0, big]`` and ``table[1, big]``
+    (negative = none), each ``chunk << 20 | (block * m + k)``: the transpose of ``extract_from_facet``
+    (core.py:243-253), i.e. ``add_to_facet`` (core.py:441-478) as a gather."""
+    k = numpy.arange(m)
+    groups = []
+    tab = cnt = members = None
+    for b, off in enumerate(sub_off0s):
+        s = int(off) * yN // N
+        big = (yN // 2 - m // 2 + s + ((k - s) % m)) % yN
+        chunk, blk = locations[b]
+        if blk * m + m > (1 << 20) or chunk >= max_chunks:
+            raise ValueError("too many contribution rows / chunks for one accumulate_facet_columns call")
+        if tab is None or (cnt[big] >= 2).any():
+            tab = numpy.full((2, yN), -1, dtype=numpy.int32)
+            cnt = numpy.zeros(yN, dtype=numpy.int64)
+            members = []
+            groups.append((members, tab))
+        tab[cnt[big], big] = (chunk << 20) | (blk * m + k)
+        cnt[big] += 1
+        members.append(b)
+    return groups
+
+
 def _torch():
     import torch  # pylint: disable=import-outside-toplevel
 
@@ -699,24 +725,7 @@ class SwiftlyCoreHip:
         hit = cache.get(key)
         if hit is not None:
             return hit
-        yN, m = self.yN_size, self.xM_yN_size
-        k = numpy.arange(m)
-        groups = []
-        tab = cnt = members = None
-        for b, off in enumerate(offs):
-            s = off * yN // self.N
-            big = (yN // 2 - m // 2 + s + ((k - s) % m)) % yN
-            chunk, blk = locs[b]
-            if blk * m + m > (1 << 20) or chunk >= self.GS_MAX_CHUNKS:
-                raise ValueError("too many contribution rows / chunks for one accumulate_facet_columns call")
-            if tab is None or (cnt[big] >= 2).any():
-                tab = numpy.full((2, yN), -1, dtype=numpy.int32)
-                cnt = numpy.zeros(yN, dtype=numpy.int64)
-                members = []
-                groups.append((members, tab))
-            tab[cnt[big], big] = (chunk << 20) | (blk * m + k)
-            cnt[big] += 1
-            members.append(b)
+        groups = build_row_sources(self.N, self.yN_size, self.xM_yN_size, offs, locs, self.GS_MAX_CHUNKS)
         out = [(list(mem), torch.from_numpy(t).to(self._device)) for mem, t in groups]
         if len(cache) >= 512:
             cache.clear()

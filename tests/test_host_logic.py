@@ -117,3 +117,37 @@ def test_catalogue():
         # the three divisibility rules of core.py:55-74 hold for every entry
         assert c["N"] % c["yN_size"] == 0 and c["N"] % c["xM_size"] == 0
         assert (c["xM_size"] * c["yN_size"]) % c["N"] == 0
+
+
+def test_row_source_tables_are_add_to_facet_as_a_gather():
+    """The gather-sum load of the backward band schedule (core_hip.build_row_sources): summing the contribution rows
+    named by the tables must equal the oracle's add_to_facet scatter (core.py:441-478), for wrapped offsets, more than
+    two overlapping subgrids (table groups) and contributions spread over several chunks."""
+    from ska_sdp_exec_swiftly_amd.core_hip import build_row_sources
+
+    W, N, xM, yN = 11.0, 1024, 256, 512
+    ref = orc.OracleCore(W, N, xM, yN)
+    m = ref.xM_yN_size
+    step = ref.subgrid_off_step
+    rng = numpy.random.default_rng(4)
+    offs = [0, 192, 192 + step, 960, -64, 192, 192, 1024 + 384]  # duplicates: up to four sources per padded row
+    chunks = [rng.standard_normal((3, m, 5)) + 1j * rng.standard_normal((3, m, 5)) for _ in range(3)]  # [block, m, cols]
+    locs = [(b % 3, b // 3) for b in range(len(offs))]
+    want = numpy.zeros((yN, 5), dtype=complex)
+    for off, (c, blk) in zip(offs, locs):
+        ref.add_to_facet(chunks[c][blk], off, axis=0, out=want)
+    got = numpy.zeros((yN, 5), dtype=complex)
+    flat = [ch.reshape(-1, 5) for ch in chunks]  # row index = block * m + k
+    seen = []
+    for members, tab in build_row_sources(N, yN, m, offs, locs):
+        seen += members
+        assert tab.shape == (2, yN) and tab.dtype == numpy.int32
+        for lvl in range(2):
+            rows = numpy.flatnonzero(tab[lvl] >= 0)
+            enc = tab[lvl, rows]
+            for r, e in zip(rows, enc):
+                got[r] += flat[e >> 20][e & 0xFFFFF]
+        assert (tab[1] >= 0).sum() <= (tab[0] >= 0).sum()
+    assert sorted(seen) == list(range(len(offs)))
+    assert len(build_row_sources(N, yN, m, offs, locs)) >= 2  # four sources per row cannot fit one table pair
+    numpy.testing.assert_array_equal(got, want)
