@@ -47,6 +47,24 @@ def calculate_pswf(W, yN_size):
     return vals
 
 
+def band_range(N, yN, m, subgrid_offs):
+    """Smallest cyclic range ``(start, length)`` of padded-facet columns that contains the ``m`` window
+    (core.py:243-253) of every subgrid offset; ``(0, yN)`` when that is everything (pure numpy, unit-tested)."""
+    keep = numpy.zeros(yN, dtype=bool)
+    for off in set(int(o) for o in subgrid_offs):
+        s = off * yN // N
+        keep[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN] = True
+    if keep.all() or not keep.any():
+        return 0, yN
+    # largest run of unused indices on the ring; the band is its complement
+    idx = numpy.flatnonzero(keep)
+    gaps = numpy.diff(numpy.concatenate([idx, [idx[0] + yN]]))
+    g = int(numpy.argmax(gaps))
+    start = int(idx[(g + 1) % idx.size])
+    length = int(yN - (gaps[g] - 1))
+    return start, length
+
+
 def build_row_sources(N, yN, m, sub_off0s, locations, max_chunks=16):
     """Host tables of the gather-sum load (see :py:meth:`SwiftlyCoreHip.column_row_sources`; pure numpy, unit-tested
     on CPU against the oracle's ``add_to_facet``): list of ``(subgrid indices, int32 table [2, yN])``.  Row ``big``
@@ -476,20 +494,7 @@ class SwiftlyCoreHip:
     def band_for_offsets(self, subgrid_offs):
         """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains
         the ``xM_yN_size`` window of every given subgrid offset (core.py:243-253); ``(0, yN_size)`` = all."""
-        yN, m = self.yN_size, self.xM_yN_size
-        keep = numpy.zeros(yN, dtype=bool)
-        for off in set(int(o) for o in subgrid_offs):
-            s = off * yN // self.N
-            keep[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN] = True
-        if keep.all() or not keep.any():
-            return 0, yN
-        # largest run of unused indices on the ring; the band is its complement
-        idx = numpy.flatnonzero(keep)
-        gaps = numpy.diff(numpy.concatenate([idx, [idx[0] + yN]]))
-        g = int(numpy.argmax(gaps))
-        start = int(idx[(g + 1) % idx.size])
-        length = int(yN - (gaps[g] - 1))
-        return start, length
+        return band_range(self.N, self.yN_size, self.xM_yN_size, subgrid_offs)
 
     def band_columns(self, band):
         """physical columns of a band buffer"""

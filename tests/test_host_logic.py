@@ -151,3 +151,30 @@ def test_row_source_tables_are_add_to_facet_as_a_gather():
     assert sorted(seen) == list(range(len(offs)))
     assert len(build_row_sources(N, yN, m, offs, locs)) >= 2  # four sources per row cannot fit one table pair
     numpy.testing.assert_array_equal(got, want)
+
+
+def test_band_range_is_the_smallest_cyclic_cover():
+    """core_hip.band_range: contains the window of every offset (wrap-around included) and cannot be shortened at
+    either end; the bench workload's band (25 columns of the 64k configuration)."""
+    from ska_sdp_exec_swiftly_amd.core_hip import band_range
+
+    N, yN, m = 65536, 32768, 512
+    rng = numpy.random.default_rng(1)
+    for trial in range(20):
+        offs = [int(o) * 928 for o in rng.integers(-70, 71, size=rng.integers(1, 12))]
+        start, length = band_range(N, yN, m, offs)
+        inside = numpy.zeros(yN, dtype=bool)
+        inside[(start + numpy.arange(length)) % yN] = True
+        used = numpy.zeros(yN, dtype=bool)
+        for off in offs:
+            s = off * yN // N
+            used[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN] = True
+        assert inside[used].all()
+        assert used[start] and used[(start + length - 1) % yN], trial  # tight at both ends
+        # no other cyclic range that covers `used` is shorter: the complement of the band is the largest unused run
+        ring = numpy.concatenate([used, used])
+        longest = max(len(run) for run in "".join("u" if u else "." for u in ring).split("u"))
+        assert length == yN - min(longest, yN - used.sum())
+    offs = [i * 928 for i in range(-12, 13)]
+    assert band_range(N, yN, m, offs)[1] == 24 * 464 + 512
+    assert band_range(N, yN, m, [i * 928 for i in range(71)]) == (0, yN)
