@@ -127,6 +127,8 @@ __global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, co
         in_row = r1;
     }
     if (A.in_rowmap) in_row = A.in_rowmap[in_row];
+    const float alive = in_row < 0 ? 0.f : 1.f;  // a row absent from a compacted input (map entry < 0) reads as zeros
+    if (in_row < 0) in_row = 0;
     const cx<float>* __restrict__ in = gin + (long long)in_row * A.in_pitch;  // uniform base
     cx<float>* __restrict__ out = gout + (long long)row * A.out_pitch;
     const float sg_ld = A.conj_ld ? -1.f : 1.f;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, co
                     if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
                     x[v] = in[idx];
                     const float wv = lw[qs * lws];
-                    w[v] = ok ? wv : 0.f;
+                    w[v] = ok ? wv * alive : 0.f;
                 });
             }
             if constexpr (c > 0) {
@@ -171,7 +173,8 @@ __global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, co
         });
         static_for<0, P>([&](auto vI) {
             constexpr int v = decltype(vI)::value;
-            x[v].y *= sg_ld;
+            x[v].x *= alive;
+            x[v].y *= sg_ld * alive;
         });
     }
 
@@ -248,6 +251,8 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
         in_row = r1;
     }
     if (A.in_rowmap) in_row = A.in_rowmap[in_row];
+    const float alive = in_row < 0 ? 0.f : 1.f;  // row absent from a compacted input: zeros
+    if (in_row < 0) in_row = 0;
     // row base pointers are wave-uniform: pin them to SGPRs so that every access is SGPR base + 32-bit lane offset
     // the row indices are wave-uniform: pin them to SGPRs so that the row bases are scalar and every access is
     // global_load/store  SGPR base + 32-bit lane offset  (the pointers keep their global address space;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
             unsigned idx = (unsigned)(qs + A.ld_c);
             if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
             const cx<float> a = rp_load(in + idx);
-            float w = ok ? 1.f : 0.f;
+            float w = ok ? alive : 0.f;
             if constexpr (HAS_WIN) w *= ld_win[qs];
             const float ax = a.x * w, ay = a.y * w * sg_ld;
             y.x += ax * cr[q] - ay * ci[q];

@@ -117,6 +117,8 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
         in_row = r1;
     }
     if (A.in_rowmap) in_row = A.in_rowmap[in_row];
+    const bool absent = in_row < 0;  // row absent from a compacted input (map entry < 0): reads as zeros
+    if (absent) in_row = 0;
     const int b = blockIdx.y;
     const cx<R>* __restrict__ in = A.in + in_row * A.in_rs + (long long)o * A.in_os + (long long)b * A.in_bs;
     cx<R>* __restrict__ out = A.out + row * A.out_rs + (long long)o * A.out_os + (long long)b * A.out_bs;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
     const R* __restrict__ win1 = A.ld.win ? A.ld.win : &kOneTable<R>::value;
     const R* __restrict__ win2 = A.ld.win2 ? A.ld.win2 : &kOneTable<R>::value;
     const int w1s = A.ld.win ? 1 : 0, w2s = A.ld.win2 ? 1 : 0;
-    const R live_f = live ? (R)1 : (R)0;
+    const R live_f = (live && !absent) ? (R)1 : (R)0;
     if (A.raw_ld) {  // uniform over the launch
         static_for<0, P>([&](auto vI) {
             constexpr int v = decltype(vI)::value;

@@ -148,6 +148,20 @@ def test_extract_column_rowmap_on_strided_bf(dtype):
             assert got.shape == (m, yN)
             rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
             assert rel < tol, rel
+    # a window that asks for rows the compacted buffer does not hold (map entry -1): those rows read as zeros
+    # (no out-of-bounds access through a negative map entry), on both layouts and every row kernel
+    other = 2 * 448
+    needs = numpy.zeros(yN, dtype=bool)
+    s0 = other * yN // N
+    needs[(yN // 2 - m // 2 + numpy.arange(m) + s0) % yN] = True
+    assert (rm[needs] < 0).any() and (rm[needs] >= 0).any()
+    held = full.astype(complex).copy()
+    held[rm < 0] = 0
+    want = orc.extract_column(ref, held, other, 1408)
+    for src in (bf_c, bf_t):
+        got = core.extract_column(src, other, 1408, rowmap=rowmap).cpu().numpy()
+        rel = numpy.sqrt(numpy.mean(numpy.abs(got - want) ** 2) / numpy.mean(numpy.abs(want) ** 2))
+        assert rel < tol, rel
 
 
 def test_integration_binding_host_staging():
