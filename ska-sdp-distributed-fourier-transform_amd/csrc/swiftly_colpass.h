@@ -120,6 +120,7 @@ struct CGeo {
     static constexpr int LOGN = LOGN_, LOGP = LOGP_;
     static constexpr bool SPLIT = SPLIT_;
     static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P;  // T waves per workgroup
+    static constexpr bool WAVE_ROWS = false;  // a column's points are spread over the T waves
     static constexpr int NT = 64 * T;
     static constexpr int RB = 64;  // columns per tile == lanes
     static constexpr int ELEM = SPLIT ? 4 : 8;

@@ -267,6 +267,8 @@ struct Geo {
     static constexpr int LOGPAD = eff_logpad(ELEM, LOGP);
     static constexpr int PITCH = N + (N >> LOGPAD);
     static constexpr size_t LDS_BYTES = (size_t)RB * PITCH * ELEM;
+    // the T threads of a row are consecutive threads of ONE wave (row-per-slice layout, rowfast = false): row_sync
+    static constexpr bool WAVE_ROWS = T <= 64 && (64 % T) == 0;
 };
 
 // Position of (row rb, element e) in the exchange buffer.  rowfast: the RB rows
@@ -449,26 +451,45 @@ __device__ __forceinline__ void gather_pass(int t, int rb, bool rowfast, const T
     });
 }
 
+// Synchronisation between the scatter and the gather of an exchange.  A row whose T threads sit inside ONE wave
+// (T <= 64, row-per-wave-slice layout) needs no workgroup barrier: the LDS operations of a wave execute in order, so
+// an ordering point for the compiler is enough and the waves of the workgroup stop marching in lock-step
+// (SWF_WAVE_SYNC=0 restores the barriers for A/B runs).
+#ifndef SWF_WAVE_SYNC
+#define SWF_WAVE_SYNC 1
+#endif
+template <class G>
+__device__ __forceinline__ void row_sync(bool rowfast) {
+    if constexpr (SWF_WAVE_SYNC && G::WAVE_ROWS) {
+        if (rowfast)
+            __syncthreads();
+        else
+            __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 template <class G, typename R, int LOGNS, int LOGR, bool PAIRJ = false>
 __device__ __forceinline__ void phase_exchange(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds) {
     if constexpr (!G::SPLIT) {
         cx<R>* buf = reinterpret_cast<cx<R>*>(lds);
         exchange_pass<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, buf, [](cx<R> v) { return v; }, true);
-        __syncthreads();
+        row_sync<G>(rowfast);
         gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, cx<R> val) { x[decltype(vI)::value] = val; });
-        __syncthreads();
+        row_sync<G>(rowfast);
     } else {
         // re and im separately: halves the LDS footprint
         R* buf = reinterpret_cast<R*>(lds);
         exchange_pass<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.x; }, true);
-        __syncthreads();
+        row_sync<G>(rowfast);
         // every old real part is in LDS now, so x[].x can take the new ones
         gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, R val) { x[decltype(vI)::value].x = val; });
-        __syncthreads();
+        row_sync<G>(rowfast);
         exchange_pass<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, buf, [](cx<R> v) { return v.y; }, false);
-        __syncthreads();
+        row_sync<G>(rowfast);
         gather_pass<G, R>(t, rb, rowfast, buf, [&](auto vI, R val) { x[decltype(vI)::value].y = val; });
-        __syncthreads();
+        row_sync<G>(rowfast);
     }
 }
 

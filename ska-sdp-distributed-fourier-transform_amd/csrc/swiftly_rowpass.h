@@ -66,6 +66,7 @@ struct RGeo {
     static constexpr int LOGN = LOGN_, LOGP = LOGP_;
     static constexpr bool SPLIT = SPLIT_;
     static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P, NT = T;
+    static constexpr bool WAVE_ROWS = false;  // a row spans the whole workgroup
     static constexpr int RB = 1;
     static constexpr int ELEM = SPLIT ? 4 : 8;
     // PAD_ = false: exactly N elements (64 KiB for the 16384-point split exchange) so that TWO workgroups fit

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void sum_finish_rows_kernel(const SumFinishArg
         constexpr int v = decltype(vI)::value;
         acc[lds_pos<GX>(rb, t + v * TR, false)] = cx<float>{0.f, 0.f};
     });
-    __syncthreads();
+    row_sync<GX>(false);
 
     for (int g = 0; g < A.ngroups; g++) {
         const cx<float>* __restrict__ in = A.in + (long long)g * A.in_gs + (long long)b * A.in_bs + (long long)rrow * A.in_rs;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void sum_finish_rows_kernel(const SumFinishArg
             o.y += v.y * w;
             *p = o;
         });
-        __syncthreads();  // also protects ex_m reuse by the next group
+        row_sync<GX>(false);  // also protects ex_m reuse by the next group
     }
 
     cx<float> y[PX];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void sum_finish_rows_kernel(const SumFinishArg
         val.y = -val.y;  // inverse transform = conj(FFT(conj(.)))
         y[v] = val;
     });
-    __syncthreads();
+    row_sync<GX>(false);
     cx<float>* __restrict__ out = A.out + (long long)b * A.out_bs + (long long)rrow * A.out_rs;
     const float* __restrict__ mask = A.mask ? A.mask + (long long)b * A.mask_bs : nullptr;
     const int st_a = A.st_a[b];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void sum_finish_facets_kernel(const SumFinishF
         constexpr int v = decltype(vI)::value;
         acc[lds_pos<GX>(rb, t + v * TR, false)] = cx<float>{0.f, 0.f};
     });
-    __syncthreads();
+    row_sync<GX>(false);
 
     for (int f = 0; f < A.nfacets; f++) {
         const int base = A.base0[f];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void sum_finish_facets_kernel(const SumFinishF
             o.y += v.y * w;
             *p = o;
         });
-        __syncthreads();  // also protects ex_m reuse by the next facet
+        row_sync<GX>(false);  // also protects ex_m reuse by the next facet
     }
 
     cx<float> y[PX];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void sum_finish_facets_kernel(const SumFinishF
         val.y = -val.y;  // inverse transform = conj(FFT(conj(.)))
         y[v] = val;
     });
-    __syncthreads();
+    row_sync<GX>(false);
     cx<float>* __restrict__ out = A.out + (long long)b * A.out_bs + (long long)(live ? row : 0) * A.out_rs;
     const float* __restrict__ mask = A.mask ? A.mask + (long long)b * A.mask_bs : nullptr;
     const int st_a = A.st_a[b];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void split_prepare_facets_kernel(const SplitFa
         fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
             acc[lds_pos<GX>(rb, e ^ (X >> 1), false)] = v;
         });
-        __syncthreads();
+        row_sync<GX>(false);
     }
     const float scale = 1.f / (float)M;
     for (int f = 0; f < A.nfacets; f++) {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void split_prepare_facets_kernel(const SplitFa
         fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
             if (on) out[e ^ (M >> 1)] = cx<float>{v.x * scale, -v.y * scale};
         });
-        __syncthreads();  // ex_m is reused by the next facet
+        row_sync<GX>(false);  // ex_m is reused by the next facet
     }
 }
 
