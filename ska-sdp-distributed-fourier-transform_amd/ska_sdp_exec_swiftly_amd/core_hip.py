@@ -532,13 +532,16 @@ class SwiftlyCoreHip:
         n_rows = self.yN_size if rowmap is None else int(n_rows)
         if out is None:
             out = torch.empty((F, n_rows, m), dtype=bands.dtype, device=self._device)
-        offs = (ctypes.c_int64 * F)(*[int(o) for o in facet_off0s])
+        # one wave through the multi-wave entry point: it takes the caller-owned four-step scratch (a stream-ordered
+        # allocation per call costs host time, see swiftly_hip.h)
+        scr = self.scratch("k2", F * self.yN_size * m * 8)
+        cvp = ctypes.c_void_p
         _lib.check(
-            self._lib.swiftly_hip_prepare_facet_columns(
-                self._handle, self._code(bands), ctypes.c_void_p(bands.data_ptr()), int(yB), bands.stride(1),
-                bands.stride(0), F, offs, int(band[0]), int(band[1]), int(subgrid_off1),
-                ctypes.c_void_p(out.data_ptr()), out.stride(1), out.stride(0),
-                ctypes.c_void_p(rowmap.data_ptr()) if rowmap is not None else None, self._stream(),
+            self._lib.swiftly_hip_prepare_facet_columns_waves(
+                self._handle, self._code(bands), cvp(bands.data_ptr()), int(yB), bands.stride(1), bands.stride(0), F,
+                self._i64(facet_off0s), int(band[0]), int(band[1]), 1, self._i64([subgrid_off1]), cvp(out.data_ptr()),
+                out.stride(1), out.stride(0), 0, cvp(rowmap.data_ptr()) if rowmap is not None else None, 0,
+                cvp(scr.data_ptr()), scr.numel(), self._stream(),
             )
         )
         return out
