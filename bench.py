@@ -515,11 +515,19 @@ def main():
         produced = [fwd.get_wave(wave).clone() for wave in waves]
         del fwd
         torch.cuda.synchronize()
+        # band schedule (waves by off1) wherever its kernels exist, else the reference schedule (waves by off0)
+        baxis = 1 if cfg.core.supports_backward_band(torch.complex64) else 0
+        bkey = (lambda c: c.off1) if baxis == 1 else (lambda c: c.off0)
+        lookup = {(c.off0, c.off1): data[k] for wave, data in zip(waves, produced) for k, c in enumerate(wave)}
+        bwaves = {}
+        for c in sg_cfgs:
+            bwaves.setdefault(bkey(c), []).append(c)
+        bwaves = list(bwaves.values())
 
         def backward_pass():
-            bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=sg_cfgs, wave_axis=wave_axis)
-            for wave, data in zip(waves, produced):
-                bwd.add_new_subgrid_tasks(wave, [data[k] for k in range(len(wave))])
+            bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=sg_cfgs, wave_axis=baxis)
+            for wave in bwaves:
+                bwd.add_new_subgrid_tasks(wave, [lookup[(c.off0, c.off1)] for c in wave])
             return bwd.finish()
 
         try:
@@ -538,13 +546,13 @@ def main():
             backward = dict(
                 ms_per_pass=round(b_ms, 3), passes=nb, each_ms=[round(t, 2) for t in each],
                 ratio_to_forward=round(b_ms / ms_per_step, 3),
-                schedule="band accumulators, waves by off1" if wave_axis == 1 else "reference schedule, waves by off0",
+                schedule="band accumulators, waves by off1" if baxis == 1 else "reference schedule, waves by off0",
                 subgrids=S, facets=F, finite=finite,
             )
             del out
         except (ValueError, NotImplementedError) as err:  # sizes without the band kernels
             backward = dict(skipped=str(err))
-        del produced
+        del produced, lookup
 
     line = dict(
         metric="facet_to_subgrid_contributions_per_s",
