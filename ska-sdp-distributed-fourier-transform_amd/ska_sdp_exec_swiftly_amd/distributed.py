@@ -91,6 +91,16 @@ def _all_to_all(send, in_counts, out_counts, group=None, async_op=True):
     torch = _torch()
     dist = torch.distributed
     recv = torch.empty(int(sum(out_counts)), dtype=send.dtype, device=send.device)
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # ranks without RCCL between them (several processes on ONE GPU, as in tests/test_hip_multiprocess_gpu.py):
+        # stage through host memory, synchronously.  Same layouts, same counts -- only the transport differs.
+        real = send.is_complex()
+        h_send = (torch.view_as_real(send) if real else send).reshape(-1).cpu()
+        h_recv = torch.empty((2 if real else 1) * int(sum(out_counts)), dtype=h_send.dtype)
+        k = 2 if real else 1
+        dist.all_to_all_single(h_recv, h_send, [k * int(n) for n in out_counts], [k * int(n) for n in in_counts], group=group)
+        (torch.view_as_real(recv) if real else recv).reshape(-1).copy_(h_recv)
+        return _Pending(None, recv, send)
     if send.is_complex():
         work = dist.all_to_all_single(
             torch.view_as_real(recv).reshape(-1), torch.view_as_real(send).reshape(-1),

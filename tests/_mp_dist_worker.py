@@ -1,0 +1,95 @@
+"""Worker of tests/test_hip_multiprocess_gpu.py: one of WORLD_SIZE processes that share GPU 0, joined by a gloo
+process group (RCCL cannot connect several ranks on one device): runs the facet-sharded forward and backward
+transforms through the REAL process-group code path (torch.distributed collectives, split sizes, pending handles)
+with real HIP kernels, and compares with the single-process classes on rank 0."""
+import os
+import sys
+
+import numpy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd"))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+
+    import ska_sdp_exec_swiftly_amd as sw
+    from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = dict(W=11.0, fov=1.0, N=1024, yB_size=352, yN_size=512, xA_size=192, xM_size=256)
+    cfg = sw.SwiftlyConfig(backend="hip", **params)
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    sg_cfgs = sw.make_full_subgrid_cover(cfg)
+    yB = params["yB_size"]
+    facets = []
+    for j, f in enumerate(facet_cfgs):
+        r = numpy.random.default_rng(50 + j)
+        d = (r.standard_normal((yB, yB)) + 1j * r.standard_normal((yB, yB))).astype(numpy.complex64)
+        facets.append(torch.from_numpy(d * f.mask0[:, None] * f.mask1[None, :]).to(torch.complex64).cuda())
+    local = [j for j in range(len(facet_cfgs)) if j % world == rank]
+    data = [facets[j] if j in local else None for j in range(len(facet_cfgs))]
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off0, []).append(c)
+    waves = list(waves.values())
+    # forward: pipelined like bench.py
+    dfw = DistributedForward(cfg, facet_cfgs, data, lru_forward=1, dtype=torch.complex64, wave_axis=0)
+    assert (dfw.rank, dfw.world) == (rank, world)
+    got, pending = {}, None
+    for wave in waves + [None]:
+        handle = (dfw.start_wave(wave), wave) if wave is not None else None
+        if pending is not None:
+            mine, res = dfw.finish_wave(pending[0])
+            for k, i in enumerate(mine):
+                c = pending[1][i]
+                got[(c.off0, c.off1)] = res[k]
+        pending = handle
+    # every rank learns all subgrids (object gather of host copies), rank 0 checks against the single-process class
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {k: v.cpu().numpy() for k, v in got.items()})
+    everything = {k: v for part in gathered for k, v in part.items()}
+    assert sorted(everything) == sorted((c.off0, c.off1) for c in sg_cfgs)
+    ref_fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), wave_axis=0)
+    ref_sub = {}
+    for wave in waves:
+        res = ref_fwd.get_wave(wave)
+        for k, c in enumerate(wave):
+            ref_sub[(c.off0, c.off1)] = res[k]
+            a, b = everything[(c.off0, c.off1)], res[k].cpu().numpy()
+            assert numpy.abs(a - b).max() <= 2e-5 * numpy.abs(b).max(), (rank, c.off0, c.off1)
+    # backward, both schedules: every rank feeds the subgrids it "holds"
+    for axis in (0, 1):
+        key = (lambda c: c.off1) if axis == 1 else (lambda c: c.off0)
+        bw = {}
+        for c in sg_cfgs:
+            bw.setdefault(key(c), []).append(c)
+        dbw = DistributedBackward(cfg, facet_cfgs, wave_axis=axis, subgrid_configs=sg_cfgs)
+        ref_bwd = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=axis, subgrid_configs=sg_cfgs)
+        pending = None
+        for wave in bw.values():
+            mine = dbw.sharding.subgrids_of(len(wave))
+            handle = dbw.start_wave(wave, [ref_sub[(wave[i].off0, wave[i].off1)] for i in mine])
+            if pending is not None:
+                dbw.finish_wave(pending)
+            pending = handle
+            ref_bwd.add_new_subgrid_tasks(wave, [ref_sub[(c.off0, c.off1)] for c in wave])
+        dbw.finish_wave(pending)
+        idx, out = dbw.finish()
+        ref = ref_bwd.finish()
+        assert idx == local
+        for j, o in zip(idx, out):
+            rms = float(ref[j].abs().pow(2).mean().sqrt())
+            assert float((o - ref[j]).abs().pow(2).mean().sqrt()) <= 3e-5 * rms, (rank, axis, j)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}/{world}: ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()
