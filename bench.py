@@ -313,7 +313,9 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; SWIFTLY_BENCH_BACKEND=gloo (+ SWIFTLY_BENCH_OVERSUBSCRIBE=1) runs several ranks on ONE
+        # GPU with a host-staged exchange -- a functional check of this launcher path, not a measurement
+        torch.distributed.init_process_group(os.environ.get("SWIFTLY_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     p = wl["params"]
