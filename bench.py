@@ -561,7 +561,7 @@ def main():
         value=round(F * S / (ms_per_step * 1e-3), 1),
         unit="contributions/s",
         n_gpus=world,
-        rccl_ranks=world if world > 1 else 0,
+        rccl_ranks=world if world > 1 and os.environ.get("SWIFTLY_BENCH_BACKEND", "nccl") == "nccl" else 0,
         steps=args.steps,
         warmup=args.warmup,
         ms_per_step=round(ms_per_step, 3),
