@@ -1049,8 +1049,18 @@ class SwiftlyBackward:
         if core.supports_fused_subgrid(dt) and F <= 64:
             # prepare_subgrid along axis 0 on the xA columns, then ONE kernel per padded row for the contiguous-axis
             # half (prepare axis 1 + extract axis 1 for every facet, on chip) and one column pass for the rest
-            sub = self._ws("stack", (S, xA, xA), dt)
-            torch.stack(subs, out=sub)
+            step = xA * xA * subs[0].element_size()
+            base = subs[0].untyped_storage().data_ptr()
+            if all(
+                t.is_contiguous() and t.data_ptr() == subs[0].data_ptr() + i * step
+                and t.untyped_storage().data_ptr() == base  # views of ONE allocation, not neighbours by chance
+                for i, t in enumerate(subs)
+            ):
+                # the subgrids already sit back to back (slices of one wave tensor, e.g. what get_wave returned)
+                sub = torch.as_strided(subs[0], (S, xA, xA), (xA * xA, xA, 1))
+            else:
+                sub = self._ws("stack", (S, xA, xA), dt)
+                torch.stack(subs, out=sub)
             work = self._ws("work", (2 * S * xM * xA,), dt)
             self._ring ^= 1
             parts = self._ws(f"parts{self._ring}", (F, S, m, m), dt)
