@@ -7,7 +7,7 @@ template <int LOGM, int LOGX>
 static int launch_one(const SumFinishArgs& a, int nbatch, hipStream_t s) {
     using S = SFGeo<LOGM, LOGX>;
     dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
-    hipLaunchKernelGGL((sum_finish_rows_kernel<LOGM, LOGX>), grid, dim3(256), S::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((sum_finish_rows_kernel<LOGM, LOGX>), grid, dim3(S::NT), S::LDS_BYTES, s, a);
     return (int)hipGetLastError();
 }
 template <int LOGM, int LOGX>
@@ -21,7 +21,7 @@ template <int LOGM, int LOGX>
 static int launch_one_f(const SumFinishFacetArgs& a, int nbatch, hipStream_t s) {
     using S = SFGeo<LOGM, LOGX>;
     dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
-    hipLaunchKernelGGL((sum_finish_facets_kernel<LOGM, LOGX>), grid, dim3(256), S::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((sum_finish_facets_kernel<LOGM, LOGX>), grid, dim3(S::NT), S::LDS_BYTES, s, a);
     return (int)hipGetLastError();
 }
 template <int LOGM, int LOGX>
@@ -35,7 +35,7 @@ template <int LOGM, int LOGX>
 static int launch_one_s(const SplitFacetArgs& a, int nbatch, hipStream_t s) {
     using S = SFGeo<LOGM, LOGX>;
     dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
-    hipLaunchKernelGGL((split_prepare_facets_kernel<LOGM, LOGX>), grid, dim3(256), S::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((split_prepare_facets_kernel<LOGM, LOGX>), grid, dim3(S::NT), S::LDS_BYTES, s, a);
     return (int)hipGetLastError();
 }
 template <int LOGM, int LOGX>

@@ -14,6 +14,11 @@
 
 namespace swf {
 
+// threads per workgroup of the row-wise fused kernels (one wave per row: NT / 64 rows per workgroup).
+// Measured (r2, same-box A/B): 128 gives the same time as 256 (K3-5 10.8 vs 10.7 ms per pass).
+#ifndef SWF_SF_NT
+#define SWF_SF_NT 256
+#endif
 constexpr int kSumFinishMaxGroups = 8;
 constexpr int kSumFinishMaxBatch = 64;
 
@@ -36,7 +41,7 @@ struct SumFinishArgs {
 template <int LOGM, int LOGX>
 struct SFGeo {
     static constexpr int TR = 64;  // threads per row
-    static constexpr int NT = 256;
+    static constexpr int NT = SWF_SF_NT;
     using GM = Geo<float, LOGM, LOGM - 6, NT, false>;
     using GX = Geo<float, LOGX, LOGX - 6, NT, false>;
     static_assert(LOGM >= 7, "at least two points per lane");
@@ -48,7 +53,7 @@ struct SFGeo {
 };
 
 template <int LOGM, int LOGX>
-__global__ __launch_bounds__(256) void sum_finish_rows_kernel(const SumFinishArgs A) {
+__global__ __launch_bounds__(SWF_SF_NT) void sum_finish_rows_kernel(const SumFinishArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GM = typename S::GM;
     using GX = typename S::GX;
@@ -145,7 +150,7 @@ struct SumFinishFacetArgs {
 };
 
 template <int LOGM, int LOGX>
-__global__ __launch_bounds__(256) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
+__global__ __launch_bounds__(SWF_SF_NT) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GM = typename S::GM;
     using GX = typename S::GX;
@@ -249,7 +254,7 @@ struct SplitFacetArgs {
 };
 
 template <int LOGM, int LOGX>
-__global__ __launch_bounds__(256) void split_prepare_facets_kernel(const SplitFacetArgs A) {
+__global__ __launch_bounds__(SWF_SF_NT) void split_prepare_facets_kernel(const SplitFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GM = typename S::GM;
     using GX = typename S::GX;
