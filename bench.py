@@ -47,6 +47,7 @@ for _p in (ROOT, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PARITY_TOL = 2e-5  # complex64 relative RMSE bound vs the complex128 oracle
+BACKWARD_PARITY_TOL = 4e-5  # the same for finished facets of the subgrid -> facet direction
 
 WORKLOADS = {
     "64k-sparse": dict(
@@ -142,6 +143,46 @@ def verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got_by_index, pixels=None, 
         checker="oracle/separable.py (numpy, complex128) on the subgrids produced by the timed objects",
         subgrids=len(rels),
         subgrid_offsets=[[int(sg_cfgs[i].off0), int(sg_cfgs[i].off1)] for i in sorted(got_by_index)],
+        rel_rmse=max(rels),
+        rel_rmse_each=[float(f"{r:.3e}") for r in rels],
+        max_abs_over_rms=max(maxs),
+        tol_rel_rmse=tol,
+        ok=bool(max(rels) < tol),
+    )
+
+
+def verify_facets(p, facet_cfgs, sg_cfgs, sg_vectors, facets_out, rows_per_facet=16, tol=None):
+    """Compare sampled rows of the finished facets of a backward pass over separable subgrids (device tensors
+    ``facets_out``, one per facet config) with oracle/separable.py:SeparableBackwardOracle, element by element.
+    Returns the ``backward.parity`` object of the JSON line."""
+    from oracle import separable as sep  # checker only
+    from oracle import swiftly_oracle as orc
+
+    core = orc.OracleCore(p["W"], p["N"], p["xM_size"], p["yN_size"])
+    f_items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    s_items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in sg_cfgs]
+    so = sep.SeparableBackwardOracle(core, f_items, s_items, sg_vectors)
+    tol = BACKWARD_PARITY_TOL if tol is None else tol
+    rels, maxs, rows_used = [], [], []
+    for j, (item, got_t) in enumerate(zip(f_items, facets_out)):
+        yB = item.size
+        # rows inside the facet's mask (the others are identically zero on both sides), spread over the facet
+        inside = numpy.flatnonzero(numpy.asarray(item.mask0) != 0) if item.mask0 is not None else numpy.arange(yB)
+        rng = numpy.random.default_rng(97 + j)
+        n = min(rows_per_facet, inside.size)
+        rows = numpy.sort(numpy.concatenate([inside[[0, -1]], rng.choice(inside[1:-1], size=n - 2, replace=False)]))
+        want = so.facet_rows(j, rows)
+        got = got_t[rows.tolist()].cpu().numpy()
+        rms = float(numpy.sqrt(numpy.mean(numpy.abs(want) ** 2)))
+        err = numpy.abs(got - want)
+        rels.append(float(numpy.sqrt(numpy.mean(err**2))) / rms)
+        maxs.append(float(err.max()) / rms)
+        rows_used.append(int(n))
+    return dict(
+        checker="oracle/separable.py:SeparableBackwardOracle (numpy, complex128): sampled rows of every finished facet, element by element",
+        facets=len(rels),
+        rows_per_facet=min(rows_used),
+        subgrids=len(sg_cfgs),
         rel_rmse=max(rels),
         rel_rmse_each=[float(f"{r:.3e}") for r in rels],
         max_abs_over_rms=max(maxs),
@@ -526,10 +567,11 @@ def main():
             bwaves.setdefault(bkey(c), []).append(c)
         bwaves = list(bwaves.values())
 
-        def backward_pass():
+        def backward_pass(data=None):
+            data = lookup if data is None else data
             bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=sg_cfgs, wave_axis=baxis)
             for wave in bwaves:
-                bwd.add_new_subgrid_tasks(wave, [lookup[(c.off0, c.off1)] for c in wave])
+                bwd.add_new_subgrid_tasks(wave, [data[(c.off0, c.off1)] for c in wave])
             return bwd.finish()
 
         try:
@@ -552,6 +594,17 @@ def main():
                 subgrids=S, facets=F, finite=finite,
             )
             del out
+            if picks:
+                # element-wise parity of the SAME schedule on separable subgrids (rank-1 outer products on the 1/8
+                # grid times the subgrid masks: exact in float32), sampled rows of every facet against the oracle
+                del produced, lookup
+                produced = lookup = None
+                sg_vec = [sep.subgrid_vectors(4321 + i, c.size, rank=1) for i, c in enumerate(sg_cfgs)]
+                sdata = {(c.off0, c.off1): separable_facet(torch, sg_vec[i], c) for i, c in enumerate(sg_cfgs)}
+                out = backward_pass(sdata)
+                torch.cuda.synchronize()
+                backward["parity"] = verify_facets(p, facet_cfgs, sg_cfgs, sg_vec, out, rows_per_facet=16)
+                del out, sdata
         except (ValueError, NotImplementedError) as err:  # sizes without the band kernels
             backward = dict(skipped=str(err))
         del produced, lookup
@@ -594,6 +647,9 @@ def main():
         torch.distributed.destroy_process_group()
     if parity is not None and not parity["ok"]:
         raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {parity['tol_rel_rmse']}")
+    bpar = (backward or {}).get("parity")
+    if bpar is not None and not bpar["ok"]:
+        raise SystemExit(f"bench.py: BACKWARD PARITY FAILURE rel_rmse={bpar['rel_rmse']:.3e} >= {bpar['tol_rel_rmse']}")
 
 
 if __name__ == "__main__":

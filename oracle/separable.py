@@ -30,12 +30,33 @@ Point sources (reference fourier_algorithm.py:218-264 placement rule) are
 rank-1 terms with delta vectors; ``point_source_pixels`` gives their pixel
 placement for building the device facet and ``make_subgrid_from_sources`` (the
 direct DFT, independent of the algorithm) the truth.
+
+The subgrid -> facet direction (reference core.py:328-484, composition
+api_helper.py:115-197) is linear and axis-separable in exactly the same way:
+for subgrids that are sums of outer products  sg_i = sum_r u_{i,r} (x) v_{i,r}
+the finished facet j is
+
+    facet_j = sum_i sum_r  A_{i,j,r} (x) B_{i,j,r},
+    A = mask0_j * finish_facet(add_to_facet(extract_from_subgrid(prepare_subgrid(u, sg.off0), off0_j), sg.off0), off0_j)
+    B = the same along axis 1 with (v, sg.off1, off1_j, mask1_j)                     (1-D, length yB)
+
+(``SeparableBackwardOracle``): any facet row or pixel costs ``S * R`` multiply-adds
+per output element once the 1-D chains are done, also at N = 65536 where the
+2-D oracle replica of SwiftlyBackward would need tens of GB per facet.
 """
 import numpy
 
 from . import swiftly_oracle as orc
 
-__all__ = ["facet_vectors", "SeparableOracle", "point_source_pixels", "pick_subgrids"]
+__all__ = [
+    "facet_vectors",
+    "subgrid_vectors",
+    "SeparableOracle",
+    "SeparableBackwardOracle",
+    "backward_contribution",
+    "point_source_pixels",
+    "pick_subgrids",
+]
 
 
 def facet_vectors(seed, yB, rank=2):
@@ -48,6 +69,12 @@ def facet_vectors(seed, yB, rank=2):
         return re + 1j * im
 
     return vec(), vec()
+
+
+def subgrid_vectors(seed, xA, rank=1):
+    """``(u, v)`` complex128 arrays ``[rank, xA]`` on the 1/8 grid (see :py:func:`facet_vectors`): a subgrid
+    ``sum_r u_r (x) v_r`` built from them in complex64 is exact."""
+    return facet_vectors(seed, xA, rank)
 
 
 def point_source_pixels(sources, image_size, item):
@@ -133,6 +160,84 @@ class SeparableOracle:
         if sg.mask1 is not None:
             res = res * numpy.asarray(sg.mask1)[None, :]
         return res
+
+
+class SeparableBackwardOracle:
+    """Oracle results for the facets of a backward pass over separable subgrids.
+
+    Follows the reference composition (api_helper.py:115-197: ``prepare_and_split_subgrid`` ->
+    ``accumulate_column`` -> ``accumulate_facet`` -> ``finish_facet``, all 1-D linear maps applied along one axis
+    each; facet masks after the ``finish_facet`` of their axis, api_helper.py:175-176, 195-196) with the sums over
+    subgrids deferred to the very end, which linearity allows.
+
+    :param core: ``OracleCore``
+    :param facet_items: facet cover items (offsets, size, masks)
+    :param sg_items: subgrid cover items (offsets, size, masks); the subgrid masks are applied to the vectors
+        here (the reference's subgrids arrive masked)
+    :param vectors: per subgrid ``(u[R, xA], v[R, xA])``
+    """
+
+    def __init__(self, core, facet_items, sg_items, vectors):
+        self.core = core
+        self.items = facet_items
+        off0s = sorted({f.off0 for f in facet_items})
+        off1s = sorted({f.off1 for f in facet_items})
+        sizes = {f.size for f in facet_items}
+        if len(sizes) != 1:
+            raise ValueError("facets of one size expected")
+        yB = sizes.pop()
+        # A[off0_f][i*R + r] / B[off1_f][...]: the 1-D chains WITHOUT the facet masks (facets sharing an offset share them)
+        self.A = {o: [] for o in off0s}
+        self.B = {o: [] for o in off1s}
+        for sg, (u, v) in zip(sg_items, vectors):
+            m0 = sg.mask0 if sg.mask0 is not None else 1.0
+            m1 = sg.mask1 if sg.mask1 is not None else 1.0
+            for r in range(u.shape[0]):
+                pu = core.prepare_subgrid(u[r] * m0, sg.off0)
+                pv = core.prepare_subgrid(v[r] * m1, sg.off1)
+                for o in off0s:
+                    self.A[o].append(self._chain(pu, sg.off0, o, yB))
+                for o in off1s:
+                    self.B[o].append(self._chain(pv, sg.off1, o, yB))
+        self.A = {o: numpy.array(rows) for o, rows in self.A.items()}  # [S*R, yB]
+        self.B = {o: numpy.array(rows) for o, rows in self.B.items()}
+
+    def _chain(self, prepared, sg_off, facet_off, yB):
+        core = self.core
+        contrib = core.extract_from_subgrid(prepared, facet_off, axis=0)   # core.py:370-406
+        padded = core.add_to_facet(contrib, sg_off, axis=0)                # core.py:408-449
+        return core.finish_facet(padded, facet_off, yB, axis=0)            # core.py:452-484
+
+    def facet_rows(self, j, rows):
+        """Rows ``rows`` of finished facet ``j``: ``[len(rows), yB]`` (facet masks applied)."""
+        item = self.items[j]
+        A, B = self.A[item.off0], self.B[item.off1]
+        rows = numpy.asarray(rows)
+        left = A[:, rows]
+        if item.mask0 is not None:
+            left = left * numpy.asarray(item.mask0)[rows][None, :]
+        out = left.T @ B
+        if item.mask1 is not None:
+            out = out * numpy.asarray(item.mask1)[None, :]
+        return out
+
+    def facet(self, j):
+        """The whole finished facet ``j`` (small configurations only)."""
+        return self.facet_rows(j, numpy.arange(self.items[j].size))
+
+
+def backward_contribution(core, u, v, sg, facet):
+    """``[m, m]`` contribution of the rank-R subgrid ``sum_r u_r (x) v_r`` (masks of ``sg`` applied here) to ``facet``:
+    ``prepare_and_split_subgrid`` (api_helper.py:115-139) for separable data."""
+    m = core.xM_yN_size
+    out = numpy.zeros((m, m), dtype=complex)
+    m0 = sg.mask0 if sg.mask0 is not None else 1.0
+    m1 = sg.mask1 if sg.mask1 is not None else 1.0
+    for r in range(u.shape[0]):
+        ca = core.extract_from_subgrid(core.prepare_subgrid(u[r] * m0, sg.off0), facet.off0, axis=0)
+        cb = core.extract_from_subgrid(core.prepare_subgrid(v[r] * m1, sg.off1), facet.off1, axis=0)
+        out += numpy.outer(ca, cb)
+    return out
 
 
 def pick_subgrids(sg_items, count=6):

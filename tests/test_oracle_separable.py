@@ -67,3 +67,30 @@ def test_point_sources_match_dft():
         got = so.subgrid(sg)
         # W = 11: the algorithm itself is accurate to ~1e-7 of the peak here (c.f. reference decimal=8 at W=13.56)
         assert numpy.abs(got - truth).max() < 3e-7 * numpy.abs(truth).max()
+
+
+@pytest.mark.parametrize("p", PARAMS)
+def test_separable_backward_matches_2d_oracle(p):
+    """SeparableBackwardOracle against the 2-D replica of SwiftlyBackward (orc.backward_all, pinned by the
+    reference-generated round-trip goldens), sparse subgrid subset, rank-2 masked subgrids."""
+    core = orc.OracleCore(p["W"], p["N"], p["xM"], p["yN"])
+    facet_items = orc.make_full_cover(p["N"], p["yB"])
+    sg_items = orc.make_full_cover(p["N"], p["xA"])[::2]
+    vectors = [sep.subgrid_vectors(700 + i, sg.size, rank=2) for i, sg in enumerate(sg_items)]
+    subgrids = []
+    for sg, (u, v) in zip(sg_items, vectors):
+        dense = sum(numpy.outer(u[r], v[r]) for r in range(u.shape[0])) * sg.mask0[:, None] * sg.mask1[None, :]
+        assert numpy.array_equal(dense.astype(numpy.complex64).astype(complex), dense)
+        subgrids.append(dense)
+    want = orc.backward_all(core, facet_items, sg_items, subgrids)
+    so = sep.SeparableBackwardOracle(core, facet_items, sg_items, vectors)
+    tol = 1e-12 if p["W"] < 12 else 2e-9
+    for j, w in enumerate(want):
+        got = so.facet(j)
+        assert numpy.abs(got - w).max() <= tol * numpy.abs(w).max(), j
+        rows = [0, 5, w.shape[0] - 1]
+        assert numpy.array_equal(so.facet_rows(j, rows), got[rows])
+    # contribution of one subgrid to one facet against prepare_and_split_subgrid
+    parts = orc.prepare_and_split_subgrid(core, subgrids[3], [sg_items[3].off0, sg_items[3].off1], facet_items)
+    c = sep.backward_contribution(core, *vectors[3], sg_items[3], facet_items[5])
+    assert numpy.abs(c - parts[5]).max() <= tol * numpy.abs(parts[5]).max()
