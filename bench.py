@@ -603,7 +603,8 @@ def main():
                 sdata = {(c.off0, c.off1): separable_facet(torch, sg_vec[i], c) for i, c in enumerate(sg_cfgs)}
                 out = backward_pass(sdata)
                 torch.cuda.synchronize()
-                backward["parity"] = verify_facets(p, facet_cfgs, sg_cfgs, sg_vec, out, rows_per_facet=16)
+                backward["parity"] = verify_facets(p, facet_cfgs, sg_cfgs, sg_vec, out, rows_per_facet=16,
+                                                   tol=wl.get("parity_tol"))
                 del out, sdata
         except (ValueError, NotImplementedError) as err:  # sizes without the band kernels
             backward = dict(skipped=str(err))

@@ -1423,7 +1423,8 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
     if (rows <= 0 || rows >= yN) return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1]", (long long)rows);
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
     if (nfacets <= 0 || nwaves <= 0) return 0;
-    if ((uint64_t)yN * (uint64_t)in_row_stride >= (uint64_t(1) << 32) || (uint64_t)yN * (uint64_t)out_row_stride >= (uint64_t(1) << 32))
+    // only `rows` input rows are ever read (the rest of the padded axis is zero fill)
+    if ((uint64_t)rows * (uint64_t)in_row_stride >= (uint64_t(1) << 32) || (uint64_t)yN * (uint64_t)out_row_stride >= (uint64_t(1) << 32))
         return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
     const int lo = yN / 2 - (int)(rows / 2);
     ColPassArgs c;

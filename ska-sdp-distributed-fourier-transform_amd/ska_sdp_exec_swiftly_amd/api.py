@@ -295,15 +295,16 @@ def _torch():
     return torch
 
 
-def preferred_wave_axis(swiftly_config, dtype=None):
+def preferred_wave_axis(swiftly_config, dtype=None, n_facets=None):
     """Which subgrid offset the forward engine should group "waves" by for
     row-major facets: 0 = ``off0`` (the reference's column cache key,
     api.py:300-324; full-facet transform along the strided axis 0 first),
     1 = ``off1`` (full-facet transform along the CONTIGUOUS axis first: one
     kernel instead of a four-step with a facet-sized scratch; the axis order is
     free because the transforms are separable).  1 when the kernels of that
-    pipeline exist for the configuration's sizes and dtype."""
-    return 1 if swiftly_config.core.supports_band_pipeline(dtype) else 0
+    pipeline exist for the configuration's sizes, dtype and -- when given -- the TOTAL number of facets of the
+    cover (the fused subgrid side sums all facets in one kernel, at most ``core.MAX_FUSED_FACETS``)."""
+    return 1 if swiftly_config.core.supports_band_pipeline(dtype, n_facets) else 0
 
 
 K1_DESCRIPTION = {
@@ -466,21 +467,7 @@ class SwiftlyForward:
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facet_tasks = facet_tasks
-        self.wave_axis = 0 if wave_axis is None else int(wave_axis)
-        if self.wave_axis not in (0, 1):
-            raise ValueError("wave_axis must be 0 or 1")
         self.task_queue = TaskQueue(queue_size)
-        # optional plan (extension): when the caller knows up front which subgrids it will ask for (sparse
-        # covers, scripts/demo_sparse_facet.py style), the facet-sized intermediate only keeps what those read
-        self._rowmap, self._n_rows = None, None
-        self._plan = None
-        if subgrid_configs is not None:
-            self._plan = list(subgrid_configs)
-            if self.wave_axis == 0:
-                self._rowmap, self._n_rows = self.core.subgrid_column_rows([sg.off0 for sg in subgrid_configs])
-            self._planned_keys = {int(self._key(sg)) for sg in subgrid_configs}
-        self._band = None
-        self._wave_rowmaps = {}
         self.facet_configs = [cfg for cfg, _ in facet_tasks]
         self.queue_size = queue_size
         self._client = client
@@ -499,6 +486,43 @@ class SwiftlyForward:
         if len(dtypes) > 1:
             raise ValueError("all facets must have the same dtype")
         self.dtype = dtypes.pop() if dtypes else torch.complex64
+        if wave_axis is None:
+            # default: the reference's schedule (waves keyed by off0) -- unless the caller hands over the plan of
+            # subgrids it is going to request AND the contiguous-axis-first kernels exist for this configuration:
+            # then that pipeline is used, and requests that cover only part of a planned wave are served from a
+            # bounded cache of finished subgrids (below), so that ANY request order stays cheap
+            self.wave_axis = 1 if subgrid_configs is not None and self._band_pipeline_ok() else 0
+        else:
+            self.wave_axis = int(wave_axis)
+        if self.wave_axis not in (0, 1):
+            raise ValueError("wave_axis must be 0 or 1")
+        # optional plan (extension): when the caller knows up front which subgrids it will ask for (sparse
+        # covers, scripts/demo_sparse_facet.py style), the facet-sized intermediate only keeps what those read
+        self._rowmap, self._n_rows = None, None
+        self._plan = None
+        if subgrid_configs is not None:
+            self._plan = list(subgrid_configs)
+            if self.wave_axis == 0:
+                self._rowmap, self._n_rows = self.core.subgrid_column_rows([sg.off0 for sg in subgrid_configs])
+            self._planned_keys = {int(self._key(sg)) for sg in subgrid_configs}
+        self._band = None
+        self._wave_rowmaps = {}
+        # finished subgrids computed ahead of their request (see get_subgrid_tasks): (off0, off1, size, id) -> tensor
+        self._results = {}
+        self._result_bytes = 0
+        self._result_budget = int(float(os.environ.get("SWIFTLY_RESULT_CACHE_GB", "16")) * 2**30)
+        self._plan_waves = None
+
+    def _band_pipeline_ok(self):
+        """the contiguous-axis-first pipeline can serve these facets (sizes, dtype, layout, facet count)"""
+        torch = _torch()
+        sizes = {info[1] for info in self._facet_info}
+        return (
+            self.dtype == torch.complex64
+            and len(sizes) == 1
+            and all(info[2] for info in self._facet_info)
+            and self.core.supports_band_pipeline(self.dtype, len(self._facet_info))
+        )
 
     # -- stage 1: BF_F = prepare_facet(axis 0), once per facet (api.py:281-298)
     def _prepare_one_facet(self, j):
@@ -569,7 +593,13 @@ class SwiftlyForward:
         """Finished subgrids for a list of configs; consecutive configs with the
         same wave key (``off0``, or ``off1`` when ``wave_axis == 1``) and
         ``size`` are processed as one wave.  Each result is registered with the
-        task queue (``queue_size``)."""
+        task queue (``queue_size``).
+
+        With a ``subgrid_configs`` plan, a request that covers only PART of a planned wave (e.g. the reference's
+        natural ``off0``-major loop over a cover while the waves are keyed by ``off1``) computes the whole
+        planned wave once and keeps the subgrids that were not asked for yet in a cache bounded by
+        ``SWIFTLY_RESULT_CACHE_GB`` (default 16); each cached subgrid is handed out once.  Beyond the budget the
+        request is computed on its own (correct, slower)."""
         out = []
         i = 0
         while i < len(subgrid_configs):
@@ -580,12 +610,54 @@ class SwiftlyForward:
                 and subgrid_configs[j].size == subgrid_configs[i].size
             ):
                 j += 1
-            res = self.get_wave(subgrid_configs[i:j])
-            tasks = [res[k] for k in range(j - i)]
+            tasks = self._serve_group(list(subgrid_configs[i:j]))
             self.task_queue.process(tasks)
             out.extend(tasks)
             i = j
         return out
+
+    @staticmethod
+    def _rid(sg):
+        return (int(sg.off0), int(sg.off1), int(sg.size), id(sg))
+
+    def _planned_wave_of(self, sg):
+        """the planned subgrids that share ``sg``'s wave key and size, in plan order (None without a plan or when
+        ``sg`` is not one of the plan's config objects)"""
+        if self._plan is None:
+            return None
+        if self._plan_waves is None:
+            waves = {}
+            for c in self._plan:
+                waves.setdefault((int(self._key(c)), int(c.size)), []).append(c)
+            self._plan_waves = (waves, {id(c) for c in self._plan})
+        waves, ids = self._plan_waves
+        if id(sg) not in ids:
+            return None
+        return waves.get((int(self._key(sg)), int(sg.size)))
+
+    def _serve_group(self, group):
+        """results for consecutive requests sharing the wave key: cache hits, a whole planned wave computed ahead,
+        or just the group"""
+        hits = [self._results.get(self._rid(sg)) for sg in group]
+        if all(h is not None for h in hits):
+            for sg, h in zip(group, hits):
+                del self._results[self._rid(sg)]
+                self._result_bytes -= h.numel() * h.element_size()
+            return hits
+        full = self._planned_wave_of(group[0])
+        asked = {id(sg) for sg in group}
+        if full is not None and len(asked) == len(group) and all(id(sg) in {id(c) for c in full} for sg in group):
+            extra = [c for c in full if id(c) not in asked and self._rid(c) not in self._results]
+            nbytes = sum(c.size * c.size for c in extra) * 8
+            if extra and self._result_bytes + nbytes <= self._result_budget:
+                res = self.get_wave(full)
+                by_id = {id(c): res[k] for k, c in enumerate(full)}
+                for c in extra:
+                    self._results[self._rid(c)] = by_id[id(c)]
+                self._result_bytes += nbytes
+                return [by_id[id(sg)] for sg in group]
+        res = self.get_wave(group)
+        return [res[k] for k in range(len(group))]
 
     def get_wave(self, sgs, timer=None):
         """Finished, masked subgrids ``[S, xA, xA]`` of one wave (configs sharing
@@ -665,8 +737,13 @@ class SwiftlyForward:
         self._check_planned(sgs)
         bands = self.prepare_all_facets()
         Q, rowmap, n_rows, compute = self._wave_Q(sgs[0].off1)
-        self.core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,
-                                  n_rows, Q, compute, [sg.off0 for sg in sgs], flat, g_layout=layout)
+        try:
+            self.core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,
+                                      n_rows, Q, compute, [sg.off0 for sg in sgs], flat, g_layout=layout)
+        except Exception:
+            if compute:  # Q was registered before it was computed: a later request must not find garbage
+                self.lru._items.pop(("b", sgs[0].off1), None)  # pylint: disable=protected-access
+            raise
 
     def _wave(self, sgs):
         # single-GPU route: the [m, m] contributions are never materialised -- the window gather is
@@ -687,6 +764,11 @@ class SwiftlyForward:
         torch = _torch()
         if not self.core.supports_band_pipeline(self.dtype):
             raise ValueError("wave_axis=1 is not available for this configuration / dtype (see preferred_wave_axis)")
+        if len(self.facet_configs) > self.core.MAX_FUSED_FACETS:
+            raise ValueError(
+                f"wave_axis=1 sums at most {self.core.MAX_FUSED_FACETS} facets per subgrid in its fused kernel, "
+                f"got {len(self.facet_configs)}; use wave_axis=0 (preferred_wave_axis(config, dtype, n_facets=...))"
+            )
         sizes = {info[1] for info in self._facet_info}
         if len(sizes) != 1 or not all(info[2] for info in self._facet_info) or self.dtype != torch.complex64:
             raise ValueError("wave_axis=1 needs equally sized row-major complex64 facets")
@@ -968,10 +1050,14 @@ class SwiftlyBackward:
     # pylint: disable=too-many-arguments,too-many-instance-attributes
     def __init__(self, swiftly_config, facets_config_list, lru_backward=1, queue_size=20, client=None,
                  subgrid_configs=None, wave_axis=None):
+        # wave_axis=None: the reference's schedule, unless the caller hands over the plan of subgrids it will add and
+        # the band kernels exist -- decided when the first subgrid shows the dtype (complex64 only)
+        self._auto_axis = wave_axis is None
         self.wave_axis = 0 if wave_axis is None else int(wave_axis)
         if self.wave_axis not in (0, 1):
             raise ValueError("wave_axis must be 0 or 1")
         self._plan = list(subgrid_configs) if subgrid_configs is not None else None
+        self._plan_counts = None
         self._wsbuf = {}
         self._ring = 0
         self._band = None
@@ -993,10 +1079,31 @@ class SwiftlyBackward:
         """Fold one subgrid into the facet sums (reference api.py:347-372)."""
         return self.add_new_subgrid_tasks([subgrid_config], [new_subgrid_task])
 
+    def _resolve_axis(self, first_subgrid):
+        if not self._auto_axis:
+            return
+        self._auto_axis = False
+        torch = _torch()
+        dt = first_subgrid.dtype
+        is_c64 = dt in (torch.complex64, torch.float32) if isinstance(first_subgrid, torch.Tensor) else (
+            numpy.asarray(first_subgrid).dtype in (numpy.complex64, numpy.float32)
+        )
+        sizes = {cfg.size for cfg in self.facets_config_list}
+        if self._plan is not None and is_c64 and len(sizes) == 1 and self.core.supports_backward_band(torch.complex64):
+            self.wave_axis = 1
+
     def add_new_subgrid_tasks(self, subgrid_configs, new_subgrid_tasks):
         """Fold a list of subgrids into the facet sums (extension: consecutive
-        subgrids sharing ``off0`` and ``size`` are processed as one wave with
-        batched launches; a single subgrid is a wave of one)."""
+        subgrids sharing the wave key -- ``off0``, or ``off1`` with ``wave_axis=1`` -- and ``size`` are processed
+        as one wave with batched launches).
+
+        Band schedule (``wave_axis=1``): the per-wave kernels run over ALL subgrids of a wave at once, so subgrids
+        that arrive one by one (or in pieces of a planned wave) are first staged -- a device copy into a per-key
+        buffer held in ``LRUCache(lru_backward)``, the counterpart of the reference's per-column partial sums
+        (api.py:402-438) -- and the wave is folded into the band accumulators when it is complete (plan known),
+        evicted from the cache, or at :py:meth:`finish`."""
+        if len(subgrid_configs) and self._auto_axis:
+            self._resolve_axis(new_subgrid_tasks[0])
         col = None
         i = 0
         key = "off1" if self.wave_axis == 1 else "off0"
@@ -1008,9 +1115,61 @@ class SwiftlyBackward:
                 and subgrid_configs[j].size == subgrid_configs[i].size
             ):
                 j += 1
-            col = self._add_wave(subgrid_configs[i:j], new_subgrid_tasks[i:j])
+            if self.wave_axis == 1:
+                col = self._add_band_group(subgrid_configs[i:j], new_subgrid_tasks[i:j])
+            else:
+                col = self._add_wave(subgrid_configs[i:j], new_subgrid_tasks[i:j])
             i = j
         return col
+
+    # ---- wave_axis = 1: staging of partial waves (the role of lru_backward in the band schedule)
+    def _planned_count(self, off1, size):
+        if self._plan is None:
+            return None
+        if self._plan_counts is None:
+            counts = {}
+            for c in self._plan:
+                k = (int(c.off1), int(c.size))
+                counts[k] = counts.get(k, 0) + 1
+            self._plan_counts = counts
+        return self._plan_counts.get((int(off1), int(size)))
+
+    def _add_band_group(self, sgs, subgrids):
+        key = (int(sgs[0].off1), int(sgs[0].size))
+        staged = self.lru.get(key)
+        planned = self._planned_count(*key)
+        if staged is None and (len(sgs) == planned or (planned is None and len(sgs) > 1)):
+            return self._add_wave(list(sgs), list(subgrids))  # a whole wave at once: no staging copy
+        torch = _torch()
+        core = self.core
+        xA = sgs[0].size
+        if staged is None:
+            cap = planned if planned is not None else 8
+            staged = dict(cfgs=[], buf=torch.empty((max(cap, len(sgs)), xA, xA), dtype=torch.complex64, device=core.device))
+        need = len(staged["cfgs"]) + len(sgs)
+        if need > staged["buf"].shape[0]:
+            grown = torch.empty((max(need, 2 * staged["buf"].shape[0]), xA, xA), dtype=torch.complex64, device=core.device)
+            grown[: len(staged["cfgs"])].copy_(staged["buf"][: len(staged["cfgs"])])
+            staged["buf"] = grown
+        for sg, data in zip(sgs, subgrids):
+            ten, _ = core._as_device(data)  # pylint: disable=protected-access
+            if tuple(ten.shape) != (xA, xA):
+                raise ValueError(f"subgrid has shape {tuple(ten.shape)}, expected {(xA, xA)}")
+            if ten.dtype != torch.complex64:
+                raise ValueError("SwiftlyBackward(wave_axis=1) needs complex64 data and power-of-two yN_size / xM_yN_size")
+            staged["buf"][len(staged["cfgs"])].copy_(ten)
+            staged["cfgs"].append(sg)
+        if planned is not None and len(staged["cfgs"]) >= planned:
+            self.lru._items.pop(key, None)  # pylint: disable=protected-access
+            return self._flush_staged(staged)
+        old_key, old = self.lru.set(key, staged)
+        if old_key is not None and old is not None:
+            self._flush_staged(old)
+        return self._bands
+
+    def _flush_staged(self, staged):
+        n = len(staged["cfgs"])
+        return self._add_wave(staged["cfgs"], [staged["buf"][k] for k in range(n)])
 
     def _ws(self, name, shape, dtype):
         """Grow-only persistent workspace (per-wave allocations of changing size are kept away from the caching
@@ -1181,20 +1340,24 @@ class SwiftlyBackward:
         if self._planned is not None and off1 not in self._planned:
             raise ValueError(f"subgrid off1={off1} is not in the subgrid_configs this SwiftlyBackward was planned for")
         F = len(self.facets_config_list)
-        base = chunks[0][1]
-        offs, fstr, off0s, locs = [], [], [], []
+        dt0 = chunks[0][1].dtype
+        fstr, off0s, locs = [], [], []
         fixed = []
         for c, (sgs, parts) in enumerate(chunks):
-            if parts.shape[0] != F or parts.dtype != base.dtype:
+            if parts.shape[0] != F or parts.dtype != dt0:
                 raise ValueError("contribution chunk does not match the facet list / dtype")
             if parts.stride(3) != 1 or parts.stride(2) != m or (parts.shape[1] > 1 and parts.stride(1) != m * m):
                 parts = parts.contiguous()
             fixed.append(parts)  # keeps a contiguous copy alive until the launch is queued
-            offs.append((parts.data_ptr() - base.data_ptr()) // base.element_size())
             fstr.append(parts.stride(0) if F > 1 else 0)
             for b, sg in enumerate(sgs):
                 off0s.append(sg.off0)
                 locs.append((c, b))
+        # chunk offsets are relative to the LOWEST chunk address: the gather-sum kernel reads a negative 64-bit offset
+        # as "no source row", so a chunk allocated below the base (a contiguous copy, a separately allocated chunk
+        # handed to accumulate_chunks) would otherwise be dropped silently
+        base = min(fixed, key=lambda t: t.data_ptr())
+        offs = [(t.data_ptr() - base.data_ptr()) // base.element_size() for t in fixed]
         if len(chunks) > core.GS_MAX_CHUNKS:
             raise ValueError(f"at most {core.GS_MAX_CHUNKS} contribution chunks per wave")
         for _members, table in core.column_row_sources(off0s, locs):
@@ -1239,6 +1402,8 @@ class SwiftlyBackward:
         torch = _torch()
         core = self.core
         if self.wave_axis == 1:
+            for _key, staged in self.lru.pop_all():
+                self._flush_staged(staged)
             out = self._finish_bands()
             self.task_queue.wait_all_done()
             return out

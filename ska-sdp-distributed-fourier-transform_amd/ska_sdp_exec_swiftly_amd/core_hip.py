@@ -472,18 +472,23 @@ class SwiftlyCoreHip:
             logs[name] = n.bit_length() - 1
         return logs
 
-    def supports_fused_subgrid(self, dtype=None):
-        """True when transform_contributions + sum_finish_facets (include/swiftly_hip.h) exist for these sizes."""
+    MAX_FUSED_FACETS = 64  # kSumFinishMaxFacets (csrc/swiftly_sumfinish.h): facets summed by one sum_finish_facets call
+
+    def supports_fused_subgrid(self, dtype=None, n_facets=None):
+        """True when transform_contributions + sum_finish_facets (include/swiftly_hip.h) exist for these sizes
+        (and, when given, for ``n_facets`` facets: the facet sum runs inside one kernel)."""
         torch = _torch()
         logs = self._logs()
         if logs is None or (dtype is not None and dtype != torch.complex64):
             return False
+        if n_facets is not None and n_facets > self.MAX_FUSED_FACETS:
+            return False
         pairs = {(7, 8), (7, 10), (8, 9), (8, 10), (9, 10), (9, 11), (10, 11)}  # sum_finish instances
         return logs["m"] <= 9 and (logs["m"], logs["xM"]) in pairs
 
-    def supports_band_pipeline(self, dtype=None):
+    def supports_band_pipeline(self, dtype=None, n_facets=None):
         """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
-        return self.supports_fused_subgrid(dtype) and self._logs()["yN"] in (14, 15, 16) and self._logs()["m"] >= 6
+        return self.supports_fused_subgrid(dtype, n_facets) and self._logs()["yN"] in (14, 15, 16) and self._logs()["m"] >= 6
 
     def supports_backward_band(self, dtype=None):
         """True when accumulate_facet_columns / finish_facet_band (include/swiftly_hip.h) exist for these sizes."""

@@ -219,7 +219,7 @@ class DistributedForward:
         local = self.sharding.local_facets
         self.dtype = dtype if dtype is not None else torch.complex64
         if wave_axis is None:
-            wave_axis = preferred_wave_axis(swiftly_config, self.dtype)
+            wave_axis = preferred_wave_axis(swiftly_config, self.dtype, n_facets=len(self.facet_configs))
         self.local = SwiftlyForward(
             swiftly_config,
             [(self.facet_configs[j], facet_data[j]) for j in local],
@@ -232,7 +232,16 @@ class DistributedForward:
         self.local.dtype = self.dtype
         self.wave_axis = wave_axis
         self.arrival_cfgs = [self.facet_configs[j] for j in self.sharding.arrival_order]
-        self.fused = self.dtype == torch.complex64 and self.local.supports_fused_subgrid_side()
+        # the receiving side sums over ALL facets of the cover in one kernel (<= MAX_FUSED_FACETS of them)
+        self.fused = (
+            self.dtype == torch.complex64
+            and self.core.supports_fused_subgrid(self.dtype, n_facets=len(self.facet_configs))
+        )
+        if self.wave_axis == 1 and not self.fused:
+            raise ValueError(
+                f"wave_axis=1 needs the fused subgrid side (complex64, <= {self.core.MAX_FUSED_FACETS} facets in total); "
+                "use wave_axis=0 (preferred_wave_axis(config, dtype, n_facets=...) says which)"
+            )
 
     def prepare_all_facets(self):
         """K1 for the local facets"""
@@ -305,13 +314,26 @@ class DistributedBackward:
     api_helper.py:115-139) in owner-major facet order -- which makes the result
     the send buffer -- and the mirror all-to-all delivers them to the facets'
     owners, who accumulate (api_helper.py:142-179) and finally finish their
-    facets (api_helper.py:182-197)."""
+    facets (api_helper.py:182-197).  ``dtype``: complex dtype of the pass; all ranks must agree on it (a rank
+    that holds no subgrid of a wave -- with ``balance`` the ranks carrying an extra facet never do -- cannot infer
+    it from data, and the all-to-all needs matching element sizes on every rank); default complex64.
+
+    At most ``MAX_IN_FLIGHT`` waves may be started and not yet finished: the send buffer of the fused route is
+    one of two alternating workspaces, so :py:meth:`start_wave` makes the compute stream wait for the exchange
+    that last read the slot it is about to overwrite."""
+
+    MAX_IN_FLIGHT = 2
 
     # pylint: disable=too-many-arguments
     def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None, rank_world=None, wave_axis=0,
-                 subgrid_configs=None):
+                 subgrid_configs=None, dtype=None):
         from .api import SwiftlyBackward  # pylint: disable=import-outside-toplevel
 
+        torch = _torch()
+        self.dtype = dtype if dtype is not None else torch.complex64
+        if self.dtype not in (torch.complex64, torch.complex128):
+            raise ValueError("dtype must be torch.complex64 or torch.complex128")
+        self._started = []  # exchanges started and not yet finished, oldest first
         self.group = group
         self.wave_axis = int(wave_axis)
         self.rank, self.world = rank_world if rank_world is not None else _dist_info(group)
@@ -328,6 +350,7 @@ class DistributedBackward:
         self.splitter = SwiftlyBackward(
             swiftly_config, [self.facet_configs[j] for j in self.sharding.arrival_order], lru_backward=1
         )
+        self.local.dtype = self.splitter.dtype = self.dtype
 
     def pack_wave(self, sgs, subgrids_mine):
         """``sgs``: all subgrid configs of the wave (same size and same ``off0`` -- ``off1`` with ``wave_axis=1``,
@@ -346,10 +369,10 @@ class DistributedBackward:
         in_counts, out_counts = backward_layout(self.sharding, S, m * m)
         if mine:
             send = self.splitter.wave_contributions([sgs[i] for i in mine], subgrids_mine).reshape(-1)
-            self.local.dtype = self.local.dtype or send.dtype
+            if send.dtype != self.dtype:
+                raise ValueError(f"subgrids are {send.dtype}, the pass was declared {self.dtype}")
         else:
-            dt = self.local.dtype or self.splitter.dtype or torch.complex64
-            send = torch.empty(0, dtype=dt, device=core.device)
+            send = torch.empty(0, dtype=self.dtype, device=core.device)
         return send, in_counts, out_counts
 
     def unpack_wave(self, sgs, recv):
@@ -372,13 +395,20 @@ class DistributedBackward:
 
     def start_wave(self, sgs, subgrids_mine):
         """:py:meth:`pack_wave` + start of the mirror all-to-all; returns a handle for :py:meth:`finish_wave`."""
+        # the send buffer about to be written may still be read by the exchange started MAX_IN_FLIGHT waves ago
+        while len(self._started) >= self.MAX_IN_FLIGHT:
+            self._started.pop(0).wait()  # stream-side wait on the collective (no host block for RCCL)
         send, in_counts, out_counts = self.pack_wave(sgs, subgrids_mine)
-        return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
+        pending = exchange_blocks(send, in_counts, out_counts, self.group)
+        self._started.append(pending)
+        return sgs, pending
 
     def finish_wave(self, handle):
         """Wait for the exchange and :py:meth:`unpack_wave`."""
         sgs, pending = handle
-        self.unpack_wave(sgs, pending.wait())
+        recv = pending.wait()
+        self._started = [q for q in self._started if q is not pending]
+        self.unpack_wave(sgs, recv)
 
     def add_wave(self, sgs, subgrids_mine):
         """start_wave + finish_wave"""

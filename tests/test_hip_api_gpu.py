@@ -273,7 +273,7 @@ def test_distributed_classes_world1(params, dtype):
     dfw = DistributedForward(cfg, facet_cfgs, [torch.from_numpy(f).cuda() for f in facets], dtype=tdt, wave_axis=0)
     assert dfw.fused == (dtype == numpy.complex64)
     bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=2)
-    dbw = DistributedBackward(cfg, facet_cfgs, lru_backward=2)
+    dbw = DistributedBackward(cfg, facet_cfgs, lru_backward=2, dtype=tdt)
     waves = {}
     for c in sg_cfgs:
         waves.setdefault(c.off0, []).append(c)

@@ -239,3 +239,96 @@ def test_forward_pipelines_match_oracle_small_rows(axis, monkeypatch):
     # unplanned subgrid is refused
     with pytest.raises(ValueError):
         fwd.get_subgrid_task(sw.SubgridConfig(5 * xA, 5 * xA, xA))
+
+
+def _small_rows_problem(seed=41):
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+
+    yB, xA = 352, 928
+    P = dict(W=W64, fov=1.0, N=N64, yB_size=yB, yN_size=yN64, xA_size=xA, xM_size=xM64)
+    cfg = sw.SwiftlyConfig(backend="hip", **P)
+    fstep = cfg.facet_off_step
+    facet_cfgs = [sw.FacetConfig(o0, o1, yB) for o0, o1 in ((0, 0), (0, 50 * fstep), (-70 * fstep, 0))]
+    vectors = [sep.facet_vectors(seed + j, yB, rank=2) for j in range(len(facet_cfgs))]
+    facets = [bench.separable_facet(torch, vectors[j], c) for j, c in enumerate(facet_cfgs)]
+    # a 3 x 4 block of subgrids in the reference's natural (off0-major) order
+    sg_cfgs = [sw.SubgridConfig(i0 * xA, i1 * xA, xA) for i0 in (0, 2, 69) for i1 in (0, 3, 4, 70)]
+    return torch, sw, cfg, facet_cfgs, facets, sg_cfgs
+
+
+def test_forward_default_axis_with_plan_serves_any_order():
+    """SwiftlyForward(subgrid_configs=plan) without wave_axis picks the contiguous-axis-first pipeline, and the
+    reference's one-subgrid-at-a-time off0-major loop costs one wave computation per off1 (finished subgrids of a
+    planned wave are cached until they are asked for), with results identical to whole-wave requests."""
+    torch, sw, cfg, facet_cfgs, facets, sg_cfgs = _small_rows_problem()
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs)
+    if not cfg.core.supports_band_pipeline(torch.complex64):
+        assert fwd.wave_axis == 0
+        pytest.skip("band pipeline not available")
+    assert fwd.wave_axis == 1
+    calls = []
+    inner = fwd.get_wave
+    fwd.get_wave = lambda sgs, timer=None: (calls.append(len(sgs)), inner(sgs, timer))[1]
+    got = [fwd.get_subgrid_task(c).cpu().numpy() for c in sg_cfgs]  # off0-major, one at a time
+    assert calls == [3, 3, 3, 3]  # one launch sequence per off1 wave, each over the 3 planned subgrids
+    assert not fwd._results and fwd._result_bytes == 0  # every cached subgrid was handed out
+    ref = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
+    by1 = sorted(range(len(sg_cfgs)), key=lambda i: (sg_cfgs[i].off1, i))
+    want = ref.get_subgrid_tasks([sg_cfgs[i] for i in by1])
+    for k, i in enumerate(by1):
+        assert numpy.array_equal(got[i], want[k].cpu().numpy())
+    # a second request for a subgrid that was already handed out recomputes (and caches the rest of its wave again)
+    again = fwd.get_subgrid_task(sg_cfgs[5]).cpu().numpy()
+    assert numpy.array_equal(again, got[5]) and len(fwd._results) == 2
+    # without the budget the group is computed on its own
+    fwd2 = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs)
+    fwd2._result_budget = 0
+    one = fwd2.get_subgrid_task(sg_cfgs[5]).cpu().numpy()
+    assert not fwd2._results and relrms(one, got[5]) < 1e-6
+    # the separable oracle agrees
+    ref_core = core64()[1]
+    so = sep.SeparableOracle(ref_core, [orc.CoverItem(c.off0, c.off1, c.size) for c in facet_cfgs],
+                             [sep.facet_vectors(41 + j, 352, rank=2) for j in range(3)])
+    c = sg_cfgs[5]
+    assert relrms(got[5], so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))) < 2e-5
+
+
+@pytest.mark.parametrize("lru_backward", [1, 2])
+def test_backward_default_axis_with_plan_stages_single_adds(lru_backward):
+    """SwiftlyBackward(subgrid_configs=plan) without wave_axis picks the band schedule for complex64 subgrids;
+    subgrids added one by one are staged per off1 (LRUCache(lru_backward)) and each wave is folded in ONCE -- when
+    complete, or on eviction / finish() for waves the caller leaves incomplete."""
+    torch, sw, cfg, facet_cfgs, _, sg_cfgs = _small_rows_problem()
+    vec = [sep.subgrid_vectors(900 + i, c.size, rank=2) for i, c in enumerate(sg_cfgs)]
+    data = [bench.separable_facet(torch, vec[i], c) for i, c in enumerate(sg_cfgs)]
+    by1 = sorted(range(len(sg_cfgs)), key=lambda i: (sg_cfgs[i].off1, i))
+    ref = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs)
+    ref.add_new_subgrid_tasks([sg_cfgs[i] for i in by1], [data[i] for i in by1])
+    want = [t.cpu().numpy() for t in ref.finish()]
+    for order_name, order in (("off0-major", list(range(len(sg_cfgs)))), ("off1-major", by1)):
+        bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=lru_backward, subgrid_configs=sg_cfgs)
+        folds = []
+        inner = bwd._add_wave
+        bwd._add_wave = lambda sgs, subs: (folds.append(len(sgs)), inner(sgs, subs))[1]
+        for i in order:
+            bwd.add_new_subgrid_task(sg_cfgs[i], data[i])
+        assert bwd.wave_axis == 1
+        got = [t.cpu().numpy() for t in bwd.finish()]
+        if order_name == "off1-major" or lru_backward >= 4:
+            assert folds == [3, 3, 3, 3], (order_name, folds)  # each planned wave folded exactly once, when complete
+        assert sum(folds) == len(sg_cfgs)
+        for a, b in zip(got, want):
+            assert relrms(a, b) < 3e-6, order_name  # same kernels; summation order of the band columns may differ
+    # no plan: single adds are staged until eviction / finish
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=lru_backward, wave_axis=1)
+    for i in by1:
+        bwd.add_new_subgrid_task(sg_cfgs[i], data[i])
+    got = [t.cpu().numpy() for t in bwd.finish()]
+    for a, b in zip(got, want):
+        assert relrms(a, b) < 3e-6
+    # complex128 subgrids keep the reference schedule
+    b128 = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
+    b128.add_new_subgrid_task(sg_cfgs[0], data[0].to(torch.complex128))
+    assert b128.wave_axis == 0
