@@ -407,6 +407,16 @@ int swiftly_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* strea
 int swiftly_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int swiftly_hip_stream_synchronize(void* stream);
 
+/* -- CU-partitioned streams: two kernels of different character (the full-facet row transform: latency / issue bound;
+ *    the per-wave column passes: bandwidth bound) can share the chip on disjoint sets of compute units.
+ *    stream_create_cu_mask: a HIP stream whose kernels only run on the CUs whose bit is set in cu_mask (nwords 32-bit
+ *    words, bit i of word i/32 = CU i in the runtime's enumeration; hipExtStreamCreateWithCUMask).  cu_census: launches
+ *    `nblocks` one-wave workgroups on `stream` and writes per block  xcc_id << 16 | se_id << 8 | cu_id  to the device
+ *    array out[nblocks] -- how a mask maps to XCDs is not documented, so callers measure it. */
+int swiftly_hip_stream_create_cu_mask(void** stream, const uint32_t* cu_mask, int nwords);
+int swiftly_hip_stream_destroy(void* stream);
+int swiftly_hip_cu_census(int32_t* out, int nblocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

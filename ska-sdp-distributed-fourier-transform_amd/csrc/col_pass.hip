@@ -9,14 +9,15 @@ struct CGeoFor {
     // exchange re and im separately from 128 rows on: 32 KiB (n = 128) / 64 KiB (n = 256) of LDS per
     // workgroup keep 16 waves per CU resident, which is what hides the HBM latency (measured:
     // 8 waves/CU -> 84 % of wave cycles waiting, 2.2 TB/s; 16 waves/CU -> 4.7 TB/s)
-    using type = CGeo<LOGN, LOGP, (LOGN >= 7)>;
+    // 1024 points: 32-column tiles (two rows per wave), 128 KiB
+    using type = CGeo<LOGN, LOGP, (LOGN >= 7), (LOGN >= 10 ? 32 : 64)>;
 };
 
 template <int LOGN, int MODE>
 static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     using G = typename CGeoFor<LOGN>::type;
-    dim3 grid((unsigned)((a.ncols + 63) / 64), (unsigned)outer, (unsigned)nbatch);
-    if constexpr (MODE != 1) {
+    dim3 grid((unsigned)((a.ncols + G::COLS - 1) / G::COLS), (unsigned)outer, (unsigned)nbatch);
+    if constexpr (MODE != 1 && !G::HALF) {
         if (a.gs) {  // gather-sum load (backward pass); the source contributions are small and re-read: cacheable
             hipLaunchKernelGGL((col_pass_kernel<G, MODE, true, true>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out,
                                a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
@@ -46,7 +47,7 @@ static int init_mode() {
     if (!rc && MODE != 2)
         rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, (MODE == 2 ? 0 : MODE), false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    if constexpr (MODE != 1) {
+    if constexpr (MODE != 1 && !G::HALF) {
         if (!rc)
             rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);

@@ -115,21 +115,43 @@ struct ColZ {
     long long c_base[kColZC], c_fs[kColZC];  // gather-sum load: element offset / facet stride of source chunk c
 };
 
-template <int LOGN_, int LOGP_, bool SPLIT_>
+// COLS_ = 64: a wave works on ONE row (all row bookkeeping wave-uniform).  COLS_ = 32 (r3, P = 32 only): the tile is 32
+// columns wide and a wave works on TWO rows, lanes 0-31 / 32-63 -- half the LDS per point, which lets a 1024-point
+// transform run in a single pass (1024 x 32 x 4 B = 128 KiB with the re/im-split exchange) instead of a four-step
+// through HBM; the row bookkeeping is per half-wave (two v_readlane + a select instead of one v_readlane).
+template <int LOGN_, int LOGP_, bool SPLIT_, int COLS_ = 64>
 struct CGeo {
     static constexpr int LOGN = LOGN_, LOGP = LOGP_;
     static constexpr bool SPLIT = SPLIT_;
-    static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P;  // T waves per workgroup
-    static constexpr bool WAVE_ROWS = false;  // a column's points are spread over the T waves
-    static constexpr int NT = 64 * T;
-    static constexpr int RB = 64;  // columns per tile == lanes
+    static constexpr int N = 1 << LOGN, P = 1 << LOGP, T = N / P;  // T thread-rows per workgroup
+    static constexpr bool WAVE_ROWS = false;  // a column's points are spread over the T thread-rows
+    static constexpr int COLS = COLS_;
+    static constexpr bool HALF = COLS_ == 32;
+    static_assert(COLS_ == 64 || (COLS_ == 32 && P == 32 && T % 2 == 0), "32-column tiles: one row slot per lane of a half-wave");
+    static constexpr int NT = COLS * T;
+    static constexpr int RB = COLS;  // columns per tile
     static constexpr int ELEM = SPLIT ? 4 : 8;
     static constexpr int PITCH = 0;  // unused (interleaved-rows layout)
     static constexpr int LOGPAD = 4;  // unused
     static constexpr size_t LDS_BYTES = T > 1 ? (size_t)N * RB * ELEM : 0;
     // minimum waves per SIMD the register allocator must leave room for
-    static constexpr int MINW = T >= 4 ? 4 : 1;
+    static constexpr int MINW = NT >= 256 ? 4 : 1;
 };
+
+// value of `val` held by the lane that describes row slot v of THIS lane's half-wave (HALF) / of the wave
+template <bool HALF>
+__device__ __forceinline__ int slot_bcast(int val, int v, int hw) {
+    if constexpr (HALF) {
+        const int a = __builtin_amdgcn_readlane(val, v), b = __builtin_amdgcn_readlane(val, 32 + v);
+        return hw ? b : a;
+    } else {
+        return __builtin_amdgcn_readlane(val, v);
+    }
+}
+template <bool HALF>
+__device__ __forceinline__ float slot_bcast_f(float val, int v, int hw) {
+    return __builtin_bit_cast(float, slot_bcast<HALF>(__builtin_bit_cast(int, val), v, hw));
+}
 
 // MODE: 0 = pass A (mapped load, four-step twiddle, raw store to scratch)
 //       1 = pass B (raw load from scratch, mapped store)
@@ -154,15 +176,20 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = G::P, T = G::T;
     static_assert(P <= 64, "one lane per row slot");
+    constexpr bool HALF = G::HALF;
+    static_assert(!(HALF && GS), "gather-sum load: 64-column tiles only");
     constexpr bool RAW_LD = MODE == 1, RAW_ST = MODE == 0;
     constexpr bool NT_LD = RAW_LD ? SNT : (SWF_NT != 0), NT_ST = RAW_ST ? SNT : (SWF_NT != 0);
     // last Stockham phase: radix 2^LR at stride 2^LNS  (phases are LOGP, LOGP, ..., remainder)
     constexpr int LR = G::LOGN <= G::LOGP ? G::LOGN : (G::LOGN % G::LOGP == 0 ? G::LOGP : G::LOGN % G::LOGP);
     constexpr int LNS = G::LOGN - LR;
     const int lane = threadIdx.x & 63;
-    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hw = HALF ? lane >> 5 : 0;              // which half-wave (32-column tiles: two rows per wave)
+    const int t = HALF ? 2 * wave + hw : wave;        // thread-row id: owns rows t + v*T
+    const int clane = HALF ? (lane & 31) : lane;      // column within the tile
     const int o = blockIdx.y;
-    const int col = blockIdx.x * 64 + lane;
+    const int col = blockIdx.x * G::COLS + clane;
     const bool live = col < A.ncols;
     const int FN = 1 << A.full_logn;
     const int z = blockIdx.z;
@@ -274,7 +301,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     cx<float> x[P];
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
-        const int row = __builtin_amdgcn_readlane(in_row, v);
+        const int row = slot_bcast<HALF>(in_row, v, hw);
         cx<float> val = {0.f, 0.f};
         if constexpr (GS) {
             const int lo1 = __builtin_amdgcn_readlane((int)gs_off1, v), hi1 = __builtin_amdgcn_readlane((int)(gs_off1 >> 32), v);
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
                 }
             }
         } else {
-            if (row >= 0) {  // uniform
+            if (row >= 0) {  // uniform (per half-wave with 32-column tiles)
                 if (live) val = cp_load<NT_LD>(in + (unsigned)row * A.in_pitch);
             }
         }
@@ -301,7 +328,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         if constexpr (!RAW_LD) {
-            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in_w), v));
+            const float w = slot_bcast_f<HALF>(in_w, v, hw);
             x[v].x *= w;
             x[v].y *= w * sg_ld;
         } else {
@@ -309,19 +336,19 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
         }
     });
 
-    fft_phases<G, float, 0>(x, t, lane, true, smem, tw, [&](int, cx<float> v, auto sI) {
+    fft_phases<G, float, 0>(x, t, clane, true, smem, tw, [&](int, cx<float> v, auto sI) {
         constexpr int s = decltype(sI)::value;
-        const int row = __builtin_amdgcn_readlane(out_row, s);
-        if (row < 0) return;  // uniform
+        const int row = slot_bcast<HALF>(out_row, s, hw);
+        if (row < 0) return;  // uniform (per half-wave with 32-column tiles)
         if constexpr (RAW_ST) {
             cx<float> w;
-            w.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_tw.x), s));
-            w.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_tw.y), s));
+            w.x = slot_bcast_f<HALF>(out_tw.x, s, hw);
+            w.y = slot_bcast_f<HALF>(out_tw.y, s, hw);
             v = cmul(v, w);
             v.y *= sg_st;
             if (live) cp_store<NT_ST>(out + (unsigned)row * A.out_pitch, v);
         } else {
-            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, out_w), s)) * col_w;
+            const float w = slot_bcast_f<HALF>(out_w, s, hw) * col_w;
             v.x *= w;
             v.y *= w * sg_st;
             cx<float>* p = out + (unsigned)row * A.out_pitch;
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
 }
 
 constexpr int kColPassMinLog = 2;
-constexpr int kColPassMaxLog = 9;
+constexpr int kColPassMaxLog = 10;  // 1024 points: 32-column tiles
 
 int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s);
 int init_col_pass();

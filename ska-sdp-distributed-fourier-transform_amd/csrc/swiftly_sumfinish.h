@@ -19,6 +19,10 @@ namespace swf {
 #ifndef SWF_SF_NT
 #define SWF_SF_NT 256
 #endif
+// facets whose rows are in flight together in sum_finish_facets_kernel (registers: SF_NB * m / 64 complex values)
+#ifndef SWF_SF_NB
+#define SWF_SF_NB 3
+#endif
 constexpr int kSumFinishMaxGroups = 8;
 constexpr int kSumFinishMaxBatch = 64;
 
@@ -170,39 +174,62 @@ __global__ __launch_bounds__(SWF_SF_NT) void sum_finish_facets_kernel(const SumF
     });
     row_sync<GX>(false);
 
-    for (int f = 0; f < A.nfacets; f++) {
-        const int base = A.base0[f];
-        // workgroup-uniform skip: does any of this workgroup's rows lie in facet f's band?
-        bool any = false;
-        for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
-        if (!any) continue;  // uniform
-        const int k = (row - base) & (X - 1);
-        const bool on = live && k < M;
-        const cx<float>* __restrict__ in = A.in + (long long)f * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
-        const float wgt = on ? 1.f : 0.f;
-        cx<float> x[PM];
-        static_for<0, PM>([&](auto vI) {
-            constexpr int v = decltype(vI)::value;
-            x[v] = in[(t + v * TR) ^ (M >> 1)];  // plain index -> centred element
+    // The facets whose band covers this workgroup's rows are taken SF_NB at a time: the rows of all of them are
+    // requested before the first one is transformed, so a wave pays the HBM latency once per group instead of once
+    // per facet (r2: one facet at a time -- 4.5 dependent round trips per row on the 3x3 cover, SQ_WAIT_ANY 58 % of
+    // the wave cycles at 12 waves per CU).
+    constexpr int NB = SWF_SF_NB;
+    int f = 0;
+    while (f < A.nfacets) {
+        int fs[NB];
+        int cnt = 0;
+        for (; f < A.nfacets && cnt < NB; f++) {  // workgroup-uniform scan
+            const int base = A.base0[f];
+            bool any = false;
+            for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
+            if (any) fs[cnt++] = f;
+        }
+        if (cnt == 0) break;
+        cx<float> x[NB][PM];
+        float wgt[NB];
+        static_for<0, NB>([&](auto sI) {
+            constexpr int sl = decltype(sI)::value;
+            if (sl < cnt) {  // uniform
+                const int ff = fs[sl];
+                const int k = (row - A.base0[ff]) & (X - 1);
+                const bool on = live && k < M;
+                const cx<float>* __restrict__ in =
+                    A.in + (long long)ff * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
+                wgt[sl] = on ? 1.f : 0.f;
+                static_for<0, PM>([&](auto vI) {
+                    constexpr int v = decltype(vI)::value;
+                    x[sl][v] = in[(t + v * TR) ^ (M >> 1)];  // plain index -> centred element
+                });
+            }
         });
-        static_for<0, PM>([&](auto vI) {
-            constexpr int v = decltype(vI)::value;
-            x[v].x *= wgt;
-            x[v].y *= wgt;
+        static_for<0, NB>([&](auto sI) {
+            constexpr int sl = decltype(sI)::value;
+            if (sl < cnt) {  // uniform
+                static_for<0, PM>([&](auto vI) {
+                    constexpr int v = decltype(vI)::value;
+                    x[sl][v].x *= wgt[sl];
+                    x[sl][v].y *= wgt[sl];
+                });
+                const int sp = A.sp1[fs[sl]];
+                fft_phases<GM, float, 0>(x[sl], t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+                    const int ck = e ^ (M >> 1);
+                    const int kk = (ck - sp) & (M - 1);
+                    const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);  // centred position in the padded subgrid
+                    const float w = A.fn[kk];
+                    cx<float>* p = acc + lds_pos<GX>(rb, dest ^ (X >> 1), false);  // stored at its plain iFFT index
+                    cx<float> o = *p;
+                    o.x += v.x * w;
+                    o.y += v.y * w;
+                    *p = o;
+                });
+                row_sync<GX>(false);  // also protects ex_m reuse by the next facet
+            }
         });
-        const int sp = A.sp1[f];
-        fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
-            const int ck = e ^ (M >> 1);
-            const int kk = (ck - sp) & (M - 1);
-            const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);  // centred position in the padded subgrid
-            const float w = A.fn[kk];
-            cx<float>* p = acc + lds_pos<GX>(rb, dest ^ (X >> 1), false);  // stored at its plain iFFT index
-            cx<float> o = *p;
-            o.x += v.x * w;
-            o.y += v.y * w;
-            *p = o;
-        });
-        row_sync<GX>(false);  // also protects ex_m reuse by the next facet
     }
 
     cx<float> y[PX];

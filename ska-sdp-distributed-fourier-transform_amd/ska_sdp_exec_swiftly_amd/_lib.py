@@ -124,6 +124,12 @@ def _declare(lib):
         fn.argtypes = [vp, vp, c_size_t, vp]
     lib.swiftly_hip_stream_synchronize.restype = c_int
     lib.swiftly_hip_stream_synchronize.argtypes = [vp]
+    lib.swiftly_hip_stream_create_cu_mask.restype = c_int
+    lib.swiftly_hip_stream_create_cu_mask.argtypes = [POINTER(vp), POINTER(ctypes.c_uint32), c_int]
+    lib.swiftly_hip_stream_destroy.restype = c_int
+    lib.swiftly_hip_stream_destroy.argtypes = [vp]
+    lib.swiftly_hip_cu_census.restype = c_int
+    lib.swiftly_hip_cu_census.argtypes = [vp, c_int, vp]
 
 
 def load():

@@ -1136,6 +1136,8 @@ class SwiftlyBackward:
 
     def _add_band_group(self, sgs, subgrids):
         key = (int(sgs[0].off1), int(sgs[0].size))
+        if self._plan is not None and not any(int(c.off1) == key[0] for c in self._plan):
+            raise ValueError(f"subgrid off1={key[0]} is not in the subgrid_configs this SwiftlyBackward was planned for")
         staged = self.lru.get(key)
         planned = self._planned_count(*key)
         if staged is None and (len(sgs) == planned or (planned is None and len(sgs) > 1)):
