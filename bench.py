@@ -10,7 +10,10 @@ subgrid wave the per-wave facet transform (K2), the window extraction (K3), the
 per-subgrid accumulation (K4) and finish (K5).  Nothing is cached across
 steps.  Prints ONE JSON line (rank 0).
 
-Workloads (BASELINE.json configs):
+Workloads (BASELINE.json configs; `--workload`): the default is the one the metric is
+quoted on; "32k-8x8" (configs[2]), "128k" / "128k-8x8" (configs[4], forward + backward round trip; one rank holds
+a stated SUBSET of the facets -- `config.facets` of `config.facets_total` -- because 288 GB do not hold all of
+them), "64k-sparse-4x4" (the headline problem with a cover that divides by 8):
   64k-sparse  (default) catalogue "64k[1]-n32k-1k": N=65536, 3x3 facets of
               22528^2, sparse subgrid set (505 of 71^2 = 10.02 %, 25 columns),
               complex64 -- the configuration BASELINE.json's metric is quoted on
@@ -59,6 +62,34 @@ WORKLOADS = {
         params=dict(W=11.0, fov=1.0, N=8192, yB_size=1408, yN_size=2048, xA_size=1024, xM_size=2048),
         sparse_radius=None,
         name="N=8192 custom (W=11, yB=1408, yN=2048, xA=1024, xM=2048), 6x6 facets -> 8x8 subgrids",
+    ),
+    # BASELINE.json configs[2] (SURVEY section 8d cfg 3, literal): 64 facets -> one rank's share divides by 8
+    "32k-8x8": dict(
+        params=dict(W=11.0, fov=1.0, N=32768, yB_size=4096, yN_size=8192, xA_size=2048, xM_size=4096),
+        sparse_radius=None,
+        name="N=32768 custom (W=11, yB=4096, yN=8192, xA=2048, xM=4096 -> m=1024), 8x8 facets -> 16x16 subgrids",
+        roundtrip=True,
+    ),
+    # the headline problem with a facet cover that divides by 8 (same kernels: yN = 32768, xM = 1024, m = 512)
+    "64k-sparse-4x4": dict(
+        params=dict(W=10.875, fov=1.0, N=65536, yB_size=16384, yN_size=32768, xA_size=928, xM_size=1024),
+        sparse_radius=12.65,
+        name="N=65536 custom cover (yB=16384, yN=32768): 4x4 facets, sparse subgrid set 505/5041 (25 columns)",
+    ),
+    # BASELINE.json configs[4]: catalogue 128k[1]-n64k-1k (reference swift_configs.py:998), forward + backward round trip.
+    # 9 facets of 45056^2 (16.2 GB) + 23.6 GB band buffer each do not fit one 288 GB GPU: a rank holds at most 2
+    "128k": dict(
+        params=dict(W=10.875, fov=1.0, N=131072, yB_size=45056, yN_size=65536, xA_size=928, xM_size=1024),
+        sparse_radius=None,
+        name="128k[1]-n64k-1k, 3x3 facets of 45056^2, full subgrid cover 142^2",
+        max_facets_per_rank=2, roundtrip=True, parity_radius=9.0,
+    ),
+    # SURVEY section 8d cfg 5 "preferred custom": 8x8 facets of 16384^2 (8 per rank on 8 GPUs), full subgrid cover
+    "128k-8x8": dict(
+        params=dict(W=10.875, fov=1.0, N=131072, yB_size=16384, yN_size=32768, xA_size=928, xM_size=1024),
+        sparse_radius=None,
+        name="N=131072 custom (yB=16384, yN=32768, xA=928, xM=1024 -> m=256), 8x8 facets -> 142^2 subgrids",
+        max_facets_per_rank=8, roundtrip=True, parity_radius=9.0,
     ),
     "1k": dict(
         params=dict(W=13.5625, fov=1.0, N=1024, yB_size=416, yN_size=512, xA_size=228, xM_size=256),
@@ -147,6 +178,11 @@ def verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got_by_index, pixels=None, 
         rel_rmse_each=[float(f"{r:.3e}") for r in rels],
         max_abs_over_rms=max(maxs),
         tol_rel_rmse=tol,
+        # BASELINE.md section 3 budgeted 1e-6 assuming float32 STORAGE rounding of un-amplified data; the facet-side
+        # intermediates carry data amplified by 1/pswf (<= 90 for W = 10.875) whose storage rounding alone, with all
+        # arithmetic in double, gives the figure below at this shape -- float32 arithmetic costs 1.26x on top
+        storage_floor_rel_rmse=1.016e-5,
+        storage_floor_source="profiles/r2a_accuracy_probe.txt (tools/accuracy_probe.py), DESIGN.md section 2",
         ok=bool(max(rels) < tol),
     )
 
@@ -215,13 +251,66 @@ class StageTimer:
 
 
 # --------------------------------------------------------------------------- CPU baseline
+REF_SRC = "/root/reference/src"  # only present in the authoring container, never on the GPU box
+
+
+def _import_reference():
+    """The reference's own numpy core + 2-D task bodies (``SwiftlyCore``, ``api_helper``), imported UNCHANGED from
+    ``/root/reference/src`` with stub modules for its absent dependencies (ska_sdp_func, dask, distributed: none of
+    them is on the numpy path) -- the recipe of SURVEY.md appendix D / tests/golden/make_golden.py.  None when the
+    reference is not there (GPU box): the caller falls back to the oracle port."""
+    import types
+
+    if not os.path.isdir(REF_SRC):
+        return None
+
+    def stub(name, **attrs):
+        mod = sys.modules.get(name)
+        if mod is None:
+            mod = types.ModuleType(name)
+            sys.modules[name] = mod
+        mod.__dict__.update(attrs)
+        return mod
+
+    try:
+        a, b = stub("ska_sdp_func"), stub("ska_sdp_func.fourier_transforms")
+        a.fourier_transforms, b.swiftly = b, stub("ska_sdp_func.fourier_transforms.swiftly")
+
+        class _NoClient:
+            @staticmethod
+            def current():
+                raise RuntimeError("dask is not installed")
+
+        d = stub("dask", delayed=lambda *x, **k: None)
+        d.array, d.distributed = stub("dask.array"), stub("dask.distributed", Client=_NoClient)
+        stub("distributed", Client=_NoClient)
+        if REF_SRC not in sys.path:
+            sys.path.insert(0, REF_SRC)
+        from ska_sdp_exec_swiftly import api_helper  # pylint: disable=import-outside-toplevel
+        from ska_sdp_exec_swiftly.fourier_transform.core import SwiftlyCore  # pylint: disable=import-outside-toplevel
+
+        return SwiftlyCore, api_helper
+    except Exception:  # pylint: disable=broad-except
+        return None
+
+
 def _cpu_sample(args):
-    """One worker's share of the CPU sample (runs in a separate process)."""
+    """One worker's share of the CPU sample (runs in a separate process): the three task kinds Dask would run --
+    prepare_facet of a facet slab (api.py:281-298), extract_column of some rows (api_helper.py:200-210),
+    extract + sum_and_finish_subgrid of one subgrid (api.py:255-279, api_helper.py:73-112)."""
     p, F, seed = args
     from oracle import swiftly_oracle as orc  # checker / baseline only
 
     yB, yN, xA, xM, N = p["yB_size"], p["yN_size"], p["xA_size"], p["xM_size"], p["N"]
-    core = orc.OracleCore(p["W"], N, xM, yN)
+    ref = _import_reference()
+    if ref is not None:
+        core = ref[0](p["W"], N, xM, yN)  # SwiftlyCore(W, N, xM_size, yN_size), reference core.py:39
+        finish = ref[1].sum_and_finish_subgrid
+        kind = "reference"
+    else:
+        core = orc.OracleCore(p["W"], N, xM, yN)
+        finish = orc.sum_and_finish_subgrid
+        kind = "port"
     m = core.xM_yN_size
     rng = numpy.random.default_rng(seed)
     ncol = max(1, min(yB, int(4.0e6 // yN)))  # K1 slab: column-independent
@@ -241,14 +330,15 @@ def _cpu_sample(args):
     sg = orc.CoverItem(0, 0, xA, numpy.ones(xA), numpy.ones(xA))
     t0 = time.perf_counter()
     contribs = [core.extract_from_facet(colfull, 0, axis=1) for _ in range(F)]
-    orc.sum_and_finish_subgrid(core, contribs, items, sg)
+    finish(core, contribs, items, sg)
     t_sg = time.perf_counter() - t0
-    return t_k1, t_k2, t_sg, ncol, nrow
+    return t_k1, t_k2, t_sg, ncol, nrow, kind
 
 
 def cpu_baseline(p, F, S, C):
-    """Oracle (numpy restatement of the reference, complex128 like the
-    reference's numpy path) timed on ALL host cores: what Dask would
+    """The reference's numpy path (``SwiftlyCore`` + ``api_helper`` imported unchanged from /root/reference/src
+    when that exists: ``kind = "reference"``; otherwise -- on the GPU box, where the reference is absent -- the
+    oracle port of the same algorithm: ``kind = "port"``; both compute in complex128) timed on ALL host cores: what Dask would
     parallelise -- independent facet column slabs, (facet, column) row slabs and
     subgrids -- runs as one process per core (numpy's pocketfft is single
     threaded), every process working on its own bounded sample concurrently (so
@@ -266,7 +356,11 @@ def cpu_baseline(p, F, S, C):
     t_k1 = float(numpy.mean([r[0] for r in res]))
     t_k2 = float(numpy.mean([r[1] for r in res]))
     t_sg = float(numpy.mean([r[2] for r in res]))
-    ncol, nrow = res[0][3], res[0][4]
+    ncol, nrow, kind = res[0][3], res[0][4], res[0][5]
+    what = (
+        "reference SwiftlyCore + api_helper (numpy backend, imported unchanged from /root/reference/src)"
+        if kind == "reference" else "oracle port of the reference's numpy path"
+    )
     # per-unit times measured with all cores busy; units are independent, so `cores` of them run at a time
     total = (F * t_k1 + F * C * t_k2 + S * t_sg) / cores
     m = p["xM_size"] * p["yN_size"] // p["N"]
@@ -274,9 +368,9 @@ def cpu_baseline(p, F, S, C):
         value=F * S / total,
         unit="contributions/s",
         cores=cores,
-        kind="port",
+        kind=kind,
         sample=(
-            f"oracle (numpy, complex128), {cores} processes concurrently, each: K1 on a {p['yB_size']}x{ncol} "
+            f"{what}, complex128, {cores} processes concurrently, each: K1 on a {p['yB_size']}x{ncol} "
             f"column slab of one facet, K2 on {nrow} of {m} rows of one (facet, column), K3-K5 for one subgrid "
             f"with {F} contributions; per-unit times averaged over processes and extrapolated linearly to {F} facets "
             f"x {C} columns x {S} subgrids spread over {cores} cores "
@@ -288,20 +382,69 @@ def cpu_baseline(p, F, S, C):
 
 
 # --------------------------------------------------------------------------- measured traffic (PMC passes)
-def measured_traffic(workload):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc summary of THIS round's build
-    (profiles/r2_pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes),
-    or None when no such measurement is recorded for the workload."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_kernels.json")
+
+
+def _pmc_record(workload):
+    """Per-kernel counter summary of THIS round's build for the workload (profiles/r3_pmc_kernels.json, written by
+    tools/pmc_kernels.py from a rocprofv3 kernel trace and separate --pmc FETCH_SIZE / WRITE_SIZE passes), or None."""
     try:
-        with open(path, encoding="utf-8") as fh:
-            rec = json.load(fh)
+        with open(PMC_FILE, encoding="utf-8") as fh:
+            return json.load(fh).get(workload)
     except (OSError, ValueError):
+        return None
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch of the roofline kernel (K1) from the committed PMC summary, or (None, None)."""
+    rec = _pmc_record(workload)
+    if not rec or "K1" not in rec.get("kernels", {}):
         return None, None
-    entry = rec.get(workload)
-    if not entry:
-        return None, None
-    return entry.get("bytes_per_launch"), entry.get("note")
+    return rec["kernels"]["K1"]["counter_bytes_per_launch"], rec.get("note")
+
+
+def kernel_table(workload, F, C, parts):
+    """Per-kernel table of the forward pass: algorithmic bytes beside the counter bytes and the
+    launch durations of the committed rocprofv3 summary of this build; both fractions are of the 8 TB/s HBM3E peak.
+    `frac_algorithmic` is the effective figure (compulsory bytes / time), `frac_sustained` what the kernel really
+    moves per second (FETCH_SIZE x 2 + WRITE_SIZE) -- a kernel that prunes its output has sustained < algorithmic,
+    one that re-reads or writes scratch has sustained > algorithmic."""
+    rec = _pmc_record(workload)
+    if not rec:
+        return None
+    k = rec["kernels"]
+    rows = []
+    spec = [
+        ("K1", ["K1"], F, parts["K1"], "prepare_facet along the contiguous axis, band-pruned store"),
+        ("K2", ["K2a", "K2b"], C, parts["K2"], "window gather + strided-axis prepare_facet per wave (four-step: pass A + pass B)"),
+        ("K3", ["K3"], C, parts["K3"], "transform_contributions (extract + add_to_subgrid axis 0)"),
+        ("K4b+K5a", ["K4b5a"], C, parts["K4"], "sum_finish_facets (facet sum + add_to_subgrid / finish_subgrid axis 1)"),
+        ("K5b", ["K5b"], C, parts["K5"], "finish_subgrid axis 0"),
+    ]
+    for stage, ids, per_pass, alg, what in spec:
+        if not all(i in k for i in ids):
+            continue
+        us = sum(k[i]["avg_us"] for i in ids) * per_pass
+        cnt = sum(k[i]["counter_bytes_per_launch"] for i in ids) * per_pass
+        rows.append(dict(
+            stage=stage, what=what, launches_per_pass=per_pass * len(ids),
+            avg_us=[k[i]["avg_us"] for i in ids],
+            us_per_pass=round(us, 1),
+            algorithmic_bytes_per_pass=int(alg),
+            counter_bytes_per_pass=int(cnt),
+            frac_algorithmic=round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            frac_sustained=round(cnt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        ))
+    if not rows:
+        return None
+    tot_us = sum(r["us_per_pass"] for r in rows)
+    return dict(
+        source="profiles/r3_pmc_kernels.json: " + rec.get("note", ""),
+        rows=rows,
+        sum_us_per_pass=round(tot_us, 1),
+        counter_bytes_per_pass=int(sum(r["counter_bytes_per_pass"] for r in rows)),
+        frac_sustained_whole_pass=round(sum(r["counter_bytes_per_pass"] for r in rows) / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+    )
 
 
 def _free_port():
@@ -315,7 +458,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="64k-sparse", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="64k-sparse", choices=sorted(WORKLOADS))  # default: BASELINE.json's metric config
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle parity check of the timed objects")
     ap.add_argument("--verify", action="store_true", help="(default) kept for explicitness")
@@ -361,11 +504,17 @@ def main():
     wl = WORKLOADS[args.workload]
     p = wl["params"]
     cfg = sw.SwiftlyConfig(backend="hip", **p)
-    facet_cfgs = sw.make_full_facet_cover(cfg)
-    sg_cfgs = select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
+    all_facet_cfgs = sw.make_full_facet_cover(cfg)
+    # a rank holds at most `max_facets_per_rank` facets (HBM capacity): with too few ranks only the first cap * world
+    # facets of the cover take part -- a stated subset; contributions are counted for those only
+    cap = wl.get("max_facets_per_rank")
+    n_active = len(all_facet_cfgs) if cap is None else min(len(all_facet_cfgs), cap * world)
+    facet_cfgs = all_facet_cfgs[:n_active]
+    all_sg_cfgs = sw.make_full_subgrid_cover(cfg)
+    sg_cfgs = select_subgrids(all_sg_cfgs, p["N"], p["xA_size"], wl["sparse_radius"])
     force_dist = os.environ.get("SWIFTLY_BENCH_FORCE_DIST") == "1"  # exercise the multi-GPU code path on 1 GPU
     single = world == 1 and not force_dist
-    wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64)
+    wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64, n_facets=len(facet_cfgs))
     if args.wave_axis is not None:
         wave_axis = args.wave_axis
     key = (lambda c: c.off1) if wave_axis == 1 else (lambda c: c.off0)
@@ -510,6 +659,10 @@ def main():
             unit="GB/s",
             frac=round(achieved / HBM_PEAK_GBS, 4),
             traffic=traffic,
+            # what the kernel really sustains: counter bytes per launch / the same live launch duration (the band
+            # store keeps 35 % of the outputs, so this is below `achieved`)
+            sustained=round(traffic / (k1["avg_ms"] * 1e-3) / 1e9, 1) if traffic else None,
+            sustained_frac=round(traffic / (k1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             traffic_note=traffic_note
             or "null: no rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE summary of this build is committed for this workload",
             algorithmic_bytes_per_launch=k1_bytes,
@@ -549,29 +702,47 @@ def main():
         )
         del buf
 
-    # subgrid -> facet direction on the subgrids this workload produced: reported beside
-    # the headline metric, never part of `value`
+    # subgrid -> facet direction: reported beside the headline metric, never part of `value`
     backward = None
-    if single and not args.no_backward:
+    roundtrip = None
+    # band schedule (waves by off1) wherever its kernels exist, else the reference schedule (waves by off0)
+    baxis = 1 if cfg.core.supports_backward_band(torch.complex64) else 0
+    bkey = (lambda c: c.off1) if baxis == 1 else (lambda c: c.off0)
+    produced_bytes = S * p["xA_size"] ** 2 * 8
+    streaming = bool(wl.get("roundtrip")) or produced_bytes > 24e9
+
+    def backward_parity(plan):
+        """element-wise parity of the band schedule on SEPARABLE subgrids (rank-1 outer products on the 1/8 grid times
+        the subgrid masks: exact in float32) of the plan ``plan``: sampled rows of every facet against the oracle"""
+        vec = [sep.subgrid_vectors(4321 + i, c.size, rank=1) for i, c in enumerate(plan)]
+        bw = {}
+        for i, c in enumerate(plan):
+            bw.setdefault(bkey(c), []).append(i)
+        bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=plan, wave_axis=baxis)
+        for idx in bw.values():  # one wave of subgrids alive at a time
+            bwd.add_new_subgrid_tasks([plan[i] for i in idx], [separable_facet(torch, vec[i], plan[i]) for i in idx])
+        out = bwd.finish()
+        torch.cuda.synchronize()
+        par = verify_facets(p, facet_cfgs, plan, vec, out, rows_per_facet=16, tol=wl.get("parity_tol"))
+        del out
+        return par
+
+    if single and not args.no_backward and not streaming:
         fwd = factory()
         fwd.prepare_all_facets()
         produced = [fwd.get_wave(wave).clone() for wave in waves]
         del fwd
         torch.cuda.synchronize()
-        # band schedule (waves by off1) wherever its kernels exist, else the reference schedule (waves by off0)
-        baxis = 1 if cfg.core.supports_backward_band(torch.complex64) else 0
-        bkey = (lambda c: c.off1) if baxis == 1 else (lambda c: c.off0)
         lookup = {(c.off0, c.off1): data[k] for wave, data in zip(waves, produced) for k, c in enumerate(wave)}
         bwaves = {}
         for c in sg_cfgs:
             bwaves.setdefault(bkey(c), []).append(c)
         bwaves = list(bwaves.values())
 
-        def backward_pass(data=None):
-            data = lookup if data is None else data
+        def backward_pass():
             bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=sg_cfgs, wave_axis=baxis)
             for wave in bwaves:
-                bwd.add_new_subgrid_tasks(wave, [data[(c.off0, c.off1)] for c in wave])
+                bwd.add_new_subgrid_tasks(wave, [lookup[(c.off0, c.off1)] for c in wave])
             return bwd.finish()
 
         try:
@@ -593,22 +764,82 @@ def main():
                 schedule="band accumulators, waves by off1" if baxis == 1 else "reference schedule, waves by off0",
                 subgrids=S, facets=F, finite=finite,
             )
-            del out
+            del out, produced, lookup
+            produced = lookup = None
             if picks:
-                # element-wise parity of the SAME schedule on separable subgrids (rank-1 outer products on the 1/8
-                # grid times the subgrid masks: exact in float32), sampled rows of every facet against the oracle
-                del produced, lookup
-                produced = lookup = None
-                sg_vec = [sep.subgrid_vectors(4321 + i, c.size, rank=1) for i, c in enumerate(sg_cfgs)]
-                sdata = {(c.off0, c.off1): separable_facet(torch, sg_vec[i], c) for i, c in enumerate(sg_cfgs)}
-                out = backward_pass(sdata)
-                torch.cuda.synchronize()
-                backward["parity"] = verify_facets(p, facet_cfgs, sg_cfgs, sg_vec, out, rows_per_facet=16,
-                                                   tol=wl.get("parity_tol"))
-                del out, sdata
+                backward["parity"] = backward_parity(sg_cfgs)
         except (ValueError, NotImplementedError) as err:  # sizes without the band kernels
             backward = dict(skipped=str(err))
         del produced, lookup
+
+    if not args.no_backward and streaming:
+        # forward + backward ROUND TRIP, streaming (facet -> subgrid wave -> folded straight back into the facet sums,
+        # the flow of the reference's scripts/demo_api.py): the finished subgrids of a big cover (20164 x 6.9 MB for
+        # N = 131072) are never all alive
+        if wave_axis != baxis:
+            roundtrip = dict(skipped="forward and backward pipelines use different wave keys for this configuration")
+        else:
+            from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward
+
+            def roundtrip_pass():
+                if single:
+                    fwd = factory()
+                    fwd.prepare_all_facets()
+                    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=sg_cfgs, wave_axis=baxis)
+                    for wave in waves:
+                        res = fwd.get_wave(wave)
+                        bwd.add_new_subgrid_tasks(wave, [res[k] for k in range(len(wave))])
+                    del fwd
+                    return bwd.finish()
+                dfw = DistributedForward(cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs,
+                                         wave_axis=wave_axis, dtype=torch.complex64)
+                dbw = DistributedBackward(cfg, facet_cfgs, wave_axis=baxis, subgrid_configs=sg_cfgs, dtype=torch.complex64)
+                dfw.prepare_all_facets()
+                pend_f = pend_b = None
+                for wave in waves + [None]:
+                    hf = (wave, dfw.start_wave(wave)) if wave is not None else None
+                    if pend_f is not None:
+                        mine, res = dfw.finish_wave(pend_f[1])
+                        hb = dbw.start_wave(pend_f[0], [res[k] for k in range(len(mine))] if res is not None else [])
+                        if pend_b is not None:
+                            dbw.finish_wave(pend_b)
+                        pend_b = hb
+                    pend_f = hf
+                dbw.finish_wave(pend_b)
+                del dfw
+                return dbw.finish()[1]
+
+            out = roundtrip_pass()
+            fence()
+            del out
+            each = []
+            for _ in range(2):
+                fence()
+                tb = time.perf_counter()
+                out = roundtrip_pass()
+                fence()
+                each.append(1e3 * (time.perf_counter() - tb))
+                finite = all(bool(torch.isfinite(torch.view_as_real(o)).all()) for o in out)
+                del out
+            rt = sum(each) / len(each)
+            if world > 1:
+                t = torch.tensor([rt], device="cuda", dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                rt = float(t.item())
+            roundtrip = dict(
+                ms_per_pass=round(rt, 3), passes=len(each), each_ms=[round(t, 2) for t in each],
+                forward_ms=round(ms_per_step, 3), backward_ms_by_difference=round(rt - ms_per_step, 3),
+                contributions_per_s_both_directions=round(2 * F * S / (rt * 1e-3), 1),
+                schedule="streaming: every forward wave is folded straight into the backward band accumulators",
+                subgrids=S, facets=F, finite=finite,
+            )
+            if single and picks:
+                plan = select_subgrids(all_sg_cfgs, p["N"], p["xA_size"], wl.get("parity_radius", wl["sparse_radius"]))
+                roundtrip["backward_parity"] = backward_parity(plan)
+                roundtrip["backward_parity"]["note"] = (
+                    f"band schedule on a plan of {len(plan)} of the {len(all_sg_cfgs)} subgrids (the oracle costs "
+                    "one length-yN transform per subgrid and facet offset)"
+                )
 
     line = dict(
         metric="facet_to_subgrid_contributions_per_s",
@@ -625,7 +856,8 @@ def main():
         dtype="complex64 (f32 arithmetic)",
         data="synthetic",
         config=dict(
-            workload=wl["name"], facets=F, subgrids=S, subgrid_columns=C, contributions=F * S, params=p,
+            workload=wl["name"], facets=F, facets_total=len(all_facet_cfgs), subgrids=S, subgrid_columns=C,
+            contributions=F * S, params=p,
             wave_axis=wave_axis,
             facet_data="separable rank-2 dense random (1/8 grid), seed 1234+j, times cover masks",
             parallelism=f"facets sharded over {world} rank(s), contribution all-to-all" if world > 1 else "1 GPU",
@@ -635,9 +867,13 @@ def main():
         algorithmic_bytes=dict(total=total_bytes, **parts),
         stages=stages,
         roofline=roofline,
+        kernels=kernel_table(args.workload, F, C, parts) if world == 1 else None,
         parity=parity,
         backward=backward,
+        roundtrip=roundtrip,
     )
+    if len(facet_cfgs) < len(all_facet_cfgs):
+        line["scaling"] = "weak (a rank holds at most %d facets: the facet subset grows with the ranks)" % cap
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p, F, S, C)
@@ -648,7 +884,7 @@ def main():
         torch.distributed.destroy_process_group()
     if parity is not None and not parity["ok"]:
         raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {parity['tol_rel_rmse']}")
-    bpar = (backward or {}).get("parity")
+    bpar = (backward or {}).get("parity") or (roundtrip or {}).get("backward_parity")
     if bpar is not None and not bpar["ok"]:
         raise SystemExit(f"bench.py: BACKWARD PARITY FAILURE rel_rmse={bpar['rel_rmse']:.3e} >= {bpar['tol_rel_rmse']}")
 

@@ -28,10 +28,12 @@
  *    be negative or >= N.
  *  - return value 0 = success; non-zero = failure, message available from
  *    swiftly_hip_last_error() (thread local).  Nothing throws across the ABI.
- *    SWIFTLY_ERR_UNSUPPORTED is returned for transform lengths that are not
- *    a power of two in [8, 32768] (complex64) / [8, 8192] (complex128);
- *    65536 is supported in complex64 for prepare_* / finish_* along a
- *    unit-stride axis and along the strided axis of contiguous rows.
+ *  - transform lengths (yN, xM, m = xM*yN/N): powers of two from 4 to 32768 run on native kernels in both
+ *    precisions (complex128 up to 8192 along a unit-stride axis); 65536 is supported in complex64 for prepare_* /
+ *    finish_* along a unit-stride axis and along the strided axis of contiguous rows.  Any other length (the
+ *    3, 5, 7, 9 x 2^k sizes of the reference's parameter catalogue) goes through a Bluestein fallback on the
+ *    power-of-two kernels (correct, ~10x the traffic) as long as 2^ceil(log2(2n-1)) <= 65536 (complex64) /
+ *    8192 (complex128); beyond that the call returns SWIFTLY_ERR_UNSUPPORTED (handle creation still succeeds).
  *  - a handle is immutable after creation and may be used concurrently from
  *    several host threads / streams (the reference scatters one core object
  *    to all Dask worker threads, api.py:145-147).  Handles may be created
@@ -249,15 +251,21 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
  */
 
 /* Number of physical columns of a band buffer holding `band_len` logical columns (parity-split layout: the
- * logical column with cyclic distance d from band_start lives at (d & 1) * ((band_len + 1) / 2) + (d >> 1)). */
+ * logical column with cyclic distance d from band_start lives at (d & 1) * H + (d >> 1), H = swiftly_hip_band_columns / 2
+ * = (band_len + 1) / 2 rounded up to a multiple of 16 columns, so that both parity runs start on a 128-byte line). */
 int64_t swiftly_hip_band_columns(int64_t band_len);
+/* The same for the band layout a HANDLE uses: parity-split as above for yN = 16384, 32768, 65536 (where the
+ * two-workgroup long-row kernel produces the band); PLAIN for shorter padded facets (logical column d at physical
+ * column d, band_columns = band_len; K1 is then the generic contiguous-axis transform and the band must be the
+ * whole padded axis (0, yN)). */
+int64_t swiftly_hip_band_columns_for(const swiftly_hip_t* h, int64_t band_len);
 
 /* K1: Swiftly.prepare_facet(in[rows, facet_size], ., facet_off) (core.py:686; numpy form core.py:212-222) along
  * the contiguous axis for every row of a facet, keeping only the centred output indices in the cyclic range
  * [band_start, band_start + band_len) of [0, yN) (band_len = yN keeps everything), parity-split (see above);
  * out[rows, band_columns(band_len)], row stride out_row_stride.  fold_other_axis_window != 0 also multiplies row r
  * by 1/pswf of the OTHER axis (facet size `rows`) -- the window prepare_facet applies along that axis later;
- * windows commute with transforms along the orthogonal axis.  yN = 32768 only (SWIFTLY_ERR_UNSUPPORTED else). */
+ * windows commute with transforms along the orthogonal axis.  yN = 16384, 32768 or 65536 (SWIFTLY_ERR_UNSUPPORTED else). */
 int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                    int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                    int64_t band_start, int64_t band_len, int fold_other_axis_window, void* stream);

@@ -45,7 +45,7 @@ static int init_one_s() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
 }
 
-#define SF_PAIRS(X) X(7, 8) X(7, 10) X(8, 9) X(8, 10) X(9, 10) X(9, 11) X(10, 11)
+#define SF_PAIRS(X) X(7, 8) X(7, 10) X(8, 9) X(8, 10) X(9, 10) X(9, 11) X(10, 11) X(10, 12)
 
 int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s) {
 #define SF_CASE(M, XX) \

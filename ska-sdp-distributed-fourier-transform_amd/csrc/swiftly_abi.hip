@@ -686,7 +686,9 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     r.nrows = a.nrows;
     r.rm_mod = a.rm_mod; r.rm_inner = a.rm_inner; r.rm_outer = a.rm_outer; r.rm_full = a.rm_full;
     r.in_rowmap = a.in_rowmap;
-    if (a.st_rowmap || a.row_win) return false;
+    if (a.st_rowmap) return false;
+    r.row_win = a.row_win;
+    if (a.row_win && logn > kRowPassMaxLog) return false;  // the two-workgroup kernels take it through prepare_facet_band only
     r.ld_a = a.ld.a; r.ld_len = a.ld.len; r.ld_c = a.ld.c; r.ld_mod = a.ld.mod; r.ld_win = a.ld.win;
     r.st_a = a.st.a; r.st_len = a.st.len; r.st_c = a.st.c; r.st_mod = a.st.mod; r.st_win = a.st.win; r.st_win2 = a.st.win2;
     r.tw = twiddles<float>(h, logn);
@@ -1380,7 +1382,22 @@ int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const v
 // ---------------------------------------------------------------------------------------------------------
 // Contiguous-axis-first pipeline
 
-int64_t swiftly_hip_band_columns(int64_t band_len) { return 2 * ((band_len + 1) / 2); }
+// half of a parity-split band buffer, in columns: a multiple of 16 (128 bytes) so that BOTH parity runs of a 64-column
+// tile of the column pass start on a cache line (r2: (band_len + 1) / 2 = 5736 left every odd run 64 bytes off a line:
+// 5 lines fetched per 4 lines' worth, FETCH_SIZE of K2 pass A 1.04 GB per wave against 0.83 GB)
+static inline int64_t band_half_columns(int64_t band_len) { return (((band_len + 1) / 2) + 15) & ~int64_t(15); }
+int64_t swiftly_hip_band_columns(int64_t band_len) { return 2 * band_half_columns(band_len); }
+// Band layout of a handle: parity-split where the two-workgroup long-row kernel produces the band (yN >= 16384), else
+// PLAIN (half = 0: logical column d of the band at physical column d; K1 is the generic contiguous-axis transform and
+// keeps the whole padded axis).
+static inline bool band_is_split(const swiftly_hip* h) { return h->log_yN >= 14 && h->log_yN <= 16; }
+static inline int band_half_of(const swiftly_hip* h, int64_t band_len) {
+    return band_is_split(h) ? (int)band_half_columns(band_len) : 0;
+}
+int64_t swiftly_hip_band_columns_for(const swiftly_hip_t* h, int64_t band_len) {
+    if (!h) return -1;
+    return band_is_split(h) ? 2 * band_half_columns(band_len) : band_len;
+}
 
 int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                    int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
@@ -1390,14 +1407,21 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: complex64 only");
     CHECK_FACET_SIZE();
     const int yN = (int)h->yN;
-    if (h->log_yN < 14 || h->log_yN > 16)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: padded facet size %d not supported (16384, 32768, 65536)", yN);
+    if (h->log_yN < 3 || h->log_yN > 16)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: padded facet size %d not supported (power of two, 8 .. 65536)", yN);
     if (rows < 0 || rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "bad row count");
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN)
         return fail(SWIFTLY_ERR_PARAM, "band [%lld, +%lld) is not a cyclic range of [0, %d)", (long long)band_start, (long long)band_len, yN);
     if (fold_other_axis_window && (rows <= 0 || rows >= h->yN))
         return fail(SWIFTLY_ERR_PARAM, "other-axis facet size %lld must be in [1, yN_size - 1]", (long long)rows);
     if (rows == 0) return 0;
+    if (!band_is_split(h)) {
+        // short rows: the generic contiguous-axis prepare_facet, whole padded axis, plain column order
+        if (band_start != 0 || band_len != yN)
+            return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: yN_size %d keeps the whole padded axis (band must be (0, yN_size))", yN);
+        return do_prepare_facet<float>(h, in, rows, facet_size, in_row_stride, 1, out, out_row_stride, 1, facet_off, INT64_MIN,
+                                       nullptr, nullptr, fold_other_axis_window, 0, (hipStream_t)stream);
+    }
     const int lo = yN / 2 - (int)(facet_size / 2);
     RowPassArgs r;
     std::memset(&r, 0, sizeof r);
@@ -1410,7 +1434,7 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     r.scale = (float)(1.0 / yN);
     r.conj_ld = r.conj_st = 1;
     r.row_win = fold_other_axis_window ? h->invp_f + (yN / 2 - (int)(rows / 2)) : nullptr;
-    r.band_start = (int)band_start; r.band_len = (int)band_len; r.band_half = (int)((band_len + 1) / 2);
+    r.band_start = (int)band_start; r.band_len = (int)band_len; r.band_half = (int)band_half_columns(band_len);
     const cx<float>* twh = twiddles<float>(h, h->log_yN - 1);
     const cx<float>* twf = twiddles<float>(h, h->log_yN);
     if (!twh || !twf) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
@@ -1451,7 +1475,7 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
     c.scale = (float)(1.0 / yN);
     c.conj_ld = c.conj_st = 1;
     c.cg_mod = m; c.cg_full = yN;
-    c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = (int)((band_len + 1) / 2);
+    c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = band_half_of(h, band_len);
     // tuning knob: facets per launch group (both passes of a group run back to back)
     static const int per_env = getenv("SWIFTLY_K2_FACETS") ? atoi(getenv("SWIFTLY_K2_FACETS")) : kColZF;
     const int per_f = std::max(1, std::min(per_env, (int)kColZF));
@@ -1549,7 +1573,7 @@ static int transform_contributions_impl(swiftly_hip_t* h, int dtype, const void*
     if (!c.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table");
     if (layout == 0) {  // in[f] = [m, yN] column buffers: window gather along the contiguous axis
         c.cg_mod = m; c.cg_full = yN;
-        c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = (int)((band_len + 1) / 2);
+        c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = band_half_of(h, band_len);
     } else if (layout == 1) {  // in[f] = [kept rows of yN, m]: window gather along the strided axis
         c.ld_mod = yN;
         c.ld_rowmap = in_rowmap;

@@ -500,14 +500,11 @@ __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool
                                            const cx<R>* __restrict__ tw, F&& fin) {
     constexpr int REM = G::LOGN - LOGNS;
     constexpr int LOGR = REM < G::LOGP ? REM : G::LOGP;
-#ifndef SWF_EXP  // timing experiments only (wrong results): 1 = no LDS exchange, 2 = no butterflies
-#define SWF_EXP 0
-#endif
-    if constexpr (!(SWF_EXP & 2)) phase_compute<G, R, LOGNS, LOGR>(x, t, tw);
+    phase_compute<G, R, LOGNS, LOGR>(x, t, tw);
     if constexpr (LOGNS + LOGR == G::LOGN) {
         phase_scatter<G, R, LOGNS, LOGR>(x, t, fin);
     } else {
-        if constexpr (!(SWF_EXP & 1)) phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
+        phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
         fft_phases<G, R, LOGNS + LOGR>(x, t, rb, rowfast, lds, tw, fin);
     }
 }

@@ -182,11 +182,12 @@ __global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, co
     const float* __restrict__ sw1 = st_win ? st_win : &kRowOne;
     const float* __restrict__ sw2 = st_win2 ? st_win2 : &kRowOne;
     const int sw1s = st_win ? 1 : 0, sw2s = st_win2 ? 1 : 0;
+    const float rscale = A.row_win ? A.scale * A.row_win[row] : A.scale;  // window of the OTHER axis, folded per row
     fft_phases<G, float, 0>(x, t, 0, false, smem, tw, [&](int e, cx<float> v) {
         const int ck = e ^ (N >> 1);
         if constexpr (!MAP_ST) {
-            v.x *= A.scale;
-            v.y *= A.scale * sg_st;
+            v.x *= rscale;
+            v.y *= rscale * sg_st;
             cx<float>* p = out + ck;
             if (A.accumulate) {
                 const cx<float> old = *p;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_kernel(const RowPassArgs A, co
             const int ds = ok ? d : 0;
             unsigned idx = (unsigned)(ds + A.st_c);
             if (idx >= (unsigned)A.st_mod) idx -= (unsigned)A.st_mod;
-            const float w = A.scale * sw1[ds * sw1s] * sw2[ds * sw2s];
+            const float w = rscale * sw1[ds * sw1s] * sw2[ds * sw2s];
             v.x *= w;
             v.y *= w * sg_st;
             if (ok) {
@@ -421,13 +422,8 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         static_for<0, 2>([&](auto qI) {
             constexpr int q = decltype(qI)::value;
             const unsigned off8 = (base8 + (unsigned)((v * T + q * H) << 3)) & (unsigned)((N << 3) - 1);
-#ifndef SWF_EXP
-#define SWF_EXP 0
-#endif
-            f32x2 val = {1.f, 0.f};
-            if constexpr (!((SWF_EXP & 16) && q == 1))  // timing experiment: drop the second half's loads
-                val = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)off8, 0, 0));
-            if constexpr (HAS_WIN && !(SWF_EXP & 4)) {
+            const f32x2 val = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)off8, 0, 0));
+            if constexpr (HAS_WIN) {
                 const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, (int)(off8 >> 1), 0, 0));
                 a[q] = cx<float>{val.x * w, val.y * w};
             } else {
@@ -537,7 +533,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
 #else
         if constexpr (BAND) {
             const int d = (ck - A.band_start) & (N - 1);
-            if ((SWF_EXP & 8) ? (d < A.band_len && val.x == 12345.f) : (d < A.band_len))  // experiment 8: (almost) no stores
+            if (d < A.band_len)
                 *reinterpret_cast<f32x2*>(outb + region + ((unsigned)(d >> 1) << 3)) = val;
         } else {
             *reinterpret_cast<f32x2*>(outb + ((unsigned)ck << 3)) = val;

@@ -44,12 +44,16 @@ struct SumFinishArgs {
 
 template <int LOGM, int LOGX>
 struct SFGeo {
-    static constexpr int TR = 64;  // threads per row
+    // threads per row: one wave up to 2048-point rows (rows are wave-private: no workgroup barriers); two waves for
+    // 4096-point rows (64 points per lane would not fit the register file; the row then synchronises with
+    // workgroup barriers, which the workgroup-uniform facet loop allows)
+    static constexpr int LOGTR = LOGX >= 12 ? 7 : 6;
+    static constexpr int TR = 1 << LOGTR;
     static constexpr int NT = SWF_SF_NT;
-    using GM = Geo<float, LOGM, LOGM - 6, NT, false>;
-    using GX = Geo<float, LOGX, LOGX - 6, NT, false>;
-    static_assert(LOGM >= 7, "at least two points per lane");
-    static_assert(GM::T == TR && GX::T == TR, "one wave per row");
+    using GM = Geo<float, LOGM, LOGM - LOGTR, NT, false>;
+    using GX = Geo<float, LOGX, LOGX - LOGTR, NT, false>;
+    static_assert(LOGM - LOGTR >= 1, "at least two points per lane");
+    static_assert(GM::T == TR && GX::T == TR, "TR threads per row");
     static constexpr int RB = NT / TR;
     static constexpr size_t LDS_M = (size_t)RB * GM::PITCH * 8;
     static constexpr size_t LDS_X = (size_t)RB * GX::PITCH * 8;

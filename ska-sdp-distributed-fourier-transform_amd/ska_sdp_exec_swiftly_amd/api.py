@@ -32,7 +32,7 @@ import os
 
 import numpy
 
-from .core_hip import SwiftlyCoreHip
+from .core_hip import SwiftlyCoreHip, band_range
 
 __all__ = [
     "FacetConfig",
@@ -1317,7 +1317,11 @@ class SwiftlyBackward:
             if len(sizes) != 1:
                 raise ValueError("SwiftlyBackward(wave_axis=1) needs facets of one size")
             yB = sizes.pop()
-            self._band = core.band_for_offsets([sg.off1 for sg in self._plan]) if self._plan else (0, core.yN_size)
+            # (the backward accumulators are plain-order bands for every yN: band_range, not the forward layout rule)
+            self._band = (
+                band_range(core.N, core.yN_size, core.xM_yN_size, [sg.off1 for sg in self._plan])
+                if self._plan else (0, core.yN_size)
+            )
             self._planned = {sg.off1 for sg in self._plan} if self._plan else None
             F = len(self.facets_config_list)
             # uninitialised: first-write flags per band column replace the zero fill

@@ -483,12 +483,14 @@ class SwiftlyCoreHip:
             return False
         if n_facets is not None and n_facets > self.MAX_FUSED_FACETS:
             return False
-        pairs = {(7, 8), (7, 10), (8, 9), (8, 10), (9, 10), (9, 11), (10, 11)}  # sum_finish instances
-        return logs["m"] <= 9 and (logs["m"], logs["xM"]) in pairs
+        pairs = {(7, 8), (7, 10), (8, 9), (8, 10), (9, 10), (9, 11), (10, 11), (10, 12)}  # sum_finish instances
+        return logs["m"] <= 10 and (logs["m"], logs["xM"]) in pairs  # m: single-pass column transform
 
     def supports_band_pipeline(self, dtype=None, n_facets=None):
         """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
-        return self.supports_fused_subgrid(dtype, n_facets) and self._logs()["yN"] in (14, 15, 16) and self._logs()["m"] >= 6
+        # K1: the two-workgroup band kernel for yN = 16384 .. 65536 (band-pruned output), the generic contiguous-axis
+        # transform below that (whole padded axis kept)
+        return self.supports_fused_subgrid(dtype, n_facets) and 6 <= self._logs()["yN"] <= 16 and self._logs()["m"] >= 6
 
     def supports_backward_band(self, dtype=None):
         """True when accumulate_facet_columns / finish_facet_band (include/swiftly_hip.h) exist for these sizes."""
@@ -499,11 +501,14 @@ class SwiftlyCoreHip:
     def band_for_offsets(self, subgrid_offs):
         """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains
         the ``xM_yN_size`` window of every given subgrid offset (core.py:243-253); ``(0, yN_size)`` = all."""
+        logs = self._logs()
+        if logs is None or not 14 <= logs["yN"] <= 16:
+            return 0, self.yN_size  # short padded facets keep the whole axis (plain band layout, swiftly_hip.h)
         return band_range(self.N, self.yN_size, self.xM_yN_size, subgrid_offs)
 
     def band_columns(self, band):
         """physical columns of a band buffer"""
-        return int(self._lib.swiftly_hip_band_columns(int(band[1])))
+        return int(self._lib.swiftly_hip_band_columns_for(self._handle, int(band[1])))
 
     def prepare_facet_band(self, facet, facet_off, band, out=None, fold_other_axis_window=True):
         """K1 (contiguous axis first): ``prepare_facet(facet, facet_off, axis=1)`` for every row of a row-major

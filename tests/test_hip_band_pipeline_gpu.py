@@ -25,7 +25,7 @@ def relrms(a, b):
 def band_cols(yN, band):
     """physical column of every logical (centred) column, -1 outside the band (parity-split layout)"""
     start, length = band
-    half = (length + 1) // 2
+    half = ((length + 1) // 2 + 15) // 16 * 16  # swiftly_hip_band_columns(length) / 2
     d = (numpy.arange(yN) - start) % yN
     return numpy.where(d < length, (d & 1) * half + (d >> 1), -1)
 

@@ -173,3 +173,85 @@ def test_backward_64k_sparse_is_adjoint_of_checked_forward():
         assert rel < 1e-6, (baxis, lhs, rhs)  # measured 2e-9 .. 3e-9: rounding errors average out in the sums
         del bwd, out
         torch.cuda.empty_cache()
+
+
+def test_forward_64k_sparse_full_rank_facets_match_direct_dft():
+    """FULL-RANK dense facets (``N(0,1) + i N(0,1)`` as complex64, ``default_rng(1234 + j)``,
+    times the cover masks) at the benchmarked shape: 16 sampled pixels of 3 subgrids against the DIRECT sum over all
+    pixels of all 9 facets (drawn with torch's generator on the device, same distribution),  sg[u] = N^-2 sum_j sum_p facet_j[p] exp(2 pi i <u, c_j(p)> / N)  -- the truth of reference
+    fourier_algorithm.py:267-315 (``make_subgrid_from_sources``) with every pixel a source, independent of the
+    algorithm and of the oracle.  The sum is evaluated in complex128 (torch matmul, plumbing).  Tolerance: the float32
+    level of DESIGN.md section 2 (the truncation error of the algorithm itself is ~3e-7 for W = 10.875)."""
+    torch, sw, p, cfg, facet_cfgs, sg_cfgs = _setup()
+    N, yB, xA = p["N"], p["yB_size"], p["xA_size"]
+    facets = []
+    for j, c in enumerate(facet_cfgs):
+        # drawn on the device (seed 1234 + j; numpy's generator would spend ~10 s of host time per 4 GB facet)
+        gen = torch.Generator(device="cuda").manual_seed(1234 + j)
+        d = torch.randn((yB, yB), dtype=torch.complex64, device="cuda", generator=gen) * (2.0 ** 0.5)  # N(0,1) + i N(0,1)
+        m0 = torch.as_tensor(c.mask0, dtype=torch.float32, device="cuda")
+        m1 = torch.as_tensor(c.mask1, dtype=torch.float32, device="cuda")
+        facets.append(d * m0[:, None] * m1[None, :])
+        del d
+    picks = sep.pick_subgrids(sg_cfgs, 3)
+    axis = sw.api.preferred_wave_axis(cfg, torch.complex64)
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=axis)
+    got = {}
+    for widx in _waves_with(sg_cfgs, picks, axis):
+        res = fwd.get_wave([sg_cfgs[i] for i in widx])
+        for k, i in enumerate(widx):
+            if i in picks:
+                got[i] = res[k].clone()
+    del fwd
+    torch.cuda.empty_cache()
+    rng = numpy.random.default_rng(77)
+    pix = {i: [(int(a), int(b)) for a, b in zip(rng.integers(0, xA, 16), rng.integers(0, xA, 16))] for i in picks}
+    truth = {i: torch.zeros(16, dtype=torch.complex128, device="cuda") for i in picks}
+    for c, fac in zip(facet_cfgs, facets):
+        f128 = fac.to(torch.complex128)
+        # image coordinates of the facet's pixels (reference fourier_algorithm.py:218-264: pixel p <-> coordinate p + off - yB//2)
+        c0 = torch.arange(yB, dtype=torch.float64, device="cuda") + (c.off0 - yB // 2)
+        c1 = torch.arange(yB, dtype=torch.float64, device="cuda") + (c.off1 - yB // 2)
+        for i in picks:
+            sg = sg_cfgs[i]
+            u0 = torch.tensor([sg.off0 - xA // 2 + a for a, _ in pix[i]], dtype=torch.float64, device="cuda")
+            u1 = torch.tensor([sg.off1 - xA // 2 + b for _, b in pix[i]], dtype=torch.float64, device="cuda")
+            # phases reduced modulo N in exact integer arithmetic (products up to 2^32 are exact in float64)
+            ph0 = torch.remainder(u0[:, None] * c0[None, :], N) * (2 * numpy.pi / N)
+            ph1 = torch.remainder(u1[:, None] * c1[None, :], N) * (2 * numpy.pi / N)
+            e0 = torch.polar(torch.ones_like(ph0), ph0)
+            e1 = torch.polar(torch.ones_like(ph1), ph1)
+            truth[i] += ((e0 @ f128) * e1).sum(dim=1) / float(N) ** 2
+        del f128
+    errs = []
+    for i in picks:
+        sg = sg_cfgs[i]
+        g = torch.stack([got[i][a, b] for a, b in pix[i]]).to(torch.complex128)
+        mask = torch.tensor([sg.mask0[a] * sg.mask1[b] for a, b in pix[i]], dtype=torch.float64, device="cuda")
+        want = truth[i] * mask
+        rms = float(got[i].abs().pow(2).mean().sqrt())  # level of the whole subgrid
+        err = float((g - want).abs().pow(2).mean().sqrt()) / rms
+        print(f"subgrid ({sg.off0},{sg.off1}): 16 pixels vs direct DFT of 9 dense facets: relRMSE {err:.3e}")
+        errs.append(err)
+    assert max(errs) < 3e-5, errs
+
+
+def test_host_fed_facet_through_the_staging_ring():
+    """Host <-> device edge: a 4 GB complex64 facet handed over as a NUMPY array goes through
+    ``_FacetIngest`` -- 31 slabs of 128 MB through the two pinned staging buffers on the copy stream -- and gives
+    bit-identical subgrids to the same facet handed over as a device tensor."""
+    torch, sw, p, cfg, facet_cfgs, sg_cfgs = _setup()
+    yB = p["yB_size"]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    dev = [torch.randn((yB, yB), dtype=torch.complex64, device="cuda", generator=gen) for _ in range(2)]
+    host0 = dev[0].cpu().numpy()
+    assert host0.nbytes > 30 * sw.api._FacetIngest.SLAB  # many slabs: the ring slots are reused
+    fcs = facet_cfgs[:2]
+    wave = [c for c in sg_cfgs if c.off1 == 0][:4]
+    axis = sw.api.preferred_wave_axis(cfg, torch.complex64)
+    ref = sw.SwiftlyForward(cfg, list(zip(fcs, dev)), subgrid_configs=wave, wave_axis=axis)
+    want = ref.get_wave(wave).clone()
+    del ref
+    fed = sw.SwiftlyForward(cfg, [(fcs[0], host0), (fcs[1], dev[1])], subgrid_configs=wave, wave_axis=axis)
+    got = fed.get_wave(wave)
+    assert torch.equal(got, want)

@@ -2,8 +2,8 @@
 GPU parity at the sizes of the other BASELINE.json configurations and for sparse FACET lists (rows g1, f2),
 complex64, against the separable oracle (oracle/separable.py) on a few facets / subgrids each:
 
-  * config 3 parameters (W=11, N=32768, yB=4096, yN=8192, xA=2048, xM=4096 -> m=1024): the sizes without fused
-    kernels (m > 512, xM = 4096) take the general launch sequence;
+  * config 3 parameters (W=11, N=32768, yB=4096, yN=8192, xA=2048, xM=4096 -> m=1024): both the general launch
+    sequence and (r3) the fused contiguous-axis-first pipeline;
   * config 5, catalogue 128k[1]-n64k-1k (N=131072, yB=45056, yN=65536, xM=1024, m=512): yN = 65536 runs through the
     contiguous-axis-first pipeline (band row kernel at 2 x 32768 points, 256 x 256 column passes);
   * a sparse facet list (scripts/demo_sparse_facet.py:34-134 style: only the facets that intersect a region) on the
@@ -67,7 +67,14 @@ def _run(P, facet_cfgs, sg_cfgs, wave_axis, tol, plan=True, seed=900):
     return wave_axis
 
 
-def test_config3_sizes_m1024_xM4096():
+@pytest.mark.parametrize("wave_axis", [0, 1])
+def test_config3_sizes_m1024_xM4096(wave_axis):
+    """wave_axis=0: the general launch sequence; wave_axis=1 (r3): the contiguous-axis-first pipeline with the
+    generic K1 for yN = 8192 (plain band layout), the single-pass 1024-point column transform for m = 1024 and the
+    two-waves-per-row sum_finish / split_prepare instances for xM = 4096 -- forward against the oracle, both backward
+    schedules through the adjoint identity."""
+    import torch
+
     import ska_sdp_exec_swiftly_amd as sw
 
     P = dict(W=11.0, fov=1.0, N=32768, yB_size=4096, yN_size=8192, xA_size=2048, xM_size=4096)
@@ -75,7 +82,11 @@ def test_config3_sizes_m1024_xM4096():
     facet_cfgs = [c for c in cover if (c.off0, c.off1) in ((0, 0), (4096, 4096 * 7))]
     sgs = sw.api.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
     sg_cfgs = [c for c in sgs if (c.off0 // 2048, c.off1 // 2048) in ((0, 0), (0, 15), (3, 2))]
-    _run(P, facet_cfgs, sg_cfgs, 0, 2e-5, plan=False)
+    if wave_axis == 1:
+        cfg = sw.SwiftlyConfig(backend="hip", **P)
+        assert sw.api.preferred_wave_axis(cfg, torch.complex64, n_facets=64) == 1
+        assert cfg.core.band_for_offsets([0, 2048]) == (0, 8192) and cfg.core.band_columns((0, 8192)) == 8192
+    _run(P, facet_cfgs, sg_cfgs, wave_axis, 2e-5, plan=wave_axis == 1)
 
 
 def test_config5_sizes_yN65536():

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Per-kernel HBM traffic of the forward pass (three rocprofv3 runs of the same command; counters in their own runs):
+#   tools/gpu_pmc.sh OUTDIR [workload]   ->  OUTDIR/pmc_kernels.json (copy to profiles/r3_pmc_kernels.json)
+out=$1; wl=${2:-64k-sparse}
+mkdir -p "$out"
+export TMPDIR=/tmp
+here=$(pwd)
+cmd="python $here/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-backward"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$here/$out/kt" -o kt -- $cmd > "$here/$out/kt.log" 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$here/$out/pf" -o pf -- $cmd > "$here/$out/pf.log" 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$here/$out/pw" -o pw -- $cmd > "$here/$out/pw.log" 2>&1 )
+kt=$(find "$out/kt" -name '*.db' | head -1); pf=$(find "$out/pf" -name '*.db' | head -1); pw=$(find "$out/pw" -name '*.db' | head -1)
+python tools/rocpd_stats.py "$kt" > "$out/kernel_stats.txt" 2>&1
+python tools/pmc_kernels.py "$kt" "$pf" "$pw" "$out/pmc_kernels.json" "$wl" | tee "$out/pmc_kernels.txt"
+rm -rf "$out/kt" "$out/pf" "$out/pw"

@@ -1,6 +1,12 @@
-"""Per-rank compute time of the 64k-sparse forward pass at world sizes 1..8, measured with VIRTUAL ranks on one GPU
-(the exchange itself is not executed: each rank's receive buffer is a dummy of the right size).  Gives the
-compute-side critical path of an N-GPU run -- an upper bound on the achievable speed-up, not a measurement of it."""
+"""Per-rank compute time and exchange volume of a forward (and backward) pass at world sizes 1..8, measured with
+VIRTUAL ranks on ONE GPU: every rank's objects are built in one process (`rank_world=`), each rank's share of the
+pass is timed on its own, and the all-to-all is NOT executed (a rank's receive buffer is a dummy of the right size).
+What this gives: the compute-side critical path per rank (max over ranks) and the bytes each rank has to send per
+pass -- the two inputs of a scaling estimate.  What it does not give: a scaling curve (RCCL over xGMI never runs here).
+
+    python tools/virtual_rank_time.py [workload] [out.json]
+"""
+import json
 import os
 import sys
 import time
@@ -13,40 +19,103 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 import ska_sdp_exec_swiftly_amd as sw  # noqa: E402
 from oracle import separable as sep  # noqa: E402  (data recipe only)
-from ska_sdp_exec_swiftly_amd.distributed import DistributedForward  # noqa: E402
+from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward  # noqa: E402
 
-wl = bench.WORKLOADS["64k-sparse"]
-p = wl["params"]
-cfg = sw.SwiftlyConfig(backend="hip", **p)
-fcs = sw.make_full_facet_cover(cfg)
-sgs = bench.select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
-axis = sw.api.preferred_wave_axis(cfg, torch.complex64)
-key = (lambda c: c.off1) if axis == 1 else (lambda c: c.off0)
-waves = {}
-for c in sgs:
-    waves.setdefault(key(c), []).append(c)
-waves = list(waves.values())
-vec = [sep.facet_vectors(1234 + j, p["yB_size"]) for j in range(len(fcs))]
-data = [bench.separable_facet(torch, vec[j], fcs[j]) for j in range(len(fcs))]
-m = cfg.core.xM_yN_size
-for world in (1, 2, 4, 8):
-    times = []
-    for rank in range(world):
-        def one_pass():
-            dfw = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64,
-                                     rank_world=(rank, world))
-            dfw.prepare_all_facets()
-            for wave in waves:
-                send, inc, outc = dfw.pack_wave(wave)
-                recv = send if world == 1 else torch.empty(sum(outc), dtype=torch.complex64, device="cuda")
-                dfw.unpack_wave(wave, recv)
-        one_pass()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            one_pass()
-        torch.cuda.synchronize()
-        times.append((time.perf_counter() - t0) / 3 * 1e3)
-        if world == 8 and rank >= 2:
-            break  # ranks 1..7 are alike
-    print(f"world {world}: per-rank compute ms {['%.2f' % t for t in times]}  max {max(times):.2f}")
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "64k-sparse"
+    out_path = sys.argv[2] if len(sys.argv) > 2 else None
+    wl = bench.WORKLOADS[name]
+    p = wl["params"]
+    cfg = sw.SwiftlyConfig(backend="hip", **p)
+    all_fcs = sw.make_full_facet_cover(cfg)
+    sgs = bench.select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
+    m = cfg.core.xM_yN_size
+    xA = p["xA_size"]
+    res = dict(workload=wl["name"], worlds={})
+    one = bench.separable_facet(torch, sep.facet_vectors(1234, p["yB_size"]), all_fcs[0])
+    for world in (1, 2, 4, 8):
+        cap = wl.get("max_facets_per_rank")
+        n_active = len(all_fcs) if cap is None else min(len(all_fcs), cap * world)
+        fcs = all_fcs[:n_active]
+        axis = sw.api.preferred_wave_axis(cfg, torch.complex64, n_facets=len(fcs))
+        key = (lambda c: c.off1) if axis == 1 else (lambda c: c.off0)
+        waves = {}
+        for c in sgs:
+            waves.setdefault(key(c), []).append(c)
+        waves = list(waves.values())
+        max_waves = int(os.environ.get("VR_MAX_WAVES", "0"))  # big covers: time a prefix of the waves and scale
+        scale = 1.0
+        if max_waves and len(waves) > max_waves:
+            scale = len(waves) / max_waves
+            waves = waves[:max_waves]
+        data = [one] * len(fcs)  # timing only: every facet holds the same numbers
+        ranks = sorted({0, 1, world - 1} & set(range(world)))  # rank 0 carries the extra facet when F % world != 0
+        ent = dict(facets=len(fcs), wave_axis=axis, waves_timed=len(waves), wave_scale=scale, ranks={})
+        for rank in ranks:
+            sent = [0]
+
+            def forward_pass():
+                dfw = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64,
+                                         rank_world=(rank, world))
+                dfw.prepare_all_facets()
+                sent[0] = 0
+                for wave in waves:
+                    send, inc, outc = dfw.pack_wave(wave)
+                    sent[0] += 8 * (sum(inc) - inc[rank])
+                    recv = send if world == 1 else torch.empty(sum(outc), dtype=torch.complex64, device="cuda")
+                    dfw.unpack_wave(wave, recv)
+
+            def backward_pass(subs):
+                dbw = DistributedBackward(cfg, fcs, wave_axis=1 if cfg.core.supports_backward_band(torch.complex64) else 0,
+                                          subgrid_configs=sgs, dtype=torch.complex64, rank_world=(rank, world))
+                for wave, mine, got in subs:
+                    send, inc, outc = dbw.pack_wave(wave, [got[k] for k in range(len(mine))] if got is not None else [])
+                    recv = send if world == 1 else torch.empty(sum(outc), dtype=torch.complex64, device="cuda")
+                    if world > 1:
+                        recv.zero_()
+                    dbw.unpack_wave(wave, recv)
+                return dbw.finish()
+
+            def timed(fn, reps=2):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e3
+
+            t_f = timed(forward_pass) * scale
+            # subgrid data for the backward leg: random subgrids of the right shape for the ones this rank holds
+            dfw0 = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64,
+                                      rank_world=(rank, world))
+            subs = []
+            bkey = (lambda c: c.off1) if cfg.core.supports_backward_band(torch.complex64) else (lambda c: c.off0)
+            bw = {}
+            for c in sgs:
+                bw.setdefault(bkey(c), []).append(c)
+            bwl = list(bw.values())[: len(waves)]
+            for wave in bwl:
+                mine = dfw0.sharding.subgrids_of(len(wave))
+                got = torch.randn((len(mine), xA, xA), dtype=torch.complex64, device="cuda") if mine else None
+                subs.append((wave, mine, got))
+            del dfw0
+            t_b = timed(lambda: backward_pass(subs)) * scale
+            ent["ranks"][str(rank)] = dict(forward_ms=round(t_f, 2), backward_ms=round(t_b, 2),
+                                           forward_sent_MB_per_pass=round(sent[0] * scale / 1e6, 1))
+            print(f"{name} world {world} rank {rank}: forward {t_f:.2f} ms, backward {t_b:.2f} ms, sends {sent[0] * scale / 1e6:.0f} MB per forward pass",
+                  flush=True)
+            del subs
+            torch.cuda.empty_cache()
+        ent["critical_path_forward_ms"] = max(r["forward_ms"] for r in ent["ranks"].values())
+        ent["critical_path_backward_ms"] = max(r["backward_ms"] for r in ent["ranks"].values())
+        res["worlds"][str(world)] = ent
+    if out_path:
+        with open(out_path, "w", encoding="utf-8") as fh:
+            json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
