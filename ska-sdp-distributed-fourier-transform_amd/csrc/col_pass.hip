@@ -1,4 +1,6 @@
 // instantiations + dispatch of the lean column-tile pass (complex64)
+#include <cstdlib>
+
 #include "swiftly_colpass.h"
 
 namespace swf {
@@ -9,7 +11,8 @@ struct CGeoFor {
     // exchange re and im separately from 128 rows on: 32 KiB (n = 128) / 64 KiB (n = 256) of LDS per
     // workgroup keep 16 waves per CU resident, which is what hides the HBM latency (measured:
     // 8 waves/CU -> 84 % of wave cycles waiting, 2.2 TB/s; 16 waves/CU -> 4.7 TB/s)
-    // 1024 points: 32-column tiles (two rows per wave), 128 KiB
+    // 1024 points: 32-column tiles (two rows per wave), 128 KiB.  (The same tiles for 512 points -- 64 KiB, two
+    // workgroups per CU instead of one -- were measured r3 on the 64k pass: 43.37 vs 43.29 ms, no gain; not kept.)
     using type = CGeo<LOGN, LOGP, (LOGN >= 7), (LOGN >= 10 ? 32 : 64)>;
 };
 

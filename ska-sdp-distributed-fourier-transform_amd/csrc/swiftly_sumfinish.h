@@ -44,10 +44,12 @@ struct SumFinishArgs {
 
 template <int LOGM, int LOGX>
 struct SFGeo {
-    // threads per row: one wave up to 2048-point rows (rows are wave-private: no workgroup barriers); two waves for
-    // 4096-point rows (64 points per lane would not fit the register file; the row then synchronises with
-    // workgroup barriers, which the workgroup-uniform facet loop allows)
-    static constexpr int LOGTR = LOGX >= 12 ? 7 : 6;
+    // threads per row: one wave up to 2048-point rows (rows are wave-private: no workgroup barriers); FOUR waves for
+    // 4096-point rows: the 35 KB accumulator row limits a CU to 3 rows, so the waves have to come from within the row
+    // (measured r3, config-3 sizes, 16 facets per row: two waves per row + two rows per workgroup = 4 waves per CU,
+    // 8.4 ms per wave of 16 subgrids = 1.0 TB/s).  The row then synchronises with workgroup barriers, which the
+    // workgroup-uniform facet loop allows.
+    static constexpr int LOGTR = LOGX >= 12 ? 8 : 6;
     static constexpr int TR = 1 << LOGTR;
     static constexpr int NT = SWF_SF_NT;
     using GM = Geo<float, LOGM, LOGM - LOGTR, NT, false>;

@@ -162,7 +162,7 @@ def test_band_range_is_the_smallest_cyclic_cover():
     rng = numpy.random.default_rng(1)
     for trial in range(20):
         offs = [int(o) * 928 for o in rng.integers(-70, 71, size=rng.integers(1, 12))]
-        start, length = band_range(N, yN, m, offs)
+        start, length = band_range(N, yN, m, offs, align=1)
         inside = numpy.zeros(yN, dtype=bool)
         inside[(start + numpy.arange(length)) % yN] = True
         used = numpy.zeros(yN, dtype=bool)
@@ -175,6 +175,15 @@ def test_band_range_is_the_smallest_cyclic_cover():
         ring = numpy.concatenate([used, used])
         longest = max(len(run) for run in "".join("u" if u else "." for u in ring).split("u"))
         assert length == yN - min(longest, yN - used.sum())
+        # default alignment: the band starts up to 31 columns early so that every window origin is a multiple of 32
+        # columns from the start (both parity runs of a 64-column tile then begin on a 128-byte line)
+        a_start, a_length = band_range(N, yN, m, offs)
+        shift = (start - a_start) % yN
+        assert shift < 32 and a_length == min(yN, length + shift) or (a_start, a_length) == (0, yN)
+        if (a_start, a_length) != (0, yN):
+            for off in offs:
+                s = off * yN // N
+                assert ((yN // 2 - m // 2 + s - a_start) + (-s % m)) % 32 == 0
     offs = [i * 928 for i in range(-12, 13)]
-    assert band_range(N, yN, m, offs)[1] == 24 * 464 + 512
+    assert band_range(N, yN, m, offs, align=1)[1] == 24 * 464 + 512
     assert band_range(N, yN, m, [i * 928 for i in range(71)]) == (0, yN)

@@ -12,7 +12,7 @@ import json, sys
 try:
     d = json.load(open(sys.argv[1]))
     par = d["parity"]["rel_rmse"] if d.get("parity") else None
-    print(sys.argv[2], "rc=" + sys.argv[3], d["ms_per_step"], {k: v["total_ms"] for k, v in d["stages"].items()}, "parity", par)
+    print(sys.argv[2], "rc=" + sys.argv[3], d["ms_per_step"], {k: v.get("total_ms", v.get("avg_ms")) for k, v in d["stages"].items()}, "parity", par)
 except Exception as exc:
     print(sys.argv[2], "rc=" + sys.argv[3], "FAILED", exc)
 PY
