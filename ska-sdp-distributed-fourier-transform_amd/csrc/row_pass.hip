@@ -1,5 +1,4 @@
 // instantiations + dispatch of the lean long-row kernel (complex64)
-#include <algorithm>
 #include <cstdlib>
 
 #include "swiftly_rowpass.h"
@@ -75,23 +74,12 @@ int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<
 using BandGeo5 = RGeo<14, 5, true>;  // 2 x 16384 points, 512 threads x 32, 66 KB LDS: two workgroups per CU
 using BandGeo4 = RGeo<14, 4, true>;  // 2 x 16384 points, 1024 threads x 16, one workgroup per CU
 template <class G, bool PAIR = false>
-static int launch_band_geo(const RowPassArgs& a_in, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
-    RowPassArgs a = a_in;
-    a.nblocks = ((a.nrows + 7) / 8) * 16;
-    // persistent workgroups (A/B switch, workgroups per CU; 0 = one workgroup per row half)
-    static const int persist = getenv("SWIFTLY_ROW_PERSIST") ? atoi(getenv("SWIFTLY_ROW_PERSIST")) : 0;
-    unsigned blocks = (unsigned)a.nblocks;
-    if (persist > 0) blocks = std::min<unsigned>(blocks, (unsigned)persist * 256u);
+static int launch_band_geo(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
+    const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
     const bool band = a.band_len > 0;
-#define SWF_LAUNCH_BAND(WIN, ST)                                                                                          \
-    do {                                                                                                                  \
-        if (blocks < (unsigned)a.nblocks)                                                                                 \
-            hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, true>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, \
-                               a, a.in, a.out, a.ld_win, tw14, tw_full);                                                  \
-        else                                                                                                              \
-            hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, false>), dim3(blocks), dim3(G::NT), G::LDS_BYTES,   \
-                               s, a, a.in, a.out, a.ld_win, tw14, tw_full);                                               \
-    } while (0)
+#define SWF_LAUNCH_BAND(WIN, ST)                                                                                        \
+    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, \
+                       a.out, a.ld_win, tw14, tw_full)
     if (a.band_len < 0) {  // mapped (crop + window) store: finish_* primitives
         SWF_LAUNCH_BAND(false, 2);
     } else if (a.ld_win) {
@@ -131,27 +119,19 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
 }
 int row_pass_band_occupancy() {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_band_kernel<BandGeo5, true, 1, false, false>, BandGeo5::NT,
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_band_kernel<BandGeo5, true, 1>, BandGeo5::NT,
                                                        BandGeo5::LDS_BYTES);
     return n;
 }
 template <class G, bool WIN, int ST>
 static int init_band() {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    if (!rc)
-        rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    return rc;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 template <class G, bool WIN, int ST>
 static int init_band_pair() {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    if (!rc)
-        rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    return rc;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 template <class G>
 static int init_band_geo() {

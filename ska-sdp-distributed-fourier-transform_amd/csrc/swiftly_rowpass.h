@@ -53,7 +53,6 @@ struct RowPassArgs {
     // (d & 1) * band_half + (d >> 1).  (The two workgroups of a row produce the even / odd outputs; with this
     // layout each of them writes one contiguous run instead of every other element.)  band_len = 0: plain row.
     int band_start, band_len, band_half;
-    int nblocks;  // virtual blocks of the launch (two per row, rounded up to 16 per 8 rows); set by the launcher
 };
 
 // physical column of logical (centred) column ck in a parity-split band buffer, or -1
@@ -327,19 +326,23 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // (Skipping the loads whose 64 lanes are all padding -- 31 % of prepare_facet's, 64 % of finish_facet's band loads --
 // with a wave-uniform branch was tried: the branches make the compiler hoist every load above the first use and wait
 // at every join, 280 B/lane of spills; not kept.)
-template <class G, bool HAS_WIN, int ST, bool PAIR, bool LOOP>
-__device__ __forceinline__ void row_pass_band_body(const RowPassArgs& A, const cx<float>* __restrict__ gin,
-                                                   cx<float>* __restrict__ gout, const float* __restrict__ ld_win,
-                                                   const cx<float>* __restrict__ tw, const cx<float>* __restrict__ tw_full,
-                                                   unsigned char* smem, const int b) {
+// (r3: PERSISTENT workgroups -- a grid of 2, 4 or 8 workgroups per CU, each looping over row halves, thread-index
+// invariants kept out of the loop so that nothing spills -- were measured SLOWER than one workgroup per row half:
+// K1 1.95 / 1.93 / 1.88 ms per facet against 1.82 ms.  The hardware dispatcher refills a CU the moment one of its two
+// workgroups retires, which also keeps the two residents out of phase; a static loop does neither.  Not kept.)
+template <class G, bool HAS_WIN, int ST, bool PAIR = false>
+__global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
+                                                                 cx<float>* __restrict__ gout,
+                                                                 const float* __restrict__ ld_win,
+                                                                 const cx<float>* __restrict__ tw,
+                                                                 const cx<float>* __restrict__ tw_full) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = G::P, T = G::T, H = G::N, N = 2 * G::N;
     constexpr bool BAND = ST == 1;
     static_assert(64 % (N / T) == 0, "the inter-half twiddle uses W_64 constants: j = t + T v, W_N^(T v) = W_64^(v 64 T / N)");
     constexpr int WSTEP = 64 / (N / T);
-    int t = threadIdx.x;
-    // persistent form: keep the compiler from hoisting everything that depends on the thread index only (LDS
-    // positions, inter-phase twiddles: ~35 VGPRs) out of the row loop -- the kernel sits at the 128-VGPR limit
-    if constexpr (LOOP) asm volatile("" : "+v"(t));
+    const int t = threadIdx.x;
+    const int b = blockIdx.x;
     const int h = (b >> 3) & 1;
     const int row = ((b >> 4) << 3) + (b & 7);  // uniform; both halves of a row on the same XCD (b mod 8)
     if (row >= A.nrows) return;
@@ -541,25 +544,6 @@ __device__ __forceinline__ void row_pass_band_body(const RowPassArgs& A, const c
         }
 #endif
     });
-}
-
-// The kernel: workgroup `blockIdx.x` works on the virtual blocks  blockIdx.x + k * gridDim.x  (k = 0, 1, ...), A.nblocks
-// in total.  gridDim.x = A.nblocks is the plain one-row-half-per-workgroup launch; a grid of a few workgroups per CU
-// makes the workgroups PERSISTENT (no per-row workgroup launch / descriptor set-up; gridDim.x must be a multiple of 16
-// so that both halves of a row stay on one XCD).  A/B switch SWIFTLY_ROW_PERSIST (workgroups per CU, 0 = off).
-template <class G, bool HAS_WIN, int ST, bool PAIR = false, bool LOOP = false>
-__global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
-                                                                 cx<float>* __restrict__ gout,
-                                                                 const float* __restrict__ ld_win,
-                                                                 const cx<float>* __restrict__ tw,
-                                                                 const cx<float>* __restrict__ tw_full) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if constexpr (LOOP) {
-        for (int b = blockIdx.x; b < A.nblocks; b += gridDim.x)
-            row_pass_band_body<G, HAS_WIN, ST, PAIR, true>(A, gin, gout, ld_win, tw, tw_full, smem, b);
-    } else {
-        row_pass_band_body<G, HAS_WIN, ST, PAIR, false>(A, gin, gout, ld_win, tw, tw_full, smem, (int)blockIdx.x);
-    }
 }
 
 constexpr int kRowPassMinLog = 13;
