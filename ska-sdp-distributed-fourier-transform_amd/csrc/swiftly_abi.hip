@@ -16,33 +16,12 @@
 // with s = floor(subgrid_off*yN/N), s' = floor(facet_off*xM/N), all arrays
 // centred (origin at index n//2).
 #include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/swiftly_hip.h"
-#include "swiftly_colpass.h"
-#include "swiftly_rowpass.h"
-#include "swiftly_sumfinish.h"
-#include "swiftly_rows.h"
-#include "swiftly_bluestein.h"
-#include <complex>
-
-using namespace swf;
+#include "swiftly_abi_internal.h"
 
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static int fail(int code, const char* fmt, ...) {
+int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -51,76 +30,6 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                      \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess) return fail(SWIFTLY_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-static inline int64_t floordiv(int64_t a, int64_t b) {
-    int64_t q = a / b;
-    if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
-    return q;
-}
-static inline int pmod(int64_t a, int64_t n) {
-    int64_t r = a % n;
-    if (r < 0) r += n;
-    return (int)r;
-}
-static inline int ilog2_exact(int64_t n) {
-    if (n <= 0 || (n & (n - 1))) return -1;
-    int l = 0;
-    while ((int64_t(1) << l) < n) l++;
-    return l;
-}
-
-struct swiftly_hip {
-    int64_t N, yN, xM, m;
-    double W;
-    int device;
-    int log_yN, log_xM, log_m;  // -1 when not a power of two
-    float* invp_f = nullptr;    // 1/pswf[k] (k = 0 -> 0)
-    double* invp_d = nullptr;
-    float* fn_f = nullptr;  // Fn[k], k < m
-    double* fn_d = nullptr;
-    std::map<int, cx<float>*> tw_f;  // by log2(length)
-    std::map<int, cx<double>*> tw_d;
-    // Bluestein tables for transform lengths that are not a power of two (swiftly_bluestein.h), by length
-    struct Blu {
-        int logL = 0;
-        cx<float>* chirp_f = nullptr;
-        cx<float>* spec_f = nullptr;
-        cx<double>* chirp_d = nullptr;
-        cx<double>* spec_d = nullptr;
-    };
-    std::map<int64_t, Blu> blu;
-    std::vector<void*> allocs;
-};
-
-template <typename R>
-static const cx<R>* twiddles(const swiftly_hip* h, int logn);
-template <>
-const cx<float>* twiddles<float>(const swiftly_hip* h, int logn) {
-    auto it = h->tw_f.find(logn);
-    return it == h->tw_f.end() ? nullptr : it->second;
-}
-template <>
-const cx<double>* twiddles<double>(const swiftly_hip* h, int logn) {
-    auto it = h->tw_d.find(logn);
-    return it == h->tw_d.end() ? nullptr : it->second;
-}
-template <typename R>
-static const R* invp(const swiftly_hip* h);
-template <>
-const float* invp<float>(const swiftly_hip* h) { return h->invp_f; }
-template <>
-const double* invp<double>(const swiftly_hip* h) { return h->invp_d; }
-template <typename R>
-static const R* fnwin(const swiftly_hip* h);
-template <>
-const float* fnwin<float>(const swiftly_hip* h) { return h->fn_f; }
-template <>
-const double* fnwin<double>(const swiftly_hip* h) { return h->fn_d; }
 
 template <typename T>
 static int upload(swiftly_hip* h, T** dst, const std::vector<T>& v) {
@@ -225,22 +134,6 @@ static int make_bluestein(swiftly_hip* h, int64_t n) {
 static std::mutex g_init_mutex;
 static std::vector<char> g_device_inited;
 
-// RAII: make `device` current for the duration of one ABI call and restore the caller's (torch's) current
-// device afterwards.  Streams handed in by the caller belong to the handle's device.
-struct DeviceGuard {
-    int prev = -1, rc = 0;
-    explicit DeviceGuard(int device) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != device) rc = (int)hipSetDevice(device);
-        else prev = -1;  // nothing to restore
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-// Transforms of length >= 2^kTwoPassMinLog along a STRIDED axis (rows contiguous) are decomposed into
-// two passes of short transforms so that every access is >= 128 B contiguous.
-static const int kTwoPassMinLog = 9;
 
 extern "C" {
 
@@ -442,14 +335,14 @@ static int launch_checked(int logn, const RowsArgs<R>& a, const OffTab& tab, hip
     return 0;
 }
 
-static ColZ plain_colz() {
+ColZ plain_colz() {
     ColZ z;
     std::memset(&z, 0, sizeof z);
     z.nb = 1;
     return z;
 }
 
-static int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz, int outer, int nb, hipStream_t st) {
+int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz, int outer, int nb, hipStream_t st) {
     int e = launch_col_pass(lg, mode, args, cz, outer, nb, st);
     if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return 0;
@@ -467,15 +360,11 @@ static int launch_col_checked(int lg, int mode, const ColPassArgs& args, const C
 // points have no workspace parameter): col_transform prefers it to a stream-ordered allocation.  Measured on
 // MI355X: hipMallocAsync with a size that changes from call to call costs ~2 ms of HOST time per call (the pool
 // does not reuse a smaller free block), which made a 25-wave pass host-bound.
-static thread_local void* t_call_ws = nullptr;
-static thread_local size_t t_call_ws_bytes = 0;
-struct CallWorkspace {
-    CallWorkspace(void* p, size_t bytes) { t_call_ws = p; t_call_ws_bytes = p ? bytes : 0; }
-    ~CallWorkspace() { t_call_ws = nullptr; t_call_ws_bytes = 0; }
-};
+thread_local void* t_call_ws = nullptr;
+thread_local size_t t_call_ws_bytes = 0;
 
-static int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st,
-                         void* ws = nullptr, size_t ws_bytes = 0) {
+int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st, void* ws,
+                  size_t ws_bytes) {
     if (!ws && t_call_ws) {
         ws = t_call_ws;
         ws_bytes = t_call_ws_bytes;
@@ -614,35 +503,6 @@ static bool try_col_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     return true;
 }
 
-
-// touched[d] = 1 for the band columns d of one wave's window (see accumulate_facet_columns)
-__global__ void mark_columns_kernel(unsigned char* __restrict__ touched, int m, int rot, int base, int yN, int band_start,
-                                    int band_len) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= m) return;
-    const int scol = (base + ((col + rot) & (m - 1))) & (yN - 1);
-    const int d = (scol - band_start) & (yN - 1);
-    if (d < band_len) touched[d] = 1;
-}
-// zero the band columns no wave has written (rows x band_len, row stride `pitch`)
-__global__ void zero_untouched_kernel(cx<float>* __restrict__ band, const unsigned char* __restrict__ touched, long long rows,
-                                      long long pitch, int band_len) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= band_len || touched[d]) return;
-    for (long long r = blockIdx.y; r < rows; r += gridDim.y) band[r * pitch + d] = cx<float>{0.f, 0.f};
-}
-
-// where does this workgroup run?  xcc_id << 16 | se_id << 8 | cu_id  (HW_REG_XCC_ID, HW_REG_HW_ID of gfx9);
-// the workgroup lingers for a few microseconds so that a census grid spreads over all CUs its stream may use
-__global__ void cu_census_kernel(int* __restrict__ out) {
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < 20000) {
-    }
-    if (threadIdx.x == 0) out[blockIdx.x] = (int)(((xcc & 0xf) << 16) | (((hw >> 13) & 0x7) << 8) | ((hw >> 8) & 0xf));
-}
 
 __global__ void mul_windows_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -948,23 +808,6 @@ static int run_rows(swiftly_hip* h, int64_t nlen, int logn, RowsArgs<R>& a, cons
     return 0;
 }
 
-#define CHECK_COMMON()                                                                       \
-    if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");                  \
-    DeviceGuard device_guard_(h->device);                                                    \
-    if (device_guard_.rc) return fail(SWIFTLY_ERR_HIP, "hipSetDevice(%d) failed", h->device); \
-    if (rows < 0) return fail(SWIFTLY_ERR_PARAM, "negative row count");                      \
-    if (dtype != SWIFTLY_C64 && dtype != SWIFTLY_C128) return fail(SWIFTLY_ERR_PARAM, "bad dtype %d", dtype); \
-    if (in_cs < 0 || out_cs < 0 || in_cs >= (int64_t(1) << 32) || out_cs >= (int64_t(1) << 32)) \
-        return fail(SWIFTLY_ERR_PARAM, "column strides must be in [0, 2^32)");                 \
-    if (rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "too many rows");
-#define CHECK_BATCH()                                                                        \
-    if (nbatch < 0 || in_bs < 0 || out_bs < 0) return fail(SWIFTLY_ERR_PARAM, "bad batch description");
-// The accumulating entry points read-modify-write their output non-atomically and run the batch items
-// concurrently: items that share output elements would lose updates.
-#define CHECK_ACCUMULATE_BATCH()                                                             \
-    if (nbatch > 1 && out_bs == 0)                                                           \
-        return fail(SWIFTLY_ERR_PARAM, "accumulating batch items must not share output elements (out_batch_stride = 0)");
-
 template <typename R>
 static void fill_io(RowsArgs<R>& a, const void* in, int64_t rows, int64_t in_rs, int64_t in_cs, void* out,
                     int64_t out_rs, int64_t out_cs) {
@@ -1099,16 +942,6 @@ static int do_finish_facet(swiftly_hip* h, const void* in, int64_t rows, int64_t
     return run_rows(h, h->yN, h->log_yN, a, bt, 4,
                     [&](int64_t gb, int b, OffTab& t) { t.st_a[b] = pmod(-(lo + bt.offs[gb]), yN); }, st);
 }
-
-#define DISPATCH(fn, ...) (dtype == SWIFTLY_C64 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
-#define CHECK_FACET_SIZE()                                                                                     \
-    if (facet_size <= 0 || facet_size >= h->yN)                                                                \
-        return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1 = %lld]", (long long)facet_size, \
-                    (long long)(h->yN - 1));
-#define CHECK_SUBGRID_SIZE()                                                                                      \
-    if (subgrid_size <= 0 || subgrid_size > h->xM)                                                                \
-        return fail(SWIFTLY_ERR_PARAM, "subgrid size %lld must be in [1, xM_size = %lld]", (long long)subgrid_size, \
-                    (long long)h->xM);
 
 extern "C" {
 
@@ -1277,128 +1110,6 @@ int swiftly_hip_finish_facet(swiftly_hip_t* h, int dtype, const void* in, int64_
                                           mask, 1, 0, 0, nullptr, 0, stream);
 }
 
-int swiftly_hip_sum_finish_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t ngroups, int64_t in_group_stride,
-                                int64_t in_batch_stride, int64_t in_row_stride, const int64_t* group_facet_offs,
-                                void* out, int64_t out_batch_stride, int64_t out_row_stride,
-                                const int64_t* subgrid_offs, int64_t subgrid_size, const void* mask,
-                                int64_t mask_batch_stride, int64_t nbatch, void* stream) {
-    if (!h || !in || !out || !group_facet_offs || !subgrid_offs) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    CHECK_SUBGRID_SIZE();
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_rows: complex64 only");
-    if (ngroups <= 0 || ngroups > kSumFinishMaxGroups)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_rows: 1..%d facet groups supported", kSumFinishMaxGroups);
-    if (!sum_finish_supported(h->log_m, h->log_xM))
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_rows: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
-                    (long long)h->xM);
-    if (nbatch <= 0) return 0;
-    const int xM = (int)h->xM, xA = (int)subgrid_size;
-    SumFinishArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.in_gs = in_group_stride;
-    a.in_bs = in_batch_stride;
-    a.in_rs = in_row_stride;
-    a.out_bs = out_batch_stride;
-    a.out_rs = out_row_stride;
-    a.nrows = xM;
-    a.ngroups = (int)ngroups;
-    a.xA = xA;
-    for (int g = 0; g < ngroups; g++) a.sp[g] = (int)floordiv(group_facet_offs[g] * h->xM, h->N);
-    a.fn = h->fn_f;
-    a.mask_bs = mask ? mask_batch_stride : 0;
-    a.tw_m = twiddles<float>(h, h->log_m);
-    a.tw_x = twiddles<float>(h, h->log_xM);
-    if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    for (int64_t b0 = 0; b0 < nbatch; b0 += kSumFinishMaxBatch) {
-        const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nbatch - b0);
-        a.in = (const cx<float>*)in + b0 * in_batch_stride;
-        a.out = (cx<float>*)out + b0 * out_batch_stride;
-        a.mask = mask ? (const float*)mask + b0 * mask_batch_stride : nullptr;
-        for (int b = 0; b < nb; b++) a.st_a[b] = pmod(-(xM / 2 - xA / 2 + subgrid_offs[b0 + b]), xM);
-        int e = launch_sum_finish_rows(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
-        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    }
-    return 0;
-}
-
-int swiftly_hip_add_to_subgrid_from_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t in_row_stride,
-                                            int64_t in_facet_stride, int64_t nfacets, void* out,
-                                            int64_t out_col_stride, int64_t out_batch_stride, int64_t facet_off0,
-                                            int64_t nsub, const int64_t* subgrid_off1s, void* stream) {
-    if (!h || !in || !out || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: complex64 only");
-    const int m = (int)h->m, xM = (int)h->xM, yN = (int)h->yN;
-    if (h->log_m < kColPassMinLog || h->log_m > kColPassMaxLog || h->log_yN < 0)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: contribution size %d not supported", m);
-    if (nfacets <= 0 || nsub <= 0) return 0;
-    if ((uint64_t)m * (uint64_t)in_row_stride + (uint64_t)yN >= (uint64_t(1) << 32) ||
-        (uint64_t)xM * (uint64_t)out_col_stride + (uint64_t)m >= (uint64_t(1) << 32))
-        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
-    const int64_t sp = floordiv(facet_off0 * h->xM, h->N);
-    ColPassArgs c;
-    std::memset(&c, 0, sizeof c);
-    c.ncols = m;
-    c.full_logn = h->log_m;
-    c.in_pitch = (unsigned)in_row_stride;
-    c.out_pitch = (unsigned)out_col_stride;
-    c.ld_mul = c.st_mul = 1;
-    c.ld_a = 0; c.ld_len = m; c.ld_c = 0; c.ld_mod = m;
-    c.st_a = pmod(-sp, m); c.st_len = m; c.st_c = pmod(xM / 2 - m / 2 + sp, xM); c.st_mod = xM;
-    c.st_win = h->fn_f;
-    c.scale = 1.f;
-    c.accumulate = 1;
-    c.tw = twiddles<float>(h, h->log_m);
-    if (!c.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table");
-    c.cg_mod = m;
-    c.cg_full = yN;
-    c.in_bs_hi = in_facet_stride;
-    c.in_bs = 0;
-    c.out_bs = out_batch_stride;
-    // batch item z = f*nb + b  (f: facet / group index, b: subgrid of this chunk); item (f, b) reads facet f's
-    // column buffer and adds into out + (f*nsub + b0 + b) * out_batch_stride
-    if (nfacets > kColZF) return fail(SWIFTLY_ERR_UNSUPPORTED, "add_to_subgrid_from_columns: too many facets per call");
-    for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
-        const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
-        ColZ cz = plain_colz();
-        cz.flags = kZColGather;
-        cz.nb = nb;
-        for (int b = 0; b < nb; b++) {
-            const int64_t s = floordiv(subgrid_off1s[b0 + b] * h->yN, h->N);
-            cz.b_rot[b] = pmod(-s, m);
-            cz.b_base[b] = pmod(yN / 2 - m / 2 + s, yN);
-        }
-        c.in = (const cx<float>*)in;
-        c.in_bdiv = nb;
-        c.out = (cx<float>*)out + b0 * out_batch_stride;
-        c.out_bdiv = nb;
-        c.out_bs_hi = nsub * out_batch_stride;
-        if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, (int)nfacets * nb, (hipStream_t)stream)) return rc;
-    }
-    return 0;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Contiguous-axis-first pipeline
-
-// half of a parity-split band buffer, in columns: a multiple of 16 (128 bytes) so that BOTH parity runs of a 64-column
-// tile of the column pass start on a cache line (r2: (band_len + 1) / 2 = 5736 left every odd run 64 bytes off a line:
-// 5 lines fetched per 4 lines' worth, FETCH_SIZE of K2 pass A 1.04 GB per wave against 0.83 GB)
-static inline int64_t band_half_columns(int64_t band_len) { return (((band_len + 1) / 2) + 15) & ~int64_t(15); }
-int64_t swiftly_hip_band_columns(int64_t band_len) { return 2 * band_half_columns(band_len); }
-// Band layout of a handle: parity-split where the two-workgroup long-row kernel produces the band (yN >= 16384), else
-// PLAIN (half = 0: logical column d of the band at physical column d; K1 is the generic contiguous-axis transform and
-// keeps the whole padded axis).
-static inline bool band_is_split(const swiftly_hip* h) { return h->log_yN >= 14 && h->log_yN <= 16; }
-static inline int band_half_of(const swiftly_hip* h, int64_t band_len) {
-    return band_is_split(h) ? (int)band_half_columns(band_len) : 0;
-}
-int64_t swiftly_hip_band_columns_for(const swiftly_hip_t* h, int64_t band_len) {
-    if (!h) return -1;
-    return band_is_split(h) ? 2 * band_half_columns(band_len) : band_len;
-}
-
 int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                    int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                    int64_t band_start, int64_t band_len, int fold_other_axis_window, void* stream) {
@@ -1443,404 +1154,6 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     return 0;
 }
 
-} // extern "C" (helpers follow)
-// K2 for `nfacets` facets x `nwaves` waves: item (f, w) gathers the window of wave_off1s[w] from band buffer f and
-// writes out + f*out_facet_stride + w*out_wave_stride through row map  rowmaps + w*rowmap_stride  (or none).
-static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
-                                      int64_t in_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
-                                      int64_t band_start, int64_t band_len, int64_t nwaves, const int64_t* wave_off1s,
-                                      void* out, int64_t out_row_stride, int64_t out_facet_stride,
-                                      int64_t out_wave_stride, const int32_t* rowmaps, int64_t rowmap_stride,
-                                      void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
-    if (!h || !in || !out || !facet_off0s || !wave_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: complex64 only");
-    const int yN = (int)h->yN, m = (int)h->m;
-    if (h->log_yN < 0 || h->log_m < 6) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: sizes not supported");
-    if (rows <= 0 || rows >= yN) return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1]", (long long)rows);
-    if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
-    if (nfacets <= 0 || nwaves <= 0) return 0;
-    // only `rows` input rows are ever read (the rest of the padded axis is zero fill)
-    if ((uint64_t)rows * (uint64_t)in_row_stride >= (uint64_t(1) << 32) || (uint64_t)yN * (uint64_t)out_row_stride >= (uint64_t(1) << 32))
-        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
-    const int lo = yN / 2 - (int)(rows / 2);
-    ColPassArgs c;
-    std::memset(&c, 0, sizeof c);
-    c.ncols = m;
-    c.full_logn = h->log_yN;
-    c.in_pitch = (unsigned)in_row_stride;
-    c.out_pitch = (unsigned)out_row_stride;
-    c.ld_mul = c.st_mul = 1;
-    c.ld_a = 0; c.ld_len = (int)rows; c.ld_c = 0; c.ld_mod = (int)rows;  // window already applied by prepare_facet_band
-    c.st_a = 0; c.st_len = yN; c.st_c = 0; c.st_mod = yN;
-    c.scale = (float)(1.0 / yN);
-    c.conj_ld = c.conj_st = 1;
-    c.cg_mod = m; c.cg_full = yN;
-    c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = band_half_of(h, band_len);
-    // tuning knob: facets per launch group (both passes of a group run back to back)
-    static const int per_env = getenv("SWIFTLY_K2_FACETS") ? atoi(getenv("SWIFTLY_K2_FACETS")) : kColZF;
-    const int per_f = std::max(1, std::min(per_env, (int)kColZF));
-    // keep the four-step scratch of one launch group below ~4 GB
-    const int64_t group_cap = ws ? (int64_t)ws_bytes : (int64_t(4) << 30);
-    const int64_t per_w_cap = std::max<int64_t>(1, group_cap / ((int64_t)yN * m * 8) / std::min<int64_t>(per_f, nfacets));
-    const int per_w = (int)std::min<int64_t>(kColZB, per_w_cap);
-    for (int64_t f0 = 0; f0 < nfacets; f0 += per_f) {
-        const int nf = (int)std::min<int64_t>(per_f, nfacets - f0);
-        for (int64_t w0 = 0; w0 < nwaves; w0 += per_w) {
-            const int nw = (int)std::min<int64_t>(per_w, nwaves - w0);
-            ColZ cz = plain_colz();
-            cz.flags = kZColGather | kZLoadAF;
-            cz.nb = nw;
-            for (int w = 0; w < nw; w++) {
-                const int64_t s = floordiv(wave_off1s[w0 + w] * h->yN, h->N);
-                cz.b_rot[w] = pmod(-s, m);
-                cz.b_base[w] = pmod(yN / 2 - m / 2 + s, yN);
-            }
-            for (int f = 0; f < nf; f++) cz.f_lda[f] = pmod(-(facet_off0s[f0 + f] + lo), yN);
-            // item z = f*nw + w reads band buffer f, writes out[f][w]
-            c.in = (const cx<float>*)in + f0 * in_facet_stride;
-            c.in_bdiv = nw; c.in_bs_hi = in_facet_stride; c.in_bs = 0;
-            c.out = (cx<float>*)out + f0 * out_facet_stride + w0 * out_wave_stride;
-            c.out_bdiv = nw; c.out_bs_hi = out_facet_stride; c.out_bs = out_wave_stride;
-            c.st_rowmap = rowmaps ? rowmaps + w0 * rowmap_stride : nullptr;
-            c.st_rowmap_bs = rowmaps ? rowmap_stride : 0;
-            const int rc = col_transform(h, h->log_yN, c, cz, m, nf * nw, (hipStream_t)stream, ws, ws_bytes);
-            if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: padded facet size %d not supported", yN);
-            if (rc) return rc;
-        }
-    }
-    return 0;
-}
-
-extern "C" {
-
-int swiftly_hip_prepare_facet_columns(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
-                                      int64_t in_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
-                                      int64_t band_start, int64_t band_len, int64_t subgrid_off1, void* out,
-                                      int64_t out_row_stride, int64_t out_facet_stride, const int32_t* out_rowmap,
-                                      void* stream) {
-    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    return prepare_facet_columns_impl(h, dtype, in, rows, in_row_stride, in_facet_stride, nfacets, facet_off0s, band_start,
-                                      band_len, 1, &subgrid_off1, out, out_row_stride, out_facet_stride, 0, out_rowmap, 0,
-                                      stream);
-}
-
-int swiftly_hip_prepare_facet_columns_waves(swiftly_hip_t* h, int dtype, const void* in, int64_t rows,
-                                            int64_t in_row_stride, int64_t in_facet_stride, int64_t nfacets,
-                                            const int64_t* facet_off0s, int64_t band_start, int64_t band_len,
-                                            int64_t nwaves, const int64_t* wave_off1s, void* out, int64_t out_row_stride,
-                                            int64_t out_facet_stride, int64_t out_wave_stride, const int32_t* rowmaps,
-                                            int64_t rowmap_stride, void* workspace, int64_t workspace_bytes,
-                                            void* stream) {
-    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    return prepare_facet_columns_impl(h, dtype, in, rows, in_row_stride, in_facet_stride, nfacets, facet_off0s, band_start,
-                                      band_len, nwaves, wave_off1s, out, out_row_stride, out_facet_stride, out_wave_stride,
-                                      rowmaps, rowmap_stride, stream, workspace, workspace ? (size_t)workspace_bytes : 0);
-}
-
-} // extern "C" (helper follows)
-// out_offs / out_fstrides (optional, per subgrid): item (f, b) is written at out + out_offs[b] + f*out_fstrides[b]
-// instead of out + f*out_facet_stride + b*out_sub_stride
-static int transform_contributions_impl(swiftly_hip_t* h, int dtype, const void* in, int layout, int64_t in_row_stride,
-                                        int64_t in_facet_stride, int64_t in_sub_stride, const int32_t* in_rowmap,
-                                        int64_t band_start, int64_t band_len, int64_t nfacets,
-                                        const int64_t* facet_off0s, int64_t nsub, const int64_t* subgrid_offs,
-                                        void* out, int64_t out_facet_stride, int64_t out_sub_stride,
-                                        const int64_t* out_offs, const int64_t* out_fstrides, void* stream) {
-    if (!h || !in || !out || !facet_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "transform_contributions: complex64 only");
-    if (layout < 0 || layout > 2) return fail(SWIFTLY_ERR_PARAM, "bad layout %d", layout);
-    if (layout != 2 && !subgrid_offs) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    const int m = (int)h->m, yN = (int)h->yN;
-    if (h->log_m < kColPassMinLog || h->log_m > kColPassMaxLog || h->log_yN < 0)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "transform_contributions: contribution size %d not supported", m);
-    if (nfacets <= 0 || nsub <= 0) return 0;
-    if ((uint64_t)yN * (uint64_t)in_row_stride + (uint64_t)yN >= (uint64_t(1) << 32))
-        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
-    ColPassArgs c;
-    std::memset(&c, 0, sizeof c);
-    c.ncols = m;
-    c.full_logn = h->log_m;
-    c.in_pitch = (unsigned)in_row_stride;
-    c.out_pitch = (unsigned)m;
-    c.ld_mul = c.st_mul = 1;
-    c.ld_a = 0; c.ld_len = m; c.ld_c = 0; c.ld_mod = m;
-    c.st_a = 0; c.st_len = m; c.st_c = 0; c.st_mod = m;   // no placement: out[k] = Fn[k] * F[(k + s') mod m]
-    c.st_win = h->fn_f;
-    c.scale = 1.f;
-    c.tw = twiddles<float>(h, h->log_m);
-    if (!c.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table");
-    if (layout == 0) {  // in[f] = [m, yN] column buffers: window gather along the contiguous axis
-        c.cg_mod = m; c.cg_full = yN;
-        c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = band_half_of(h, band_len);
-    } else if (layout == 1) {  // in[f] = [kept rows of yN, m]: window gather along the strided axis
-        c.ld_mod = yN;
-        c.ld_rowmap = in_rowmap;
-    }
-    for (int64_t f0 = 0; f0 < nfacets; f0 += kColZF) {
-        const int nf = (int)std::min<int64_t>(kColZF, nfacets - f0);
-        for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
-            const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
-            ColZ cz = plain_colz();
-            cz.nb = nb;
-            cz.flags = kZStoreAF;
-            for (int f = 0; f < nf; f++) cz.f_sta[f] = pmod(-floordiv(facet_off0s[f0 + f] * h->xM, h->N), m);
-            for (int b = 0; b < nb && layout != 2; b++) {
-                const int64_t s = floordiv(subgrid_offs[b0 + b] * h->yN, h->N);
-                if (layout == 0) {
-                    cz.b_rot[b] = pmod(-s, m);
-                    cz.b_base[b] = pmod(yN / 2 - m / 2 + s, yN);
-                } else {
-                    cz.b_lda[b] = pmod(-s, m);
-                    cz.b_ldc[b] = pmod(yN / 2 - m / 2 + s, yN);
-                }
-            }
-            if (layout == 0) cz.flags |= kZColGather;
-            if (layout == 1) cz.flags |= kZLoadB;
-            // item z = f*nb + b reads in + f*in_facet_stride (+ b*in_sub_stride for layout 2), writes out[f][b]
-            c.in = (const cx<float>*)in + f0 * in_facet_stride + (layout == 2 ? b0 * in_sub_stride : 0);
-            c.in_bdiv = nb; c.in_bs_hi = in_facet_stride; c.in_bs = layout == 2 ? in_sub_stride : 0;
-            c.out = (cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
-            c.out_bdiv = nb; c.out_bs_hi = out_facet_stride; c.out_bs = out_sub_stride;
-            if (out_offs) {
-                cz.flags |= kZOutB;
-                c.out = (cx<float>*)out;
-                for (int b = 0; b < nb; b++) {
-                    cz.b_out_fs[b] = out_fstrides[b0 + b];
-                    cz.b_out_off[b] = out_offs[b0 + b] + f0 * out_fstrides[b0 + b];
-                }
-            }
-            if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, nf * nb, (hipStream_t)stream)) return rc;
-        }
-    }
-    return 0;
-}
-
-extern "C" {
-int swiftly_hip_transform_contributions(swiftly_hip_t* h, int dtype, const void* in, int layout, int64_t in_row_stride,
-                                        int64_t in_facet_stride, int64_t in_sub_stride, const int32_t* in_rowmap,
-                                        int64_t band_start, int64_t band_len, int64_t nfacets,
-                                        const int64_t* facet_off0s, int64_t nsub, const int64_t* subgrid_offs,
-                                        void* out, int64_t out_facet_stride, int64_t out_sub_stride, void* stream) {
-    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    return transform_contributions_impl(h, dtype, in, layout, in_row_stride, in_facet_stride, in_sub_stride, in_rowmap,
-                                        band_start, band_len, nfacets, facet_off0s, nsub, subgrid_offs, out,
-                                        out_facet_stride, out_sub_stride, nullptr, nullptr, stream);
-}
-
-int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t nfacets, int64_t in_facet_stride,
-                                  int64_t in_sub_stride, int64_t in_row_stride, const int64_t* facet_off0s,
-                                  const int64_t* facet_off1s, void* out, int64_t out_sub_stride, int64_t out_row_stride,
-                                  const int64_t* subgrid_off1s, int64_t subgrid_size, const void* mask,
-                                  int64_t mask_batch_stride, int64_t nsub, void* stream) {
-    if (!h || !in || !out || !facet_off0s || !facet_off1s || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    CHECK_SUBGRID_SIZE();
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_facets: complex64 only");
-    if (nfacets <= 0 || nfacets > kSumFinishMaxFacets)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_facets: 1..%d facets supported", kSumFinishMaxFacets);
-    if (!sum_finish_supported(h->log_m, h->log_xM))
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_facets: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
-                    (long long)h->xM);
-    if (nsub <= 0) return 0;
-    const int xM = (int)h->xM, xA = (int)subgrid_size, m = (int)h->m;
-    SumFinishFacetArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.in_fs = in_facet_stride; a.in_bs = in_sub_stride; a.in_rs = in_row_stride;
-    a.out_bs = out_sub_stride; a.out_rs = out_row_stride;
-    a.nrows = xM;
-    a.nfacets = (int)nfacets;
-    a.xA = xA;
-    for (int f = 0; f < nfacets; f++) {
-        const int sp0 = (int)floordiv(facet_off0s[f] * h->xM, h->N);
-        a.base0[f] = pmod(xM / 2 - m / 2 + sp0, xM);  // first padded-subgrid row facet f contributes to
-        a.sp1[f] = (int)floordiv(facet_off1s[f] * h->xM, h->N);
-    }
-    a.fn = h->fn_f;
-    a.mask_bs = mask ? mask_batch_stride : 0;
-    a.tw_m = twiddles<float>(h, h->log_m);
-    a.tw_x = twiddles<float>(h, h->log_xM);
-    if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    for (int64_t b0 = 0; b0 < nsub; b0 += kSumFinishMaxBatch) {
-        const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nsub - b0);
-        a.in = (const cx<float>*)in + b0 * in_sub_stride;
-        a.out = (cx<float>*)out + b0 * out_sub_stride;
-        a.mask = mask ? (const float*)mask + b0 * mask_batch_stride : nullptr;
-        for (int b = 0; b < nb; b++) a.st_a[b] = pmod(-(xM / 2 - xA / 2 + subgrid_off1s[b0 + b]), xM);
-        int e = launch_sum_finish_facets(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
-        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    }
-    return 0;
-}
-
-/* Backward subgrid side, contiguous-axis half + axis-0 remainder (see swiftly_sumfinish.h): in[b] = [xM, xA] =
- * prepare_subgrid(axis 0) of subgrid b; out[f][b] = [m, m] = the contribution of subgrid b to facet f
- * (api_helper.prepare_and_split_subgrid, api_helper.py:115-139). */
-int swiftly_hip_split_prepare_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t in_sub_stride,
-                                     int64_t in_row_stride, int64_t subgrid_size, int64_t nsub,
-                                     const int64_t* subgrid_off1s, int64_t nfacets, const int64_t* facet_off0s,
-                                     const int64_t* facet_off1s, void* out, int64_t out_facet_stride,
-                                     int64_t out_sub_stride, void* stream) {
-    if (!h || !in || !out || !facet_off0s || !facet_off1s || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    CHECK_SUBGRID_SIZE();
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "split_prepare_facets: complex64 only");
-    if (nfacets <= 0 || nfacets > kSumFinishMaxFacets)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "split_prepare_facets: 1..%d facets supported", kSumFinishMaxFacets);
-    if (!sum_finish_supported(h->log_m, h->log_xM) || h->log_m > kColPassMaxLog)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "split_prepare_facets: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
-                    (long long)h->xM);
-    if (nsub <= 0) return 0;
-    const int xM = (int)h->xM, xA = (int)subgrid_size, m = (int)h->m;
-    SplitFacetArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.in_bs = in_sub_stride; a.in_rs = in_row_stride;
-    a.out_fs = out_facet_stride; a.out_bs = out_sub_stride; a.out_rs = m;
-    a.nrows = xM;
-    a.nfacets = (int)nfacets;
-    a.xA = xA;
-    for (int f = 0; f < nfacets; f++) {
-        const int sp0 = (int)floordiv(facet_off0s[f] * h->xM, h->N);
-        a.base0[f] = pmod(xM / 2 - m / 2 + sp0, xM);
-        a.sp1[f] = (int)floordiv(facet_off1s[f] * h->xM, h->N);
-    }
-    a.fn = h->fn_f;
-    a.tw_m = twiddles<float>(h, h->log_m);
-    a.tw_x = twiddles<float>(h, h->log_xM);
-    if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    for (int64_t b0 = 0; b0 < nsub; b0 += kSumFinishMaxBatch) {
-        const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nsub - b0);
-        a.in = (const cx<float>*)in + b0 * in_sub_stride;
-        a.out = (cx<float>*)out + b0 * out_sub_stride;
-        for (int b = 0; b < nb; b++) a.ld_a[b] = pmod(-(xM / 2 - xA / 2 + subgrid_off1s[b0 + b]), xM);
-        int e = launch_split_prepare_facets(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
-        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    }
-    // axis-0 remainder of extract_from_subgrid, in place: out[f][b][:, j] = cifft_m( Fn[k] * E[f][b][(k - s'0_f) ..., j] )
-    ColPassArgs c;
-    std::memset(&c, 0, sizeof c);
-    c.ncols = m;
-    c.full_logn = h->log_m;
-    c.in_pitch = c.out_pitch = (unsigned)m;
-    c.ld_mul = c.st_mul = 1;
-    c.ld_a = 0; c.ld_len = m; c.ld_c = 0; c.ld_mod = m;
-    c.ld_win = h->fn_f;
-    c.st_a = 0; c.st_len = m; c.st_c = 0; c.st_mod = m;
-    c.conj_ld = c.conj_st = 1;
-    c.scale = 1.f / (float)m;
-    c.tw = a.tw_m;
-    for (int64_t f0 = 0; f0 < nfacets; f0 += kColZF) {
-        const int nf = (int)std::min<int64_t>(kColZF, nfacets - f0);
-        for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
-            const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
-            ColZ cz = plain_colz();
-            cz.nb = nb;
-            cz.flags = kZLoadAF;
-            for (int f = 0; f < nf; f++) cz.f_lda[f] = pmod(-floordiv(facet_off0s[f0 + f] * h->xM, h->N), m);
-            c.in = (const cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
-            c.in_bdiv = nb; c.in_bs_hi = out_facet_stride; c.in_bs = out_sub_stride;
-            c.out = (cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
-            c.out_bdiv = nb; c.out_bs_hi = out_facet_stride; c.out_bs = out_sub_stride;
-            if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, nf * nb, (hipStream_t)stream)) return rc;
-        }
-    }
-    return 0;
-}
-
-/* The whole subgrid side of one backward wave natively, without stream-ordered allocations: prepare_subgrid along
- * axis 0 (four-step through `work`) + split_prepare_facets.  work: device scratch of >= 2 * nsub * xM * subgrid_size
- * complex64 elements (first half: tmp[nsub][xM][subgrid_size], second half: four-step scratch). */
-int swiftly_hip_wave_split_subgrids(swiftly_hip_t* h, int dtype, const void* subgrids, int64_t subgrid_size, int64_t nsub,
-                                    const int64_t* subgrid_off0s, const int64_t* subgrid_off1s, int64_t nfacets,
-                                    const int64_t* facet_off0s, const int64_t* facet_off1s, void* work,
-                                    int64_t work_elems, void* out, int64_t out_facet_stride, int64_t out_sub_stride,
-                                    void* stream) {
-    if (!h || !subgrids || !work || !out || !subgrid_off0s || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    CHECK_SUBGRID_SIZE();
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_split_subgrids: complex64 only");
-    if (nsub <= 0 || nfacets <= 0) return 0;
-    const int xM = (int)h->xM, xA = (int)subgrid_size;
-    const int64_t half = nsub * (int64_t)xM * xA;
-    if (work_elems < 2 * half) return fail(SWIFTLY_ERR_PARAM, "work holds %lld elements, %lld needed", (long long)work_elems, (long long)(2 * half));
-    cx<float>* tmp = (cx<float>*)work;
-    ColPassArgs c;
-    std::memset(&c, 0, sizeof c);
-    c.ncols = xA;
-    c.full_logn = h->log_xM;
-    c.in_pitch = c.out_pitch = (unsigned)xA;
-    c.ld_mul = c.st_mul = 1;
-    c.ld_a = 0; c.ld_len = xA; c.ld_c = 0; c.ld_mod = xA;
-    c.st_a = 0; c.st_len = xM; c.st_c = 0; c.st_mod = xM;
-    c.scale = 1.f;
-    for (int64_t b0 = 0; b0 < nsub; b0 += kColZB) {
-        const int nb = (int)std::min<int64_t>(kColZB, nsub - b0);
-        ColZ cz = plain_colz();
-        cz.nb = nb;
-        cz.flags = kZLoadB;
-        for (int b = 0; b < nb; b++) {
-            cz.b_lda[b] = pmod(-(xM / 2 - xA / 2 + subgrid_off0s[b0 + b]), xM);
-            cz.b_ldc[b] = 0;
-        }
-        c.in = (const cx<float>*)subgrids + b0 * (int64_t)xA * xA;
-        c.in_bs = (long long)xA * xA;
-        c.out = tmp + b0 * (int64_t)xM * xA;
-        c.out_bs = (long long)xM * xA;
-        const int rc = col_transform(h, h->log_xM, c, cz, xA, nb, (hipStream_t)stream, tmp + half, (size_t)half * sizeof(cx<float>));
-        if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_split_subgrids: padded subgrid size %d not supported", xM);
-        if (rc) return rc;
-    }
-    return swiftly_hip_split_prepare_facets(h, dtype, tmp, (int64_t)xM * xA, xA, subgrid_size, nsub, subgrid_off1s, nfacets,
-                                            facet_off0s, facet_off1s, out, out_facet_stride, out_sub_stride, stream);
-}
-
-
-/* One forward wave in two calls (the whole launch sequence runs natively: per-wave host work is two ABI calls). */
-int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
-                                int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
-                                int64_t band_start, int64_t band_len, int64_t wave_off1, const int32_t* rowmap,
-                                int64_t n_rows, void* q_work, int64_t q_facet_stride, int compute_q, int64_t nsub,
-                                const int64_t* sub_off0s, void* g_out,
-                                int64_t g_facet_stride, int64_t g_sub_stride, const int64_t* g_offsets,
-                                const int64_t* g_facet_strides, void* scratch, int64_t scratch_bytes, void* stream) {
-    if (!h || (!bands && compute_q) || !q_work || !g_out || !facet_off0s || !sub_off0s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    if (nfacets <= 0 || nsub <= 0) return 0;
-    const int64_t m = h->m;
-    if (n_rows <= 0 || n_rows > h->yN || q_facet_stride < n_rows * m)
-        return fail(SWIFTLY_ERR_PARAM, "bad row count %lld / facet stride %lld", (long long)n_rows, (long long)q_facet_stride);
-    // K2: Q[f] = [n_rows, m] (skipped when the caller still holds the wave's Q: compute_q = 0)
-    DeviceGuard device_guard_(h->device);
-    if (compute_q) {
-        int rc = prepare_facet_columns_impl(h, dtype, bands, rows, band_row_stride, band_facet_stride, nfacets, facet_off0s,
-                                            band_start, band_len, 1, &wave_off1, q_work, m, q_facet_stride, 0, rowmap, 0,
-                                            stream, scratch, scratch ? (size_t)scratch_bytes : 0);
-        if (rc) return rc;
-    }
-    // K3 + K4a from Q (layout 1)
-    return transform_contributions_impl(h, dtype, q_work, 1, m, q_facet_stride, 0, rowmap, 0, 0, nfacets, facet_off0s, nsub,
-                                        sub_off0s, g_out, g_facet_stride, g_sub_stride, g_offsets, g_facet_strides, stream);
-}
-
-int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
-                                  int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
-                                  int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
-                                  const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
-                                  void* tmp_work, void* out, void* scratch, int64_t scratch_bytes, void* stream) {
-    if (!h || !g || !tmp_work || !out || !sub_off0s || !sub_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    if (nsub <= 0) return 0;
-    const int64_t m = h->m, xM = h->xM, xA = subgrid_size;
-    // K4b + K5a: tmp[b] = [xM, xA]
-    int rc = swiftly_hip_sum_finish_facets(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, m, facet_off0s, facet_off1s,
-                                           tmp_work, xM * xA, xA, sub_off1s, subgrid_size, mask1, mask1_bs, nsub, stream);
-    if (rc) return rc;
-    // K5b: finish_subgrid along axis 0 (strided): rows of the op = xA columns
-    CallWorkspace call_ws(scratch, scratch ? (size_t)scratch_bytes : 0);
-    return swiftly_hip_finish_subgrid_batch(h, dtype, tmp_work, xA, 1, xA, out, 1, xA, 0, subgrid_size, mask0, nsub,
-                                            xM * xA, xA * xA, sub_off0s, mask0 ? mask0_bs : 0, stream);
-}
-
 int swiftly_hip_finish_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
                                   int64_t band_start, int64_t band_len, void* out, int64_t out_row_stride,
                                   int64_t facet_off, int64_t facet_size, const void* mask, void* stream) {
@@ -1855,137 +1168,5 @@ int swiftly_hip_finish_facet_band(swiftly_hip_t* h, int dtype, const void* in, i
                     mask, bt, (hipStream_t)stream, band_start, band_len);
 }
 
-int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void* parts, int64_t part_row_stride,
-                                         int64_t nchunks, const int64_t* chunk_offsets,
-                                         const int64_t* chunk_facet_strides, const int32_t* row_sources,
-                                         int64_t nfacets, const int64_t* facet_off0s, int64_t facet_size,
-                                         const float* masks, int64_t subgrid_off1, void* bands, int64_t band_row_stride,
-                                         int64_t band_facet_stride, int64_t band_start, int64_t band_len,
-                                         unsigned char* touched, void* workspace, int64_t workspace_bytes,
-                                         void* stream) {
-    if (!h || !parts || !bands || !chunk_offsets || !chunk_facet_strides || !row_sources || !facet_off0s)
-        return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: complex64 only");
-    CHECK_FACET_SIZE();
-    const int yN = (int)h->yN, m = (int)h->m;
-    if (h->log_yN < 0 || h->log_m < 0 || h->log_yN > 18)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: sizes not supported (powers of two)");
-    if (nchunks <= 0 || nchunks > kColZC) return fail(SWIFTLY_ERR_PARAM, "1..%d source chunks", kColZC);
-    if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
-    if (nfacets <= 0) return 0;
-    if ((uint64_t)facet_size * (uint64_t)band_row_stride >= (uint64_t(1) << 32) ||
-        (uint64_t)part_row_stride << kGsRowBits >= (uint64_t(1) << 32))
-        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
-    const int lo = yN / 2 - (int)(facet_size / 2);
-    ColPassArgs c;
-    std::memset(&c, 0, sizeof c);
-    c.ncols = m;
-    c.full_logn = h->log_yN;
-    c.in = (const cx<float>*)parts;
-    c.in_pitch = (unsigned)part_row_stride;
-    c.out_pitch = (unsigned)band_row_stride;
-    c.ld_mul = c.st_mul = 1;
-    c.ld_a = 0; c.ld_len = yN; c.ld_c = 0; c.ld_mod = yN;
-    c.ld_rowmap = row_sources; c.gs = 1;
-    c.st_a = 0; c.st_len = (int)facet_size; c.st_c = 0; c.st_mod = (int)facet_size;
-    c.st_win = masks; c.st_win_bs = masks ? facet_size : 0;
-    c.st_win2 = h->invp_f + lo;
-    c.scale = 1.f;
-    c.accumulate = 1;
-    c.touched = touched;
-    c.cg_mod = m; c.cg_full = yN;
-    c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = 0;
-    const int64_t cap = workspace ? workspace_bytes : (int64_t(4) << 30);
-    const int per_f = (int)std::max<int64_t>(1, std::min<int64_t>(kColZF, cap / ((int64_t)yN * m * 8)));
-    const int64_t s1 = floordiv(subgrid_off1 * h->yN, h->N);
-    for (int64_t f0 = 0; f0 < nfacets; f0 += per_f) {
-        const int nf = (int)std::min<int64_t>(per_f, nfacets - f0);
-        ColZ cz = plain_colz();
-        cz.flags = kZColScatter | kZStoreAF;
-        cz.nb = 1;
-        cz.b_rot[0] = pmod(-s1, m);
-        cz.b_base[0] = pmod(yN / 2 - m / 2 + s1, yN);
-        for (int f = 0; f < nf; f++) cz.f_sta[f] = pmod(-(lo + facet_off0s[f0 + f]), yN);
-        for (int k = 0; k < nchunks; k++) {
-            cz.c_base[k] = chunk_offsets[k] + f0 * chunk_facet_strides[k];
-            cz.c_fs[k] = chunk_facet_strides[k];
-        }
-        c.out = (cx<float>*)bands + f0 * band_facet_stride;
-        c.out_bs = band_facet_stride;
-        if (masks) c.st_win = masks + f0 * facet_size;
-        const int rc = col_transform(h, h->log_yN, c, cz, m, nf, (hipStream_t)stream, workspace,
-                                     workspace ? (size_t)workspace_bytes : 0);
-        if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: padded facet size %d not supported", yN);
-        if (rc) return rc;
-    }
-    if (touched) {
-        hipLaunchKernelGGL(mark_columns_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, touched,
-                           m, pmod(-s1, m), pmod(yN / 2 - m / 2 + s1, yN), yN, (int)band_start, (int)band_len);
-        HIP_TRY(hipGetLastError());
-    }
-    return 0;
-}
-
-int swiftly_hip_band_zero_untouched(swiftly_hip_t* h, int dtype, void* bands, int64_t rows, int64_t band_row_stride,
-                                    int64_t band_len, const unsigned char* touched, void* stream) {
-    if (!h || !bands || !touched) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "band_zero_untouched: complex64 only");
-    if (rows <= 0 || band_len <= 0) return 0;
-    dim3 grid((unsigned)((band_len + 63) / 64), (unsigned)std::min<int64_t>(rows, 1024));
-    hipLaunchKernelGGL(zero_untouched_kernel, grid, dim3(64), 0, (hipStream_t)stream, (cx<float>*)bands, touched,
-                       (long long)rows, (long long)band_row_stride, (int)band_len);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int swiftly_hip_debug_row_band_occupancy(void) { return swf::row_pass_band_occupancy(); }
-
-int swiftly_hip_debug_occupancy(int lds_bytes) { return swf::row_pass_half_occupancy(lds_bytes); }
-
-int swiftly_hip_malloc(void** ptr, size_t bytes) {
-    if (!ptr) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    HIP_TRY(hipMalloc(ptr, bytes));
-    return 0;
-}
-int swiftly_hip_free(void* ptr) {
-    HIP_TRY(hipFree(ptr));
-    return 0;
-}
-int swiftly_hip_memset_async(void* ptr, int value, size_t bytes, void* stream) {
-    HIP_TRY(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
-    return 0;
-}
-int swiftly_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
-    return 0;
-}
-int swiftly_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    return 0;
-}
-int swiftly_hip_stream_synchronize(void* stream) {
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return 0;
-}
-
-int swiftly_hip_stream_create_cu_mask(void** stream, const uint32_t* cu_mask, int nwords) {
-    if (!stream || !cu_mask || nwords <= 0) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    hipStream_t st = nullptr;
-    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, cu_mask));
-    *stream = (void*)st;
-    return 0;
-}
-int swiftly_hip_stream_destroy(void* stream) {
-    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
-    return 0;
-}
-int swiftly_hip_cu_census(int32_t* out, int nblocks, void* stream) {
-    if (!out || nblocks <= 0) return fail(SWIFTLY_ERR_PARAM, "null argument");
-    hipLaunchKernelGGL(cu_census_kernel, dim3((unsigned)nblocks), dim3(64), 0, (hipStream_t)stream, out);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
 
 }  // extern "C"

@@ -1,0 +1,172 @@
+// Internals shared by the translation units of the C ABI (swiftly_abi.hip: handles + the eight primitives and their
+// batch forms; swiftly_abi_pipeline.hip: the fused / per-wave entry points of the streaming classes;
+// swiftly_abi_util.hip: device memory, stream and diagnostic helpers).  Not installed: include/swiftly_hip.h is the
+// public header.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/swiftly_hip.h"
+#include "swiftly_colpass.h"
+#include "swiftly_rowpass.h"
+#include "swiftly_sumfinish.h"
+#include "swiftly_rows.h"
+#include "swiftly_bluestein.h"
+#include <complex>
+
+using namespace swf;
+
+// ---------------------------------------------------------------------------
+// error state: integer status + thread-local message (swiftly_hip_last_error)
+int fail(int code, const char* fmt, ...);
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(SWIFTLY_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int64_t floordiv(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+    return q;
+}
+static inline int pmod(int64_t a, int64_t n) {
+    int64_t r = a % n;
+    if (r < 0) r += n;
+    return (int)r;
+}
+static inline int ilog2_exact(int64_t n) {
+    if (n <= 0 || (n & (n - 1))) return -1;
+    int l = 0;
+    while ((int64_t(1) << l) < n) l++;
+    return l;
+}
+
+struct swiftly_hip {
+    int64_t N, yN, xM, m;
+    double W;
+    int device;
+    int log_yN, log_xM, log_m;  // -1 when not a power of two
+    float* invp_f = nullptr;    // 1/pswf[k] (k = 0 -> 0)
+    double* invp_d = nullptr;
+    float* fn_f = nullptr;  // Fn[k], k < m
+    double* fn_d = nullptr;
+    std::map<int, cx<float>*> tw_f;  // by log2(length)
+    std::map<int, cx<double>*> tw_d;
+    // Bluestein tables for transform lengths that are not a power of two (swiftly_bluestein.h), by length
+    struct Blu {
+        int logL = 0;
+        cx<float>* chirp_f = nullptr;
+        cx<float>* spec_f = nullptr;
+        cx<double>* chirp_d = nullptr;
+        cx<double>* spec_d = nullptr;
+    };
+    std::map<int64_t, Blu> blu;
+    std::vector<void*> allocs;
+};
+
+template <typename R>
+inline const cx<R>* twiddles(const swiftly_hip* h, int logn);
+template <>
+inline const cx<float>* twiddles<float>(const swiftly_hip* h, int logn) {
+    auto it = h->tw_f.find(logn);
+    return it == h->tw_f.end() ? nullptr : it->second;
+}
+template <>
+inline const cx<double>* twiddles<double>(const swiftly_hip* h, int logn) {
+    auto it = h->tw_d.find(logn);
+    return it == h->tw_d.end() ? nullptr : it->second;
+}
+template <typename R>
+inline const R* invp(const swiftly_hip* h);
+template <>
+inline const float* invp<float>(const swiftly_hip* h) { return h->invp_f; }
+template <>
+inline const double* invp<double>(const swiftly_hip* h) { return h->invp_d; }
+template <typename R>
+inline const R* fnwin(const swiftly_hip* h);
+template <>
+inline const float* fnwin<float>(const swiftly_hip* h) { return h->fn_f; }
+template <>
+inline const double* fnwin<double>(const swiftly_hip* h) { return h->fn_d; }
+// RAII: make `device` current for the duration of one ABI call and restore the caller's (torch's) current
+// device afterwards.  Streams handed in by the caller belong to the handle's device.
+struct DeviceGuard {
+    int prev = -1, rc = 0;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) rc = (int)hipSetDevice(device);
+        else prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+// Transforms of length >= 2^kTwoPassMinLog along a STRIDED axis (rows contiguous) are decomposed into
+// two passes of short transforms so that every access is >= 128 B contiguous.
+static const int kTwoPassMinLog = 9;
+
+// column-tile passes (swiftly_abi.hip)
+ColZ plain_colz();
+int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz, int outer, int nb, hipStream_t st);
+// scratch handed down by an entry point for the duration of one ABI call on this host thread (see col_transform)
+extern thread_local void* t_call_ws;
+extern thread_local size_t t_call_ws_bytes;
+struct CallWorkspace {
+    CallWorkspace(void* p, size_t bytes) { t_call_ws = p; t_call_ws_bytes = p ? bytes : 0; }
+    ~CallWorkspace() { t_call_ws = nullptr; t_call_ws_bytes = 0; }
+};
+int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st,
+                  void* ws = nullptr, size_t ws_bytes = 0);
+
+#define CHECK_COMMON()                                                                       \
+    if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");                  \
+    DeviceGuard device_guard_(h->device);                                                    \
+    if (device_guard_.rc) return fail(SWIFTLY_ERR_HIP, "hipSetDevice(%d) failed", h->device); \
+    if (rows < 0) return fail(SWIFTLY_ERR_PARAM, "negative row count");                      \
+    if (dtype != SWIFTLY_C64 && dtype != SWIFTLY_C128) return fail(SWIFTLY_ERR_PARAM, "bad dtype %d", dtype); \
+    if (in_cs < 0 || out_cs < 0 || in_cs >= (int64_t(1) << 32) || out_cs >= (int64_t(1) << 32)) \
+        return fail(SWIFTLY_ERR_PARAM, "column strides must be in [0, 2^32)");                 \
+    if (rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "too many rows");
+#define CHECK_BATCH()                                                                        \
+    if (nbatch < 0 || in_bs < 0 || out_bs < 0) return fail(SWIFTLY_ERR_PARAM, "bad batch description");
+// The accumulating entry points read-modify-write their output non-atomically and run the batch items
+// concurrently: items that share output elements would lose updates.
+#define CHECK_ACCUMULATE_BATCH()                                                             \
+    if (nbatch > 1 && out_bs == 0)                                                           \
+        return fail(SWIFTLY_ERR_PARAM, "accumulating batch items must not share output elements (out_batch_stride = 0)");
+
+#define DISPATCH(fn, ...) (dtype == SWIFTLY_C64 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
+#define CHECK_FACET_SIZE()                                                                                     \
+    if (facet_size <= 0 || facet_size >= h->yN)                                                                \
+        return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1 = %lld]", (long long)facet_size, \
+                    (long long)(h->yN - 1));
+#define CHECK_SUBGRID_SIZE()                                                                                      \
+    if (subgrid_size <= 0 || subgrid_size > h->xM)                                                                \
+        return fail(SWIFTLY_ERR_PARAM, "subgrid size %lld must be in [1, xM_size = %lld]", (long long)subgrid_size, \
+                    (long long)h->xM);
+
+
+// ---------------------------------------------------------------------------------------------------------
+// band buffers of the contiguous-axis-first pipeline
+// half of a parity-split band buffer, in columns: a multiple of 16 (128 bytes) so that BOTH parity runs of a 64-column
+// tile of the column pass start on a cache line (r2: (band_len + 1) / 2 = 5736 left every odd run 64 bytes off a line:
+// 5 lines fetched per 4 lines' worth, FETCH_SIZE of K2 pass A 1.04 GB per wave against 0.83 GB)
+static inline int64_t band_half_columns(int64_t band_len) { return (((band_len + 1) / 2) + 15) & ~int64_t(15); }
+// Band layout of a handle: parity-split where the two-workgroup long-row kernel produces the band (yN >= 16384), else
+// PLAIN (half = 0: logical column d of the band at physical column d; K1 is the generic contiguous-axis transform and
+// keeps the whole padded axis).
+static inline bool band_is_split(const swiftly_hip* h) { return h->log_yN >= 14 && h->log_yN <= 16; }
+static inline int band_half_of(const swiftly_hip* h, int64_t band_len) {
+    return band_is_split(h) ? (int)band_half_columns(band_len) : 0;
+}

@@ -51,7 +51,10 @@ struct SFGeo {
     // workgroup-uniform facet loop allows.
     static constexpr int LOGTR = LOGX >= 12 ? 8 : 6;
     static constexpr int TR = 1 << LOGTR;
-    static constexpr int NT = SWF_SF_NT;
+    // threads per workgroup.  2048-point rows (21.7 KB of LDS per row): ONE row per workgroup so that seven rows fit
+    // a CU (four rows per workgroup = 87 KB = one workgroup of four waves per CU: measured r3 on the N = 8192
+    // workload, 485 us per wave of 8 subgrids); 4096-point rows: the row IS the workgroup (four waves)
+    static constexpr int NT = LOGX >= 12 ? 256 : (LOGX == 11 ? 64 : SWF_SF_NT);
     using GM = Geo<float, LOGM, LOGM - LOGTR, NT, false>;
     using GX = Geo<float, LOGX, LOGX - LOGTR, NT, false>;
     static_assert(LOGM - LOGTR >= 1, "at least two points per lane");
@@ -63,7 +66,7 @@ struct SFGeo {
 };
 
 template <int LOGM, int LOGX>
-__global__ __launch_bounds__(SWF_SF_NT) void sum_finish_rows_kernel(const SumFinishArgs A) {
+__global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_rows_kernel(const SumFinishArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GM = typename S::GM;
     using GX = typename S::GX;
@@ -160,7 +163,7 @@ struct SumFinishFacetArgs {
 };
 
 template <int LOGM, int LOGX>
-__global__ __launch_bounds__(SWF_SF_NT) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
+__global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GM = typename S::GM;
     using GX = typename S::GX;
@@ -287,7 +290,7 @@ struct SplitFacetArgs {
 };
 
 template <int LOGM, int LOGX>
-__global__ __launch_bounds__(SWF_SF_NT) void split_prepare_facets_kernel(const SplitFacetArgs A) {
+__global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_kernel(const SplitFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GM = typename S::GM;
     using GX = typename S::GX;
