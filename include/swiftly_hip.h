@@ -372,6 +372,22 @@ int swiftly_hip_wave_split_subgrids(swiftly_hip_t* h, int dtype, const void* sub
                                     int64_t work_elems, void* out, int64_t out_facet_stride, int64_t out_sub_stride,
                                     void* stream);
 
+/* Forward subgrid side with the axis-0 half finished FIRST (r3; replaces transform_contributions + sum_finish_facets +
+ * finish_subgrid_batch(axis 0) on one GPU): the same reference calls -- extract_from_facet, add_to_subgrid along both
+ * axes, the facet sums and finish_subgrid + masks, api_helper.py:73-112 -- re-associated by facet off1 GROUP so that the
+ * only intermediate is V[g][b] = [subgrid_size, m] per group (finished along axis 0, not yet transformed along axis 1):
+ *   q + f*q_facet_stride = Q_f[rows kept, m] (output of prepare_facet_columns), rowmap as there;
+ *   v_work: device scratch of >= n_groups * nsub * subgrid_size * m complex64 elements (n_groups = distinct facet off1);
+ *   out[b] = finished, masked subgrid [subgrid_size, subgrid_size], contiguous.
+ * Available when swiftly_hip_grouped_subgrid_side_supported(h) != 0 (m < xM <= 1024 with a kernel instance), <= 64 facets. */
+int swiftly_hip_grouped_subgrid_side_supported(const swiftly_hip_t* h);
+int swiftly_hip_wave_subgrid_side_grouped(swiftly_hip_t* h, int dtype, const void* q, int64_t q_row_stride,
+                                          int64_t q_facet_stride, const int32_t* rowmap, int64_t nfacets,
+                                          const int64_t* facet_off0s, const int64_t* facet_off1s, int64_t nsub,
+                                          const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
+                                          const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
+                                          void* v_work, int64_t v_work_elems, void* out, void* stream);
+
 /* Backward pass with the contiguous-axis transform LAST (mirror of prepare_facet_band / prepare_facet_columns;
  * waves = subgrids sharing off1).  Replaces, for all facets of a wave, api_helper.accumulate_column +
  * accumulate_facet (api_helper.py:142-179) with the two axes swapped (they commute):

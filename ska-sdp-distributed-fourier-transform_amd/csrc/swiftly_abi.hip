@@ -172,6 +172,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         if (int rc = init_col_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (col pass): %d", rc);
         if (int rc = init_row_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (row pass): %d", rc);
         if (int rc = init_sum_finish_rows()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (sum finish): %d", rc);
+        if (int rc = init_group_finish()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (group finish): %d", rc);
         // keep freed scratch (the four-step intermediate, up to yN*yB*8 bytes) in the stream-ordered pool instead of
         // returning it to the driver at every synchronisation point
         hipMemPool_t pool;

@@ -20,6 +20,7 @@
 #include "swiftly_colpass.h"
 #include "swiftly_rowpass.h"
 #include "swiftly_sumfinish.h"
+#include "swiftly_groupfinish.h"
 #include "swiftly_rows.h"
 #include "swiftly_bluestein.h"
 #include <complex>

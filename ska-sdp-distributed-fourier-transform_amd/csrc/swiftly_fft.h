@@ -305,7 +305,18 @@ constexpr int lds_delta(int d, bool rowfast) {
 #ifndef SWF_TW_TABLE
 #define SWF_TW_TABLE 0
 #endif
-template <typename R, int LOGR, int NB, int U, int PTOT, int N>
+// geometries may ask for the register-lean twiddle form at every radix (kernels that keep an accumulator in registers
+// next to the transform: swiftly_groupfinish.h): `static constexpr bool LEAN_TW = true`
+template <class G, class = void>
+struct lean_tw_of {
+    static constexpr bool value = false;
+};
+template <class G>
+struct lean_tw_of<G, std::enable_if_t<G::LEAN_TW>> {
+    static constexpr bool value = true;
+};
+
+template <typename R, int LOGR, int NB, int U, int PTOT, int N, bool LEAN = false>
 __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx) {
     constexpr int RAD = 1 << LOGR;
     if constexpr (SWF_TW_TWO_FACTOR && LOGR >= 2) {
@@ -341,7 +352,7 @@ __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __
             constexpr int r = decltype(rI)::value;
             x[U + r * NB] = cmul(x[U + r * NB], tw[(kidx * r) & (N - 1)]);
         });
-    } else if constexpr (LOGR >= 5) {
+    } else if constexpr (LOGR >= 5 || LEAN) {
         // register-lean form: keep only the LOGR table values alive and build
         // each w^r from the set bits of r
         cx<R> wp[LOGR];
@@ -384,7 +395,7 @@ __device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<
             int j = t + u * G::T;
             int k = j & ((1 << LOGNS) - 1);
             // angle = -2 pi k r / (Ns * RAD)  ->  table index k * N/(Ns*RAD) * r
-            twiddle_inputs<R, LOGR, NB, u, G::P, G::N>(x, tw, k << (G::LOGN - LOGNS - LOGR));
+            twiddle_inputs<R, LOGR, NB, u, G::P, G::N, lean_tw_of<G>::value>(x, tw, k << (G::LOGN - LOGNS - LOGR));
         }
         fft_reg<R, LOGR, NB, u, G::P>(x);
     });

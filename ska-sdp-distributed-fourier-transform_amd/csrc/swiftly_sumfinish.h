@@ -160,6 +160,9 @@ struct SumFinishFacetArgs {
     long long mask_bs;
     const cx<float>* tw_m;
     const cx<float>* tw_x;
+    // direct-row mode (the axis-0 half is finished already, swiftly_groupfinish.h): the `nfacets` inputs are off1
+    // GROUPS, every one of them covers every row, and row r of the output reads row r of each (nrows = xA)
+    int direct_rows;
 };
 
 template <int LOGM, int LOGX>
@@ -194,7 +197,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
         int cnt = 0;
         for (; f < A.nfacets && cnt < NB; f++) {  // workgroup-uniform scan
             const int base = A.base0[f];
-            bool any = false;
+            bool any = A.direct_rows != 0;
             for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
             if (any) fs[cnt++] = f;
         }
@@ -205,8 +208,8 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
             constexpr int sl = decltype(sI)::value;
             if (sl < cnt) {  // uniform
                 const int ff = fs[sl];
-                const int k = (row - A.base0[ff]) & (X - 1);
-                const bool on = live && k < M;
+                const int k = A.direct_rows ? row : ((row - A.base0[ff]) & (X - 1));
+                const bool on = live && (A.direct_rows || k < M);
                 const cx<float>* __restrict__ in =
                     A.in + (long long)ff * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
                 wgt[sl] = on ? 1.f : 0.f;

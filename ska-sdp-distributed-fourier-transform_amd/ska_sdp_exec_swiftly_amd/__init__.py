@@ -7,6 +7,7 @@ Public interface mirrors reference src/ska_sdp_exec_swiftly/__init__.py:4-35.
 """
 from . import api  # noqa: F401  (submodule access: sw.api.preferred_wave_axis, ...)
 from .api import (
+    DeviceTask,
     FacetConfig,
     SubgridConfig,
     SwiftlyBackward,
@@ -27,6 +28,7 @@ from .core_hip import SwiftlyCoreHip, calculate_pswf
 from .swift_configs import SWIFT_CONFIGS
 
 __all__ = [
+    "DeviceTask",
     "FacetConfig",
     "SubgridConfig",
     "SwiftlyConfig",

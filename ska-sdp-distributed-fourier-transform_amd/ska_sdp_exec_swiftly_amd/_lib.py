@@ -75,6 +75,12 @@ def _declare(lib):
     lib.swiftly_hip_add_to_subgrid_from_columns.argtypes = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, pi64, vp]
     lib.swiftly_hip_band_columns.restype = i64
     lib.swiftly_hip_band_columns.argtypes = [i64]
+    lib.swiftly_hip_grouped_subgrid_side_supported.restype = c_int
+    lib.swiftly_hip_grouped_subgrid_side_supported.argtypes = [vp]
+    lib.swiftly_hip_wave_subgrid_side_grouped.restype = c_int
+    lib.swiftly_hip_wave_subgrid_side_grouped.argtypes = [
+        vp, c_int, vp, i64, i64, vp, i64, pi64, pi64, i64, pi64, pi64, i64, vp, i64, vp, i64, vp, i64, vp, vp,
+    ]
     lib.swiftly_hip_band_columns_for.restype = i64
     lib.swiftly_hip_band_columns_for.argtypes = [vp, i64]
     lib.swiftly_hip_prepare_facet_band.restype = c_int

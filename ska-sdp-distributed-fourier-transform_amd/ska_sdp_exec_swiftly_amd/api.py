@@ -42,6 +42,7 @@ __all__ = [
     "SwiftlyBackward",
     "LRUCache",
     "TaskQueue",
+    "DeviceTask",
     "preferred_wave_axis",
     "make_full_facet_cover",
     "make_full_subgrid_cover",
@@ -295,6 +296,64 @@ def _torch():
     return torch
 
 
+class DeviceTask:
+    """Handle of one asynchronous result: the counterpart of the ``dask.delayed`` / future objects the reference's
+    streaming classes hand out (api.py:238-253, 347-400).  It wraps the device tensor whose producing kernels have
+    been enqueued plus a HIP event recorded right behind them.
+
+    * ``tensor`` -- the device tensor, valid in stream order (pass it, or the task itself, to
+      ``SwiftlyBackward.add_new_subgrid_task``: no synchronisation happens);
+    * ``done()`` -- has the GPU finished it?  ``wait()`` blocks the host until it has;
+    * ``compute()`` / ``result()`` -- host copy as a numpy array (what ``Delayed.compute()`` / ``Future.result()``
+      give a caller of the reference); ``numpy.asarray(task)`` works too.
+
+    ``SwiftlyForward(..., delayed=True)`` / ``SwiftlyBackward(..., delayed=True)`` return these instead of bare tensors.
+    """
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self._event = None
+        if getattr(tensor, "is_cuda", False):
+            self._event = _torch().cuda.Event()
+            self._event.record()
+
+    def done(self):
+        """True once the producing kernels have completed"""
+        return self._event is None or self._event.query()
+
+    def wait(self):
+        """block the calling host thread until the result is complete"""
+        if self._event is not None:
+            self._event.synchronize()
+        return self
+
+    def compute(self):
+        """host copy of the result (numpy)"""
+        self.wait()
+        return self.tensor.cpu().numpy()
+
+    result = compute
+
+    def __array__(self, dtype=None, copy=None):
+        arr = self.compute()
+        return arr.astype(dtype) if dtype is not None else arr
+
+    @property
+    def shape(self):
+        """shape of the result"""
+        return tuple(self.tensor.shape)
+
+    @property
+    def dtype(self):
+        """torch dtype of the result"""
+        return self.tensor.dtype
+
+
+def _unwrap(data):
+    """the device tensor of a :class:`DeviceTask`, anything else unchanged"""
+    return data.tensor if isinstance(data, DeviceTask) else data
+
+
 def preferred_wave_axis(swiftly_config, dtype=None, n_facets=None):
     """Which subgrid offset the forward engine should group "waves" by for
     row-major facets: 0 = ``off0`` (the reference's column cache key,
@@ -462,8 +521,10 @@ class SwiftlyForward:
     # pylint: disable=too-many-arguments,too-many-instance-attributes
     def __init__(
         self, swiftly_config, facet_tasks, lru_forward=1, queue_size=20, client=None, subgrid_configs=None,
-        wave_axis=None,
+        wave_axis=None, delayed=False,
     ):
+        self.delayed = bool(delayed)  # hand out DeviceTask handles instead of bare device tensors
+        facet_tasks = [(cfg, _unwrap(data)) for cfg, data in facet_tasks]
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facet_tasks = facet_tasks
@@ -612,7 +673,7 @@ class SwiftlyForward:
                 j += 1
             tasks = self._serve_group(list(subgrid_configs[i:j]))
             self.task_queue.process(tasks)
-            out.extend(tasks)
+            out.extend(DeviceTask(t) for t in tasks) if self.delayed else out.extend(tasks)
             i = j
         return out
 
@@ -893,13 +954,31 @@ class SwiftlyForward:
         return Q, rowmap, n_rows, True
 
     def _wave_b(self, sgs):
-        """One wave = two native calls: facet side (K2 + K3 + K4a) and subgrid side (K4b + K5)."""
+        """One wave = two native calls: facet side (K2 + K3 + K4a) and subgrid side (K4b + K5).  ``SWIFTLY_GROUPED=1``
+        (where the facets form off1 groups) selects K2 + the grouped subgrid side that finishes axis 0 first instead:
+        79 -> 49 MB of HBM traffic per subgrid at the same speed (measured r3: 42.5 vs 42.4 ms per 64k pass; the fused
+        column kernel is register-bound), so it is not the default."""
         torch = _torch()
         core = self.core
         self._check_planned(sgs)
         bands = self.prepare_all_facets()
         Q, rowmap, n_rows, compute = self._wave_Q(sgs[0].off1)
         m = core.xM_yN_size
+        off1s = [cfg.off1 for cfg in self.facet_configs]
+        if os.environ.get("SWIFTLY_GROUPED", "0") == "1" and core.supports_grouped_subgrid_side(self.dtype, off1s, sgs[0].size):
+            off0s = [cfg.off0 for cfg in self.facet_configs]
+            xA, S = sgs[0].size, len(sgs)
+            try:
+                if compute:
+                    core.prepare_facet_columns(bands, off0s, self._band, sgs[0].off1, rowmap, n_rows, out=Q)
+            except Exception:
+                self.lru._items.pop(("b", sgs[0].off1), None)  # pylint: disable=protected-access
+                raise
+            mask1 = _mask_table(core, sgs, "mask1", xA, self.dtype)
+            mask0 = _mask_table(core, sgs, "mask0", xA, self.dtype)
+            res = torch.empty((S, xA, xA), dtype=self.dtype, device=core.device)
+            return core.wave_subgrid_side_grouped(Q, rowmap, off0s, off1s, [sg.off0 for sg in sgs], [sg.off1 for sg in sgs],
+                                                  xA, mask0, mask1, res)
         G = torch.empty((len(self.facet_configs), len(sgs), m, m), dtype=self.dtype, device=core.device)
         try:
             core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,
@@ -1049,7 +1128,8 @@ class SwiftlyBackward:
 
     # pylint: disable=too-many-arguments,too-many-instance-attributes
     def __init__(self, swiftly_config, facets_config_list, lru_backward=1, queue_size=20, client=None,
-                 subgrid_configs=None, wave_axis=None):
+                 subgrid_configs=None, wave_axis=None, delayed=False):
+        self.delayed = bool(delayed)  # finish() hands out DeviceTask handles instead of bare device tensors
         # wave_axis=None: the reference's schedule, unless the caller hands over the plan of subgrids it will add and
         # the band kernels exist -- decided when the first subgrid shows the dtype (complex64 only)
         self._auto_axis = wave_axis is None
@@ -1102,6 +1182,7 @@ class SwiftlyBackward:
         buffer held in ``LRUCache(lru_backward)``, the counterpart of the reference's per-column partial sums
         (api.py:402-438) -- and the wave is folded into the band accumulators when it is complete (plan known),
         evicted from the cache, or at :py:meth:`finish`."""
+        new_subgrid_tasks = [_unwrap(t) for t in new_subgrid_tasks]
         if len(subgrid_configs) and self._auto_axis:
             self._resolve_axis(new_subgrid_tasks[0])
         col = None
@@ -1412,7 +1493,7 @@ class SwiftlyBackward:
                 self._flush_staged(staged)
             out = self._finish_bands()
             self.task_queue.wait_all_done()
-            return out
+            return [DeviceTask(t) for t in out] if self.delayed else out
         for old_off0, old_col in self.lru.pop_all():
             self.update_MNAF_BMNAFs(old_off0, old_col)
         out = []
@@ -1423,4 +1504,4 @@ class SwiftlyBackward:
             else:
                 out.append(core.finish_facet(acc, cfg.off0, cfg.size, axis=0, mask=cfg.mask0))
         self.task_queue.wait_all_done()
-        return out
+        return [DeviceTask(t) for t in out] if self.delayed else out

@@ -691,6 +691,40 @@ class SwiftlyCoreHip:
         )
         return out
 
+    def supports_grouped_subgrid_side(self, dtype, facet_off1s, subgrid_size):
+        """True when the forward subgrid side can finish axis 0 first, per facet ``off1`` group
+        (``swiftly_hip_wave_subgrid_side_grouped``): kernels instantiated for these sizes, complex64, <= 64 facets, and
+        the per-group intermediate ``[groups, S, xA, m]`` smaller than the per-facet one ``[F, S, m, m]`` it replaces (a
+        facet list with few facets per off1 -- a sparse plus-shaped cover, a two-facet subset -- stays on the per-facet
+        route)."""
+        torch = _torch()
+        if dtype != torch.complex64 or not self._lib.swiftly_hip_grouped_subgrid_side_supported(self._handle):
+            return False
+        F = len(facet_off1s)
+        groups = len({int(o) for o in facet_off1s})
+        return 0 < F <= self.MAX_FUSED_FACETS and 4 * groups * int(subgrid_size) <= 3 * F * self.xM_yN_size
+
+    def wave_subgrid_side_grouped(self, Q, rowmap, facet_off0s, facet_off1s, sub_off0s, sub_off1s, subgrid_size, mask0,
+                                  mask1, out):
+        """K3..K5 of one wave with the axis-0 half finished first (``swiftly_hip_wave_subgrid_side_grouped``):
+        ``Q[F, rows, m]`` (prepare_facet_columns) -> ``out[S, xA, xA]``."""
+        F, S = Q.shape[0], len(sub_off0s)
+        cvp = ctypes.c_void_p
+        groups = len({int(o) for o in facet_off1s})
+        nwork = groups * S * int(subgrid_size) * self.xM_yN_size
+        work = self.scratch("grouped", nwork * 8)
+        _lib.check(
+            self._lib.swiftly_hip_wave_subgrid_side_grouped(
+                self._handle, self._code(Q), cvp(Q.data_ptr()), Q.stride(1), Q.stride(0),
+                cvp(rowmap.data_ptr()) if rowmap is not None else None, F, self._i64(facet_off0s), self._i64(facet_off1s), S,
+                self._i64(sub_off0s), self._i64(sub_off1s), int(subgrid_size),
+                cvp(mask0.data_ptr()) if mask0 is not None else None, mask0.stride(0) if mask0 is not None else 0,
+                cvp(mask1.data_ptr()) if mask1 is not None else None, mask1.stride(0) if mask1 is not None else 0,
+                cvp(work.data_ptr()), nwork, cvp(out.data_ptr()), self._stream(),
+            )
+        )
+        return out
+
     def sum_finish_facets(self, G, facet_off0s, facet_off1s, out, subgrid_off1s, subgrid_size, mask=None):
         """K4b + K5a: sum over facets + axis-1 finish of ``G[F, S, m, m]`` (transform_contributions) ->
         ``out[S, xM, subgrid_size]`` (see include/swiftly_hip.h)."""

@@ -409,3 +409,35 @@ def test_backward_fused_split_matches_primitives(params):
     assert err < 2e-6
     for f in range(len(facet_cfgs)):
         assert float((got[f] - want[f]).abs().max()) <= 2e-5 * float(want[f].abs().max())
+
+
+def test_delayed_handles_roundtrip():
+    """``delayed=True``: the streaming classes hand out ``DeviceTask`` handles (the counterpart of the reference's
+    Dask Delayed / Future objects, api.py:238-253): ``compute()`` gives the numpy result, the handle itself can be fed
+    to ``SwiftlyBackward`` without synchronising, and the round trip equals the plain-tensor one."""
+    import torch
+
+    sw, cfg, facet_cfgs, sg_cfgs, facets = small_problem(SMALL11_PARAMS, numpy.complex64, 4321)
+    plain = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)))
+    want = [t.cpu().numpy() for t in plain.get_subgrid_tasks(sg_cfgs)]
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), delayed=True, queue_size=3)
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, delayed=True)
+    tasks = []
+    for sg in sg_cfgs:
+        task = fwd.get_subgrid_task(sg)
+        assert isinstance(task, sw.DeviceTask) and task.shape == (sg.size, sg.size) and task.dtype == torch.complex64
+        bwd.add_new_subgrid_task(sg, task)  # a handle is accepted wherever subgrid data is
+        tasks.append(task)
+    for task, w in zip(tasks, want):
+        assert numpy.array_equal(task.compute(), w) and task.done()
+        assert numpy.array_equal(numpy.asarray(task), task.result())
+    out = bwd.finish()
+    ref = sw.SwiftlyBackward(cfg, facet_cfgs)
+    for sg, w in zip(sg_cfgs, want):
+        ref.add_new_subgrid_task(sg, w)
+    for a, b in zip(out, ref.finish()):
+        assert isinstance(a, sw.DeviceTask)
+        assert numpy.array_equal(a.compute(), b.cpu().numpy())
+    # facets may be handed over as handles too
+    fwd2 = sw.SwiftlyForward(cfg, [(c, sw.DeviceTask(torch.from_numpy(f).cuda())) for c, f in zip(facet_cfgs, facets)])
+    assert numpy.array_equal(fwd2.get_subgrid_task(sg_cfgs[3]).cpu().numpy(), want[3])
