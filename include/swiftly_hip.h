@@ -78,6 +78,12 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN_size, int64_t 
                        const double* pswf, int device);
 void swiftly_hip_destroy(swiftly_hip_t* h);
 int64_t swiftly_hip_contribution_size(const swiftly_hip_t* h); /* xM*yN/N, core.py:48 */
+/* Sticky device-side error of the handle: non-zero once a bounded in-launch wait (the fused four-step column
+ * transform hands its intermediate from pass-A to pass-B workgroups inside one launch) has timed out.  Results produced
+ * since then are invalid; every later call that launches such a kernel fails with SWIFTLY_ERR_HIP.  Reads a pinned
+ * host word: no synchronisation, so synchronise the stream first when checking a specific call.  (No reference
+ * counterpart: numpy has no asynchronous failure mode.) */
+int swiftly_hip_async_error(const swiftly_hip_t* h);
 
 /* -- facet -> subgrid ------------------------------------------------------ */
 

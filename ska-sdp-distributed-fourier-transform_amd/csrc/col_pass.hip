@@ -5,17 +5,6 @@
 
 namespace swf {
 
-template <int LOGN>
-struct CGeoFor {
-    static constexpr int LOGP = LOGN < 5 ? LOGN : 5;
-    // exchange re and im separately from 128 rows on: 32 KiB (n = 128) / 64 KiB (n = 256) of LDS per
-    // workgroup keep 16 waves per CU resident, which is what hides the HBM latency (measured:
-    // 8 waves/CU -> 84 % of wave cycles waiting, 2.2 TB/s; 16 waves/CU -> 4.7 TB/s)
-    // 1024 points: 32-column tiles (two rows per wave), 128 KiB.  (The same tiles for 512 points -- 64 KiB, two
-    // workgroups per CU instead of one -- were measured r3 on the 64k pass: 43.37 vs 43.29 ms, no gain; not kept.)
-    using type = CGeo<LOGN, LOGP, (LOGN >= 7), (LOGN >= 10 ? 32 : 64)>;
-};
-
 template <int LOGN, int MODE>
 static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     using G = typename CGeoFor<LOGN>::type;

@@ -173,6 +173,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         if (int rc = init_row_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (row pass): %d", rc);
         if (int rc = init_sum_finish_rows()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (sum finish): %d", rc);
         if (int rc = init_group_finish()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (group finish): %d", rc);
+        if (int rc = init_col_fourstep()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (fused four-step): %d", rc);
         // keep freed scratch (the four-step intermediate, up to yN*yB*8 bytes) in the stream-ordered pool instead of
         // returning it to the driver at every synchronisation point
         hipMemPool_t pool;
@@ -225,6 +226,18 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         }
     for (int64_t len : {yN, xM, h->m})
         if (!rc) rc = make_bluestein(h, len);
+    if (!rc) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            rc = fail(SWIFTLY_ERR_HIP, "hipHostMalloc(error word) failed");
+        } else {
+            h->async_err = (unsigned*)hp;
+            h->async_err_dev = (unsigned*)dp;
+            *(volatile unsigned*)h->async_err = 0;
+        }
+    }
     if (rc) {
         swiftly_hip_destroy(h);
         return rc;
@@ -237,7 +250,13 @@ void swiftly_hip_destroy(swiftly_hip_t* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->async_err) (void)hipHostFree(h->async_err);
     delete h;
+}
+
+int swiftly_hip_async_error(const swiftly_hip_t* h) {
+    if (!h || !h->async_err) return 0;
+    return (int)*(volatile const unsigned*)h->async_err;
 }
 
 int64_t swiftly_hip_contribution_size(const swiftly_hip_t* h) { return h ? h->m : -1; }
@@ -343,6 +362,24 @@ ColZ plain_colz() {
     return z;
 }
 
+// the tables of a fused four-step launch (at most kFsZB subgrids per facet, no gather-sum chunks)
+static ColZS slim_colz(const ColZ& z) {
+    ColZS s;
+    std::memset(&s, 0, sizeof s);
+    s.flags = z.flags;
+    s.nb = z.nb;
+    for (int b = 0; b < kFsZB; b++) {
+        s.b_rot[b] = z.b_rot[b]; s.b_base[b] = z.b_base[b];
+        s.b_lda[b] = z.b_lda[b]; s.b_ldc[b] = z.b_ldc[b]; s.b_sta[b] = z.b_sta[b];
+        s.b_out_off[b] = z.b_out_off[b]; s.b_out_fs[b] = z.b_out_fs[b];
+    }
+    for (int f = 0; f < kColZF; f++) {
+        s.f_lda[f] = z.f_lda[f];
+        s.f_sta[f] = z.f_sta[f];
+    }
+    return s;
+}
+
 int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz, int outer, int nb, hipStream_t st) {
     int e = launch_col_pass(lg, mode, args, cz, outer, nb, st);
     if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -393,24 +430,52 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     const bool gathered = (cz.flags & kZColGather) != 0;
     const long long slab = (slab_env >= 64 && nb == 1 && !gathered) ? (slab_env / 64) * 64 : (long long)W;
     const long long Ws = std::min<long long>(slab, (long long)W);  // scratch row width
+    // both passes in one launch with the intermediate handed over in flight (swiftly_fourstep.h; measured slower than
+    // the two launches, see there): opt-in with SWIFTLY_FOURSTEP_FUSED=1 (read per call), SWIFTLY_FOURSTEP_LAG = distance
+    // in chunks between a chunk's pass A and its pass B.  Needs one arrival counter per (batch item, 64-column tile),
+    // taken from the tail of the scratch.
+    const char* fused_s = getenv("SWIFTLY_FOURSTEP_FUSED");
+    const char* lag_s = getenv("SWIFTLY_FOURSTEP_LAG");
+    const int fused_env = fused_s ? atoi(fused_s) : 0;
+    const int lag_env = lag_s ? std::max(1, atoi(lag_s)) : 4;
+    const long long chunks = (long long)nb * ((W + 63) / 64);
+    const bool fused = fused_env && Ws == (long long)W && !c.gs && cz.nb <= kFsZB && chunks < (1 << 24) &&
+                       col_fourstep_supported(l1, l2);
+    const size_t scratch_bytes = (size_t)nb * n * (size_t)Ws * sizeof(cx<float>);
+    const size_t cnt_bytes = fused ? (((size_t)chunks * sizeof(unsigned) + 255) & ~size_t(255)) : 0;
     void* scratch = nullptr;
+    unsigned* counters = nullptr;
+    bool own_counters = false;
     hipError_t he = hipSuccess;
     // caller-provided workspace (deterministic; the stream-ordered pool reuses memory across STREAMS only
     // opportunistically, which made the two-stream schedule fall back to fresh multi-GB allocations on some runs)
-    const bool own = !(ws && ws_bytes >= (size_t)nb * n * (size_t)Ws * sizeof(cx<float>));
+    const bool own = !(ws && ws_bytes >= scratch_bytes);
     if (own) {
-        he = hipMallocAsync(&scratch, (size_t)nb * n * (size_t)Ws * sizeof(cx<float>), st);
+        he = hipMallocAsync(&scratch, scratch_bytes + cnt_bytes, st);
         if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
+        if (fused) counters = (unsigned*)((char*)scratch + scratch_bytes);
     } else {
         scratch = ws;
+        if (fused) {
+            if (ws_bytes >= scratch_bytes + cnt_bytes) {
+                counters = (unsigned*)((char*)scratch + scratch_bytes);
+            } else {  // a fixed-size request: served from the pool without a driver call after the first time
+                void* p = nullptr;
+                he = hipMallocAsync(&p, std::max<size_t>(cnt_bytes, size_t(64) << 10), st);
+                if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(hand-off counters): %s", hipGetErrorString(he));
+                counters = (unsigned*)p;
+                own_counters = true;
+            }
+        }
     }
     int rc = 0;
+    if (swiftly_hip_async_error(h))
+        rc = fail(SWIFTLY_ERR_HIP, "an in-launch hand-off of an earlier call on this handle timed out (results since then are invalid)");
     // scratch accesses: a small intermediate is left cacheable so that pass B finds it in the 256 MiB Infinity
     // Cache (measured: the 160 MB of a K5b wave, K3-5 12.5 -> 11.6 ms per pass); a large one is streamed
     // non-temporally (measured: K2, 1.2 GB per wave, 18.5 ms vs 19.6 ms cacheable).  SWIFTLY_SCRATCH_NT forces.
     static const int scratch_nt_env = getenv("SWIFTLY_SCRATCH_NT") ? atoi(getenv("SWIFTLY_SCRATCH_NT")) : -1;
-    const size_t scratch_bytes = (size_t)nb * n * (size_t)Ws * sizeof(cx<float>);
-    const int scratch_nt = scratch_nt_env >= 0 ? scratch_nt_env : (scratch_bytes > (size_t(192) << 20) ? 1 : 0);
+    const int scratch_nt = scratch_nt_env >= 0 ? scratch_nt_env : (!fused && scratch_bytes > (size_t(192) << 20) ? 1 : 0);
     for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
         const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
         // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
@@ -427,8 +492,10 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.col_win = nullptr; A.st_rowmap = nullptr; A.st_win = nullptr; A.st_win2 = nullptr;
         ColZ za = cz;
         za.flags &= ~kZColScatter;  // the scratch is written plainly
-        rc = launch_col_checked(l1, 0, A, za, n2, nb, st);
-        if (rc) break;
+        if (!fused) {
+            rc = launch_col_checked(l1, 0, A, za, n2, nb, st);
+            if (rc) break;
+        }
         // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
         ColPassArgs B = c;
         B.scratch_nt = scratch_nt;
@@ -444,7 +511,21 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         B.tw = tw2; B.tw_full = twf;
         B.conj_ld = 0;
         if (B.col_win) B.col_win += c0;
-        rc = launch_col_checked(l2, 1, B, zb, n1, nb, st);
+        if (!fused) {
+            rc = launch_col_checked(l2, 1, B, zb, n1, nb, st);
+            continue;
+        }
+        he = hipMemsetAsync(counters, 0, (size_t)chunks * sizeof(unsigned), st);
+        if (he != hipSuccess) {
+            rc = fail(SWIFTLY_ERR_HIP, "hipMemsetAsync(hand-off counters): %s", hipGetErrorString(he));
+            break;
+        }
+        const int e = launch_col_fourstep(l1, l2, A, B, slim_colz(za), slim_colz(zb), nb, lag_env, counters, h->async_err_dev, st);
+        if (e) rc = fail(SWIFTLY_ERR_HIP, "fused four-step launch failed: %s", e < 0 ? "no instance" : hipGetErrorString((hipError_t)e));
+    }
+    if (own_counters) {
+        he = hipFreeAsync(counters, st);
+        if (!rc && he != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(he));
     }
     if (own) {
         he = hipFreeAsync(scratch, st);

@@ -18,6 +18,7 @@
 
 #include "../../include/swiftly_hip.h"
 #include "swiftly_colpass.h"
+#include "swiftly_fourstep.h"
 #include "swiftly_rowpass.h"
 #include "swiftly_sumfinish.h"
 #include "swiftly_groupfinish.h"
@@ -74,6 +75,10 @@ struct swiftly_hip {
     };
     std::map<int64_t, Blu> blu;
     std::vector<void*> allocs;
+    // sticky error word of the in-launch hand-offs (swiftly_fourstep.h): pinned host memory the device writes on a
+    // timed-out wait; checked at the start of every call that launches such a kernel and by swiftly_hip_async_error
+    unsigned* async_err = nullptr;      // host view
+    unsigned* async_err_dev = nullptr;  // device view of the same word
 };
 
 template <typename R>

@@ -101,19 +101,21 @@ constexpr int kGsRowBits = 20;
 // kZColScatter: the column map of kZColGather applied to the OUTPUT column (add_to_facet along the contiguous axis
 // fused into the store; cg_band_half = 0 selects a plain band: column d = (scol - cg_band_start) mod cg_full)
 enum { kZColGather = 1, kZLoadB = 2, kZLoadAF = 4, kZStoreAF = 8, kZStoreAB = 16, kZOutB = 32, kZColScatter = 64 };
-struct ColZ {
+template <int NB_, int NF_, int NC_>
+struct ColZT {
     int flags;
     int nb;                            // z = f*nb + b ; nb >= 1
-    int b_rot[kColZB], b_base[kColZB];  // kZColGather: column gather (window) per subgrid
-    int b_lda[kColZB], b_ldc[kColZB];   // kZLoadB: load-map offsets (ld_a, ld_c) per subgrid (row window)
-    int b_sta[kColZB];                  // kZStoreAB: store-map offset st_a per subgrid
+    int b_rot[NB_], b_base[NB_];  // kZColGather: column gather (window) per subgrid
+    int b_lda[NB_], b_ldc[NB_];   // kZLoadB: load-map offsets (ld_a, ld_c) per subgrid (row window)
+    int b_sta[NB_];                  // kZStoreAB: store-map offset st_a per subgrid
     // kZOutB: output placement per subgrid -- item (f, b) writes at out + b_out_off[b] + f * b_out_fs[b] (elements):
     // lets one launch fill a rank-ordered all-to-all send buffer [dest][facet][subgrid of dest]
-    long long b_out_off[kColZB], b_out_fs[kColZB];
-    int f_lda[kColZF];                  // kZLoadAF: load-map offset ld_a per facet
-    int f_sta[kColZF];                  // kZStoreAF: store-map offset st_a per facet
-    long long c_base[kColZC], c_fs[kColZC];  // gather-sum load: element offset / facet stride of source chunk c
+    long long b_out_off[NB_], b_out_fs[NB_];
+    int f_lda[NF_];                  // kZLoadAF: load-map offset ld_a per facet
+    int f_sta[NF_];                  // kZStoreAF: store-map offset st_a per facet
+    long long c_base[NC_], c_fs[NC_];  // gather-sum load: element offset / facet stride of source chunk c
 };
+using ColZ = ColZT<kColZB, kColZF, kColZC>;
 
 // COLS_ = 64: a wave works on ONE row (all row bookkeeping wave-uniform).  COLS_ = 32 (r3, P = 32 only): the tile is 32
 // columns wide and a wave works on TWO rows, lanes 0-31 / 32-63 -- half the LDS per point, which lets a 1024-point
@@ -136,6 +138,18 @@ struct CGeo {
     static constexpr size_t LDS_BYTES = T > 1 ? (size_t)N * RB * ELEM : 0;
     // minimum waves per SIMD the register allocator must leave room for
     static constexpr int MINW = NT >= 256 ? 4 : 1;
+};
+
+// the geometry used for a LOGN-point pass
+template <int LOGN>
+struct CGeoFor {
+    static constexpr int LOGP = LOGN < 5 ? LOGN : 5;
+    // exchange re and im separately from 128 rows on: 32 KiB (n = 128) / 64 KiB (n = 256) of LDS per
+    // workgroup keep 16 waves per CU resident, which is what hides the HBM latency (measured:
+    // 8 waves/CU -> 84 % of wave cycles waiting, 2.2 TB/s; 16 waves/CU -> 4.7 TB/s)
+    // 1024 points: 32-column tiles (two rows per wave), 128 KiB.  (The same tiles for 512 points -- 64 KiB, two
+    // workgroups per CU instead of one -- were measured r3 on the 64k pass: 43.37 vs 43.29 ms, no gain; not kept.)
+    using type = CGeo<LOGN, LOGP, (LOGN >= 7), (LOGN >= 10 ? 32 : 64)>;
 };
 
 // value of `val` held by the lane that describes row slot v of THIS lane's half-wave (HALF) / of the wave
@@ -163,17 +177,14 @@ __device__ __forceinline__ float slot_bcast_f(float val, int v, int hw) {
 // coalesced vector load per table instead of P dependent scalar loads), and
 // the main loops fetch the values with v_readlane.  The output-side
 // bookkeeping is issued before the butterflies so its latency hides under them.
-template <class G, int MODE, bool SNT, bool GS = false>
-__global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassArgs A, const cx<float>* __restrict__ gin,
-                                                         cx<float>* __restrict__ gout,
-                                                         const float* __restrict__ ld_win,
-                                                         const float* __restrict__ ld_win2,
-                                                         const float* __restrict__ st_win,
-                                                         const float* __restrict__ st_win2,
-                                                         const int* __restrict__ st_rowmap,
-                                                         const cx<float>* __restrict__ tw,
-                                                         const cx<float>* __restrict__ tw_full, const ColZ cz) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <class G, int MODE, bool SNT, bool GS, class CZ>
+__device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<float>* __restrict__ gin,
+                                              cx<float>* __restrict__ gout, const float* __restrict__ ld_win,
+                                              const float* __restrict__ ld_win2, const float* __restrict__ st_win,
+                                              const float* __restrict__ st_win2, const int* __restrict__ st_rowmap,
+                                              const cx<float>* __restrict__ tw, const cx<float>* __restrict__ tw_full,
+                                              const CZ& cz, const int wave, const int lane, const int bx, const int o,
+                                              const int z, unsigned char* smem) {
     constexpr int P = G::P, T = G::T;
     static_assert(P <= 64, "one lane per row slot");
     constexpr bool HALF = G::HALF;
@@ -183,16 +194,12 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     // last Stockham phase: radix 2^LR at stride 2^LNS  (phases are LOGP, LOGP, ..., remainder)
     constexpr int LR = G::LOGN <= G::LOGP ? G::LOGN : (G::LOGN % G::LOGP == 0 ? G::LOGP : G::LOGN % G::LOGP);
     constexpr int LNS = G::LOGN - LR;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hw = HALF ? lane >> 5 : 0;              // which half-wave (32-column tiles: two rows per wave)
     const int t = HALF ? 2 * wave + hw : wave;        // thread-row id: owns rows t + v*T
     const int clane = HALF ? (lane & 31) : lane;      // column within the tile
-    const int o = blockIdx.y;
-    const int col = blockIdx.x * G::COLS + clane;
+    const int col = bx * G::COLS + clane;
     const bool live = col < A.ncols;
     const int FN = 1 << A.full_logn;
-    const int z = blockIdx.z;
     const int zf = z / cz.nb, zb = z - zf * cz.nb;  // uniform
     int scol = col;
     if (cz.flags & (kZColGather | kZColScatter)) {  // uniform
@@ -206,14 +213,17 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     }
     const int lcol = (cz.flags & kZColGather) ? scol : col;    // column read
     const int ocol = (cz.flags & kZColScatter) ? scol : col;   // column written
+    // (selects of VALUES, with in-range indices whatever the flags say: a conditional assignment from the table makes
+    // the compiler select between POINTERS into `cz` and a local, which keeps a private copy of the whole table alive)
+    constexpr int NBZ = sizeof(cz.b_lda) / sizeof(int), NFZ = sizeof(cz.f_lda) / sizeof(int);
+    const int zbi = zb < NBZ ? zb : 0, zfi = zf < NFZ ? zf : 0;
+    const int t_lda = cz.b_lda[zbi], t_ldc = cz.b_ldc[zbi], t_flda = cz.f_lda[zfi], t_fsta = cz.f_sta[zfi], t_bsta = cz.b_sta[zbi];
     int ld_a = A.ld_a, ld_c = A.ld_c, st_a = A.st_a;
-    if (cz.flags & kZLoadB) {
-        ld_a = cz.b_lda[zb];
-        ld_c = cz.b_ldc[zb];
-    }
-    if (cz.flags & kZLoadAF) ld_a = cz.f_lda[zf];
-    if (cz.flags & kZStoreAF) st_a = cz.f_sta[zf];
-    if (cz.flags & kZStoreAB) st_a = cz.b_sta[zb];
+    ld_a = (cz.flags & kZLoadB) ? t_lda : ld_a;
+    ld_c = (cz.flags & kZLoadB) ? t_ldc : ld_c;
+    ld_a = (cz.flags & kZLoadAF) ? t_flda : ld_a;
+    st_a = (cz.flags & kZStoreAF) ? t_fsta : st_a;
+    st_a = (cz.flags & kZStoreAB) ? t_bsta : st_a;
     const long long in_off =
         A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs : (long long)z * A.in_bs;
     const cx<float>* __restrict__ in = gin + (GS ? 0ll : in_off) + lcol;
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             if (idx >= A.st_mod) idx -= A.st_mod;
             const bool ok = d < A.st_len;
             const int ds = ok ? d : 0;
-            if (st_win) out_w *= st_win[(long long)blockIdx.z * A.st_win_bs + ds];
+            if (st_win) out_w *= st_win[(long long)z * A.st_win_bs + ds];
             if (st_win2) out_w *= st_win2[ds];
             int row = idx;
             if (st_rowmap) row = st_rowmap[(long long)zb * A.st_rowmap_bs + (ok ? idx : 0)];
@@ -362,6 +372,24 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
             if (live) cp_store<NT_ST>(p, v);
         }
     });
+}
+
+// (wave = workgroup-uniform wave index, lane; bx / o / z = column tile, outer index, batch item: the grid of the plain
+// kernel, a schedule of its own in the fused four-step kernel of swiftly_fourstep.h)
+template <class G, int MODE, bool SNT, bool GS = false>
+__global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassArgs A, const cx<float>* __restrict__ gin,
+                                                         cx<float>* __restrict__ gout,
+                                                         const float* __restrict__ ld_win,
+                                                         const float* __restrict__ ld_win2,
+                                                         const float* __restrict__ st_win,
+                                                         const float* __restrict__ st_win2,
+                                                         const int* __restrict__ st_rowmap,
+                                                         const cx<float>* __restrict__ tw,
+                                                         const cx<float>* __restrict__ tw_full, const ColZ cz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    col_pass_body<G, MODE, SNT, GS>(A, gin, gout, ld_win, ld_win2, st_win, st_win2, st_rowmap, tw, tw_full, cz,
+                                    __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, blockIdx.x,
+                                    blockIdx.y, blockIdx.z, smem);
 }
 
 constexpr int kColPassMinLog = 2;

@@ -35,6 +35,8 @@ def _declare(lib):
     lib.swiftly_hip_destroy.argtypes = [vp]
     lib.swiftly_hip_contribution_size.restype = i64
     lib.swiftly_hip_contribution_size.argtypes = [vp]
+    lib.swiftly_hip_async_error.restype = ctypes.c_int
+    lib.swiftly_hip_async_error.argtypes = [vp]
     # (h, dtype, in, rows, [size,] in_rs, in_cs, out, out_rs, out_cs, off, [size, mask,] stream)
     sized_in = [vp, c_int, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp]
     plain = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, vp]

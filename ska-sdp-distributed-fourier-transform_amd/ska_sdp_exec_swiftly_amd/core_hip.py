@@ -599,6 +599,13 @@ class SwiftlyCoreHip:
     def _i64(values):
         return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
 
+    def async_error(self):
+        """Sticky device-side error of this core (``swiftly_hip_async_error``): non-zero once a bounded in-launch wait
+        of the opt-in fused four-step transform has timed out.  Synchronise first to check a specific call."""
+        return int(self._lib.swiftly_hip_async_error(self._handle))
+
+    SCRATCH_TAIL_BYTES = 1 << 16
+
     def scratch(self, name, nbytes):
         """Grow-only persistent device scratch of this core, by name (four-step intermediates of the native wave
         calls; stream-ordered allocations of changing size cost ~2 ms of host time each)."""
@@ -607,9 +614,11 @@ class SwiftlyCoreHip:
         # one buffer per HIP stream: calls on one stream are ordered, calls on different streams (other host
         # threads, side streams) must not share a scratch
         key = (name, torch.cuda.current_stream(self._device).cuda_stream)
+        # + room for the arrival counters of the fused four-step launches (one word per batch item and column tile)
+        nbytes = int(nbytes) + self.SCRATCH_TAIL_BYTES
         buf = pool.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = pool[key] = torch.empty((int(nbytes),), dtype=torch.uint8, device=self._device)
+            buf = pool[key] = torch.empty((nbytes,), dtype=torch.uint8, device=self._device)
         return buf
 
     def wave_facet_side(self, bands, facet_off0s, band, wave_off1, rowmap, n_rows, Q, compute_q, sub_off0s, g_out,

@@ -109,6 +109,33 @@ def test_prepare_facet_columns(band, use_rowmap):
             assert rel < 2e-6, (off1, f, rel)
 
 
+@pytest.mark.parametrize("lag", [1, 4])
+def test_prepare_facet_columns_fused_four_step_is_bit_identical(lag, monkeypatch):
+    """Opt-in single-launch four-step (csrc/swiftly_fourstep.h: pass-A workgroups hand the intermediate to pass-B
+    workgroups of the same grid through agent-scope release / acquire): same arithmetic as the two launches, so the
+    result must be identical to the last bit, on every column tile of every facet, and no wait may time out."""
+    import torch
+
+    core, _ = core64()
+    band = (10736, 11472)
+    rng = numpy.random.default_rng(23)
+    yB0, F = 22528, 3  # full-size columns: 3 facets x 8 column tiles = 24 hand-over chunks of 16.8 MB
+    ncols = core.band_columns(band)
+    bands = torch.from_numpy(rng.standard_normal((F, yB0, ncols, 2)).astype(numpy.float32)).cuda()
+    bands = torch.view_as_complex(bands)
+    off0s = [0, 22528, -22528]
+    rowmap, n_rows = core.subgrid_column_rows([0, 3 * 928, -5 * 928, 20 * 928])
+    monkeypatch.delenv("SWIFTLY_FOURSTEP_FUSED", raising=False)
+    want = core.prepare_facet_columns(bands, off0s, band, 7 * 928, rowmap, n_rows).clone()
+    monkeypatch.setenv("SWIFTLY_FOURSTEP_FUSED", "1")
+    monkeypatch.setenv("SWIFTLY_FOURSTEP_LAG", str(lag))
+    for _ in range(3):  # repeated: a stale line or a missed arrival would not show every time
+        got = core.prepare_facet_columns(bands, off0s, band, 7 * 928, rowmap, n_rows)
+        torch.cuda.synchronize()
+        assert core.async_error() == 0
+        assert torch.equal(torch.view_as_real(got), torch.view_as_real(want))
+
+
 P11 = dict(W=11.0, N=1024, yB=352, yN=512, xA=192, xM=256)  # m = 128: sum_finish instance (7, 8)
 
 
