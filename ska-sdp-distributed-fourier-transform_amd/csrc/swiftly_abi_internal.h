@@ -135,6 +135,29 @@ struct CallWorkspace {
 int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st,
                   void* ws = nullptr, size_t ws_bytes = 0);
 
+// Facet tables of the row-wise fused kernels (swiftly_sumfinish.h), grouped by off1: entries of one group are adjacent.
+template <class Args>
+static inline void fill_facet_groups(Args& a, const swiftly_hip* h, int64_t nfacets, const int64_t* facet_off0s,
+                                     const int64_t* facet_off1s) {
+    const int xM = (int)h->xM, m = (int)h->m;
+    std::vector<int> order((size_t)nfacets);
+    for (int f = 0; f < nfacets; f++) order[(size_t)f] = f;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return facet_off1s[x] < facet_off1s[y]; });
+    a.ngroups = 0;
+    for (int n = 0; n < nfacets; n++) {
+        const int f = order[(size_t)n];
+        if (n == 0 || facet_off1s[f] != facet_off1s[order[(size_t)n - 1]]) {
+            a.gstart[a.ngroups] = n;
+            a.gsp1[a.ngroups] = (int)floordiv(facet_off1s[f] * h->xM, h->N);
+            a.ngroups++;
+        }
+        a.fidx[n] = f;
+        const int sp0 = (int)floordiv(facet_off0s[f] * h->xM, h->N);
+        a.base0[n] = pmod(xM / 2 - m / 2 + sp0, xM);  // first padded-subgrid row the facet contributes to
+    }
+    a.gstart[a.ngroups] = (int)nfacets;
+}
+
 #define CHECK_COMMON()                                                                       \
     if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");                  \
     DeviceGuard device_guard_(h->device);                                                    \

@@ -334,7 +334,7 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
         return fail(SWIFTLY_ERR_UNSUPPORTED, "sum_finish_facets: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
                     (long long)h->xM);
     if (nsub <= 0) return 0;
-    const int xM = (int)h->xM, xA = (int)subgrid_size, m = (int)h->m;
+    const int xM = (int)h->xM, xA = (int)subgrid_size;
     SumFinishFacetArgs a;
     std::memset(&a, 0, sizeof a);
     a.in_fs = in_facet_stride; a.in_bs = in_sub_stride; a.in_rs = in_row_stride;
@@ -342,11 +342,7 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
     a.nrows = xM;
     a.nfacets = (int)nfacets;
     a.xA = xA;
-    for (int f = 0; f < nfacets; f++) {
-        const int sp0 = (int)floordiv(facet_off0s[f] * h->xM, h->N);
-        a.base0[f] = pmod(xM / 2 - m / 2 + sp0, xM);  // first padded-subgrid row facet f contributes to
-        a.sp1[f] = (int)floordiv(facet_off1s[f] * h->xM, h->N);
-    }
+    fill_facet_groups(a, h, nfacets, facet_off0s, facet_off1s);
     a.fn = h->fn_f;
     a.mask_bs = mask ? mask_batch_stride : 0;
     a.tw_m = twiddles<float>(h, h->log_m);
@@ -390,11 +386,7 @@ int swiftly_hip_split_prepare_facets(swiftly_hip_t* h, int dtype, const void* in
     a.nrows = xM;
     a.nfacets = (int)nfacets;
     a.xA = xA;
-    for (int f = 0; f < nfacets; f++) {
-        const int sp0 = (int)floordiv(facet_off0s[f] * h->xM, h->N);
-        a.base0[f] = pmod(xM / 2 - m / 2 + sp0, xM);
-        a.sp1[f] = (int)floordiv(facet_off1s[f] * h->xM, h->N);
-    }
+    fill_facet_groups(a, h, nfacets, facet_off0s, facet_off1s);
     a.fn = h->fn_f;
     a.tw_m = twiddles<float>(h, h->log_m);
     a.tw_x = twiddles<float>(h, h->log_xM);
@@ -601,7 +593,13 @@ int swiftly_hip_wave_subgrid_side_grouped(swiftly_hip_t* h, int dtype, const voi
     sf.in_fs = v_grp; sf.in_bs = v_sub; sf.in_rs = m;
     sf.out_bs = (int64_t)xA * xA; sf.out_rs = xA;
     sf.nrows = xA; sf.nfacets = (int)ng; sf.xA = xA; sf.direct_rows = 1;
-    for (int64_t g = 0; g < ng; g++) sf.sp1[g] = (int)floordiv(goff[(size_t)g] * h->xM, h->N);
+    sf.ngroups = (int)ng;  // direct-row mode: every input is a group of its own
+    for (int64_t g = 0; g < ng; g++) {
+        sf.gstart[g] = (int)g;
+        sf.fidx[g] = (int)g;
+        sf.gsp1[g] = (int)floordiv(goff[(size_t)g] * h->xM, h->N);
+    }
+    sf.gstart[ng] = (int)ng;
     sf.fn = h->fn_f;
     sf.mask_bs = mask1 ? mask1_bs : 0;
     sf.tw_m = a.tw_m; sf.tw_x = a.tw_x;

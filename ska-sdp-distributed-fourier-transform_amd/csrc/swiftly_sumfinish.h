@@ -152,8 +152,15 @@ struct SumFinishFacetArgs {
     long long out_bs, out_rs;
     int nrows;             // padded rows per subgrid (xM)
     int nfacets, xA;
-    int base0[kSumFinishMaxFacets];  // (xM/2 - m/2 + s'0_f) mod xM: first padded row of facet f's band
-    int sp1[kSumFinishMaxFacets];    // s'1_f = floor(facet_off1 * xM / N)
+    // The facets are listed GROUPED by their off1 (entries gstart[g] .. gstart[g+1] of fidx / base0 belong to group g):
+    // the placement along this axis only depends on off1, so the rows of one group's facets are summed BEFORE the
+    // m-point transform (linearity) -- one transform + one scatter per group that covers the row instead of one per
+    // facet (3 instead of 4.5 per row on the 3x3 cover, 8 instead of 16 on an 8x8 cover); r3.
+    int ngroups;
+    int gstart[kSumFinishMaxFacets + 1];
+    int fidx[kSumFinishMaxFacets];   // facet index into `in` of entry n
+    int base0[kSumFinishMaxFacets];  // (xM/2 - m/2 + s'0_f) mod xM of entry n: first padded row of that facet's band
+    int gsp1[kSumFinishMaxFacets];   // s'1 = floor(facet_off1 * xM / N) of GROUP g
     int st_a[kSumFinishMaxBatch];    // (-(xM/2 - xA//2 + off1_b)) mod xM per subgrid
     const float* fn;       // Fn[m]
     const float* mask;     // optional [nbatch][xA]
@@ -186,62 +193,70 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
     });
     row_sync<GX>(false);
 
-    // The facets whose band covers this workgroup's rows are taken SF_NB at a time: the rows of all of them are
-    // requested before the first one is transformed, so a wave pays the HBM latency once per group instead of once
-    // per facet (r2: one facet at a time -- 4.5 dependent round trips per row on the 3x3 cover, SQ_WAIT_ANY 58 % of
-    // the wave cycles at 12 waves per CU).
+    // Per off1 group: the rows of the group's facets whose band covers this workgroup's rows are requested SF_NB at a
+    // time (a wave pays the HBM latency once per batch, not once per facet; r2: one facet at a time -- 4.5 dependent
+    // round trips per row on the 3x3 cover, SQ_WAIT_ANY 58 % of the wave cycles at 12 waves per CU) and summed in
+    // registers; the sum is transformed, weighted and scattered into the accumulator row once.
     constexpr int NB = SWF_SF_NB;
-    int f = 0;
-    while (f < A.nfacets) {
-        int fs[NB];
-        int cnt = 0;
-        for (; f < A.nfacets && cnt < NB; f++) {  // workgroup-uniform scan
-            const int base = A.base0[f];
-            bool any = A.direct_rows != 0;
-            for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
-            if (any) fs[cnt++] = f;
+    for (int g = 0; g < A.ngroups; g++) {  // workgroup-uniform
+        cx<float> xs[PM];
+        static_for<0, PM>([&](auto vI) { xs[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
+        bool anyg = false;
+        int n = A.gstart[g];
+        const int ne = A.gstart[g + 1];
+        while (n < ne) {
+            int fs[NB];
+            int cnt = 0;
+            for (; n < ne && cnt < NB; n++) {  // workgroup-uniform scan
+                const int base = A.base0[n];
+                bool any = A.direct_rows != 0;
+                for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
+                if (any) fs[cnt++] = n;
+            }
+            if (cnt == 0) break;
+            anyg = true;
+            cx<float> x[NB][PM];
+            float wgt[NB];
+            static_for<0, NB>([&](auto sI) {
+                constexpr int sl = decltype(sI)::value;
+                if (sl < cnt) {  // uniform
+                    const int nn = fs[sl];
+                    const int k = A.direct_rows ? row : ((row - A.base0[nn]) & (X - 1));
+                    const bool on = live && (A.direct_rows || k < M);
+                    const cx<float>* __restrict__ in =
+                        A.in + (long long)A.fidx[nn] * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
+                    wgt[sl] = on ? 1.f : 0.f;
+                    static_for<0, PM>([&](auto vI) {
+                        constexpr int v = decltype(vI)::value;
+                        x[sl][v] = in[(t + v * TR) ^ (M >> 1)];  // plain index -> centred element
+                    });
+                }
+            });
+            static_for<0, NB>([&](auto sI) {
+                constexpr int sl = decltype(sI)::value;
+                if (sl < cnt) {  // uniform
+                    static_for<0, PM>([&](auto vI) {
+                        constexpr int v = decltype(vI)::value;
+                        xs[v].x += x[sl][v].x * wgt[sl];
+                        xs[v].y += x[sl][v].y * wgt[sl];
+                    });
+                }
+            });
         }
-        if (cnt == 0) break;
-        cx<float> x[NB][PM];
-        float wgt[NB];
-        static_for<0, NB>([&](auto sI) {
-            constexpr int sl = decltype(sI)::value;
-            if (sl < cnt) {  // uniform
-                const int ff = fs[sl];
-                const int k = A.direct_rows ? row : ((row - A.base0[ff]) & (X - 1));
-                const bool on = live && (A.direct_rows || k < M);
-                const cx<float>* __restrict__ in =
-                    A.in + (long long)ff * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
-                wgt[sl] = on ? 1.f : 0.f;
-                static_for<0, PM>([&](auto vI) {
-                    constexpr int v = decltype(vI)::value;
-                    x[sl][v] = in[(t + v * TR) ^ (M >> 1)];  // plain index -> centred element
-                });
-            }
+        if (!anyg) continue;
+        const int sp = A.gsp1[g];
+        fft_phases<GM, float, 0>(xs, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+            const int ck = e ^ (M >> 1);
+            const int kk = (ck - sp) & (M - 1);
+            const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);  // centred position in the padded subgrid
+            const float w = A.fn[kk];
+            cx<float>* p = acc + lds_pos<GX>(rb, dest ^ (X >> 1), false);  // stored at its plain iFFT index
+            cx<float> o = *p;
+            o.x += v.x * w;
+            o.y += v.y * w;
+            *p = o;
         });
-        static_for<0, NB>([&](auto sI) {
-            constexpr int sl = decltype(sI)::value;
-            if (sl < cnt) {  // uniform
-                static_for<0, PM>([&](auto vI) {
-                    constexpr int v = decltype(vI)::value;
-                    x[sl][v].x *= wgt[sl];
-                    x[sl][v].y *= wgt[sl];
-                });
-                const int sp = A.sp1[fs[sl]];
-                fft_phases<GM, float, 0>(x[sl], t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
-                    const int ck = e ^ (M >> 1);
-                    const int kk = (ck - sp) & (M - 1);
-                    const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);  // centred position in the padded subgrid
-                    const float w = A.fn[kk];
-                    cx<float>* p = acc + lds_pos<GX>(rb, dest ^ (X >> 1), false);  // stored at its plain iFFT index
-                    cx<float> o = *p;
-                    o.x += v.x * w;
-                    o.y += v.y * w;
-                    *p = o;
-                });
-                row_sync<GX>(false);  // also protects ex_m reuse by the next facet
-            }
-        });
+        row_sync<GX>(false);  // also protects ex_m reuse by the next group
     }
 
     cx<float> y[PX];
@@ -284,8 +299,13 @@ struct SplitFacetArgs {
     long long out_fs, out_bs, out_rs;
     int nrows;             // padded rows per subgrid (xM)
     int nfacets, xA;
-    int base0[kSumFinishMaxFacets];  // (xM/2 - m/2 + s'0_f) mod xM
-    int sp1[kSumFinishMaxFacets];    // s'1_f
+    // facets grouped by off1 as in SumFinishFacetArgs: what is extracted for row r only depends on the facet's off1,
+    // so it is computed once per group and stored into every facet of the group whose band covers the row
+    int ngroups;
+    int gstart[kSumFinishMaxFacets + 1];
+    int fidx[kSumFinishMaxFacets];   // facet index into `out` of entry n
+    int base0[kSumFinishMaxFacets];  // (xM/2 - m/2 + s'0_f) mod xM of entry n
+    int gsp1[kSumFinishMaxFacets];   // s'1 of group g
     int ld_a[kSumFinishMaxBatch];    // (-(xM/2 - xA//2 + off1_b)) mod xM per subgrid
     const float* fn;
     const cx<float>* tw_m;
@@ -324,28 +344,50 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_
         row_sync<GX>(false);
     }
     const float scale = 1.f / (float)M;
-    for (int f = 0; f < A.nfacets; f++) {
-        const int base = A.base0[f];
-        bool any = false;  // workgroup-uniform skip
-        for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
-        if (!any) continue;
-        const int k = (row - base) & (X - 1);
-        const bool on = live && k < M;
-        const int sp = A.sp1[f];
+    constexpr int NS = 4;  // facets of a group served by one transform (more: the transform is repeated)
+    for (int g = 0; g < A.ngroups; g++) {  // workgroup-uniform
+        int n = A.gstart[g];
+        const int ne = A.gstart[g + 1];
+        const int sp = A.gsp1[g];
         const int c1 = ((X >> 1) - (M >> 1) + sp) & (X - 1);
-        cx<float> x[PM];
-        static_for<0, PM>([&](auto vI) {
-            constexpr int v = decltype(vI)::value;
-            const int q = (((t + v * TR) ^ (M >> 1)) - sp) & (M - 1);
-            const cx<float> val = acc[lds_pos<GX>(rb, (q + c1) & (X - 1), false)];
-            const float w = A.fn[q];
-            x[v] = cx<float>{val.x * w, -val.y * w};  // inverse transform = conj(FFT(conj(.)))
-        });
-        cx<float>* __restrict__ out = A.out + (long long)f * A.out_fs + (long long)b * A.out_bs + (long long)(on ? k : 0) * A.out_rs;
-        fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
-            if (on) out[e ^ (M >> 1)] = cx<float>{v.x * scale, -v.y * scale};
-        });
-        row_sync<GX>(false);  // ex_m is reused by the next facet
+        while (n < ne) {
+            int fs[NS];
+            int cnt = 0;
+            for (; n < ne && cnt < NS; n++) {  // workgroup-uniform scan
+                const int base = A.base0[n];
+                bool any = false;
+                for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
+                if (any) fs[cnt++] = n;
+            }
+            if (cnt == 0) break;
+            cx<float>* outp[NS];
+            static_for<0, NS>([&](auto sI) {
+                constexpr int sl = decltype(sI)::value;
+                outp[sl] = nullptr;
+                if (sl < cnt) {  // uniform
+                    const int nn = fs[sl];
+                    const int k = (row - A.base0[nn]) & (X - 1);
+                    if (live && k < M)
+                        outp[sl] = A.out + (long long)A.fidx[nn] * A.out_fs + (long long)b * A.out_bs + (long long)k * A.out_rs;
+                }
+            });
+            cx<float> x[PM];
+            static_for<0, PM>([&](auto vI) {
+                constexpr int v = decltype(vI)::value;
+                const int q = (((t + v * TR) ^ (M >> 1)) - sp) & (M - 1);
+                const cx<float> val = acc[lds_pos<GX>(rb, (q + c1) & (X - 1), false)];
+                const float w = A.fn[q];
+                x[v] = cx<float>{val.x * w, -val.y * w};  // inverse transform = conj(FFT(conj(.)))
+            });
+            fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+                const cx<float> o = cx<float>{v.x * scale, -v.y * scale};
+                static_for<0, NS>([&](auto sI) {
+                    constexpr int sl = decltype(sI)::value;
+                    if (outp[sl]) outp[sl][e ^ (M >> 1)] = o;
+                });
+            });
+            row_sync<GX>(false);  // ex_m is reused by the next transform
+        }
     }
 }
 
