@@ -91,6 +91,13 @@ WORKLOADS = {
         name="N=131072 custom (yB=16384, yN=32768, xA=928, xM=1024 -> m=256), 8x8 facets -> 142^2 subgrids",
         max_facets_per_rank=8, roundtrip=True, parity_radius=9.0,
     ),
+    # a catalogue entry whose facet side is not a power of two (yN = 3 * 2048): radix-3 pass + power-of-two kernels
+    # (csrc/swiftly_mixed.h); SWIFTLY_NO_MIXED=1 times the Bluestein fallback instead
+    "12k": dict(
+        params=dict(W=11.0, fov=1.0, N=12288, yB_size=4224, yN_size=6144, xA_size=448, xM_size=512),
+        sparse_radius=None,
+        name="12k[1]-n6k-512 (yN = 6144 = 3 * 2^11), 3x3 facets -> 28x28 subgrids",
+    ),
     "1k": dict(
         params=dict(W=13.5625, fov=1.0, N=1024, yB_size=416, yN_size=512, xA_size=228, xM_size=256),
         sparse_radius=None,

@@ -129,6 +129,48 @@ static int make_bluestein(swiftly_hip* h, int64_t n) {
     return rc;
 }
 
+// n = Q * 2^k with Q in {3, 5, 7, 9} and 2^k a length the power-of-two kernels take: Q and k, else false
+static bool mixed_factor(int64_t n, int* Q, int* logM) {
+    if (n <= 0) return false;
+    for (int q : {3, 5, 7, 9}) {
+        if (n % q) continue;
+        const int l = ilog2_exact(n / q);
+        if (l >= kMinLogN && (q != 3 || (n / q) % 3 != 0)) {
+            *Q = q;
+            *logM = l;
+            return true;
+        }
+    }
+    return false;
+}
+
+// Tables for a length n = Q * 2^k (swiftly_mixed.h): the full-length twiddles and the power-of-two tables of the
+// sub-transforms (with the halves their strided four-step form uses).
+static int make_mixed(swiftly_hip* h, int64_t n) {
+    int Q = 0, logM = 0;
+    if (!mixed_factor(n, &Q, &logM) || h->mixed.count(n)) return 0;
+    if (logM > kMaxLogNFloat) return 0;  // stays with the fallbacks
+    swiftly_hip::Mixed t;
+    t.Q = Q;
+    t.logM = logM;
+    std::vector<cx<float>> tf((size_t)n);
+    std::vector<cx<double>> td((size_t)n);
+    for (int64_t k = 0; k < n; k++) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+        td[(size_t)k] = {(double)cosl(a), (double)sinl(a)};
+        tf[(size_t)k] = {(float)cosl(a), (float)sinl(a)};
+    }
+    int rc = upload(h, &t.tw_f, tf);
+    if (!rc && logM <= kMaxLogNDouble) rc = upload(h, &t.tw_d, td);
+    if (!rc) rc = make_twiddles(h, logM);
+    if (!rc && logM >= kTwoPassMinLog) rc = make_twiddles(h, logM / 2);
+    if (!rc && logM >= kTwoPassMinLog) rc = make_twiddles(h, logM - logM / 2);
+    if (!rc && logM == 15) rc = make_twiddles(h, 14);
+    if (!rc && logM == 15) rc = make_twiddles(h, 13);
+    if (!rc) h->mixed[n] = t;
+    return rc;
+}
+
 // Kernel attributes (max dynamic LDS) and the memory-pool release threshold are per DEVICE state: they are set
 // once for every device a handle is created on, under a lock (handles may be created from several host threads).
 static std::mutex g_init_mutex;
@@ -226,6 +268,8 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         }
     for (int64_t len : {yN, xM, h->m})
         if (!rc) rc = make_bluestein(h, len);
+    for (int64_t len : {yN, xM, h->m})
+        if (!rc) rc = make_mixed(h, len);
     if (!rc) {
         void* hp = nullptr;
         void* dp = nullptr;
@@ -698,22 +742,31 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
 // Launch the mapped row FFT for `a` (batch of a.nbatch <= kMaxBatch items with
 // per-item offsets in `tab`).  Transforms of length >= 2^kTwoPassMinLog along
 // a strided axis are decomposed (four-step) through a stream-ordered scratch.
+// Sub-transform form (swiftly_mixed.h): qmul = Q > 1 says that `a` is sub-transform j = qadd of a length-Q*2^logn
+// transform whose radix-Q pass has run: the input is the plain scratch of that pass (a.raw_ld set by the caller, element
+// e at in + e*in_cs), the store map refers to the full length a.full_n with plain output index Q*e + j.
 template <typename R>
-static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab& tab, hipStream_t st) {
+static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab& tab, hipStream_t st, int qmul = 1,
+                          int qadd = 0) {
     a.tw = twiddles<R>(h, logn);
     if (!a.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table for 2^%d", logn);
+    const bool sub = qmul > 1;
     a.full_logn = logn;
-    a.ld_mul = a.st_mul = 1;
+    if (!sub) a.full_n = 0;
+    a.ld_mul = 1;
+    a.st_mul = qmul;
+    a.st_add0 = qadd;
     a.ld_addmul = a.st_addmul = 0;
     a.outer = 1;
     a.in_os = a.out_os = 0;
     a.tw_full = nullptr;
     a.tw_on_store = 0;
-    a.raw_ld = a.raw_st = 0;
+    a.raw_st = 0;
+    if (!sub) a.raw_ld = 0;
     if constexpr (std::is_same<R, float>::value) {
         int rc = 0;
-        if (try_col_pass(h, logn, a, tab, st, &rc)) return rc;
-        if (try_row_pass(h, logn, a, tab, st, &rc)) return rc;
+        if (!sub && try_col_pass(h, logn, a, tab, st, &rc)) return rc;
+        if (!sub && try_row_pass(h, logn, a, tab, st, &rc)) return rc;
     }
     if (logn > kMaxLogNFloat && sizeof(R) == 4)
         return fail(SWIFTLY_ERR_UNSUPPORTED, "transform length 65536 is only supported for complex64 prepare_* / finish_* "
@@ -742,6 +795,16 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     A.outer = n2;
     A.ld_mul = n2;
     A.ld_addmul = 1;
+    if (sub) {  // raw input: element y1*n2 + y2 of the sub-transform, outer index y2
+        if ((uint64_t)a.in_cs * n >= (uint64_t(1) << 32)) {
+            (void)hipFreeAsync(scratch, st);
+            return fail(SWIFTLY_ERR_PARAM, "transform length * column stride must be < 2^32");
+        }
+        A.in_cs = a.in_cs * (unsigned)n2;
+        A.in_os = (long long)a.in_cs;
+    }
+    A.st_mul = 1;
+    A.st_add0 = 0;
     A.raw_st = 1;
     A.out = (cx<R>*)scratch;
     A.out_rs = 1;
@@ -766,8 +829,9 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
         B.rm_mod = 0;
         B.in_rowmap = nullptr;  // the scratch is indexed by plain (k1, y2), never through the compaction map
         B.outer = n1;
-        B.st_mul = n1;
-        B.st_addmul = 1;
+        B.st_mul = qmul * n1;
+        B.st_addmul = qmul;
+        B.st_add0 = qadd;
         B.conj_ld = 0;
         rc = launch_checked(l2, B, tab, st);
     }
@@ -853,6 +917,59 @@ static int run_rows_bluestein(swiftly_hip* h, int64_t n, RowsArgs<R>& a, const O
     return rc;
 }
 
+// Transform length n = Q * 2^k (Q in {3, 5, 7, 9}): one radix-Q pass (swiftly_mixed.h) into a stream-ordered scratch,
+// then the Q power-of-two sub-transforms with the store map of the primitive.
+template <typename R>
+static int run_rows_mixed(swiftly_hip* h, int64_t n, const swiftly_hip::Mixed& mx, RowsArgs<R>& a, const OffTab& tab,
+                          hipStream_t st) {
+    const cx<R>* tw_n;
+    if constexpr (sizeof(R) == 4) tw_n = mx.tw_f; else tw_n = mx.tw_d;
+    if (!tw_n) return fail(SWIFTLY_ERR_UNSUPPORTED, "transform length %lld: no %s tables", (long long)n, sizeof(R) == 8 ? "complex128" : "complex64");
+    const int Q = mx.Q, logM = mx.logM;
+    const long long M = 1ll << logM;
+    const int nb = a.nbatch > 0 ? a.nbatch : 1;
+    const long long W = a.nrows;
+    if ((uint64_t)n * (uint64_t)W >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "rows * transform length must be < 2^32 for lengths that are not a power of two; split the call");
+    void* scratch = nullptr;
+    HIP_TRY(hipMallocAsync(&scratch, (size_t)nb * (size_t)n * (size_t)W * sizeof(cx<R>), st));
+    MixedArgs<R> X;
+    std::memset(&X, 0, sizeof X);
+    X.Q = Q; X.M = (int)M; X.n = (int)n;
+    for (int r = 0; r < Q; r++) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)r / (long double)Q;
+        X.wq[r] = cx<R>{(R)cosl(ang), (R)sinl(ang)};
+    }
+    X.tw_n = tw_n;
+    X.scratch = (cx<R>*)scratch;
+    X.s_b = (long long)n * W;
+    if (a.rowfast) {  // rows are the contiguous direction: scratch[b][j][y2][row]
+        X.s_row = 1; X.s_y = W; X.s_j = M * W;
+    } else {          // scratch[b][row][j][y2]
+        X.s_row = n; X.s_j = M; X.s_y = 1;
+    }
+    RowsArgs<R> P = a;
+    P.full_n = (int)n;
+    int e = launch_mixed_pass(Q, P, tab, X, nb, st);
+    int rc = e ? fail(SWIFTLY_ERR_HIP, "kernel launch failed (radix-%d pass): %s", Q, hipGetErrorString((hipError_t)e)) : 0;
+    for (int j = 0; j < Q && !rc; j++) {
+        RowsArgs<R> B = a;
+        B.in = (const cx<R>*)scratch + (long long)j * X.s_j;
+        B.in_rs = X.s_row;
+        B.in_cs = (unsigned)X.s_y;
+        B.in_bs = X.s_b;
+        B.raw_ld = 1;
+        B.conj_ld = 0;        // applied by the pass
+        B.rm_mod = 0;
+        B.in_rowmap = nullptr;
+        B.full_n = (int)n;
+        rc = run_rows_chunk(h, logM, B, tab, st, Q, j);
+    }
+    hipError_t e2 = hipFreeAsync(scratch, st);
+    if (!rc && e2 != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e2));
+    return rc;
+}
+
 // `fill(b, tab_index)` sets the per-item offsets of batch item b into the
 // OffTab; called once per item per chunk.  `nlen` = transform length, `logn` = its log2 or -1.
 template <typename R, class Fill>
@@ -885,7 +1002,18 @@ static int run_rows(swiftly_hip* h, int64_t nlen, int logn, RowsArgs<R>& a, cons
         c.nbatch = nb;
         c.st_win_bs = bt.mask_bs;
         if (win0) c.st.win = win0 + b0 * bt.mask_bs;
-        if (int rc = logn < 0 ? run_rows_bluestein(h, nlen, c, tab, st) : run_rows_chunk(h, logn, c, tab, st)) return rc;
+        int rc;
+        if (logn >= 0) {
+            rc = run_rows_chunk(h, logn, c, tab, st);
+        } else {
+            // SWIFTLY_NO_MIXED=1 (read per call): Bluestein for every length that is not a power of two (A/B, tests)
+            const char* no_mixed = getenv("SWIFTLY_NO_MIXED");
+            auto it = h->mixed.find(nlen);
+            const bool have = it != h->mixed.end() && (sizeof(R) == 4 ? it->second.tw_f != nullptr : it->second.tw_d != nullptr);
+            rc = (have && !(no_mixed && atoi(no_mixed))) ? run_rows_mixed(h, nlen, it->second, c, tab, st)
+                                                          : run_rows_bluestein(h, nlen, c, tab, st);
+        }
+        if (rc) return rc;
     }
     return 0;
 }

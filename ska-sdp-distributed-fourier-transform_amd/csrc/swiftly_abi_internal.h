@@ -24,6 +24,7 @@
 #include "swiftly_groupfinish.h"
 #include "swiftly_rows.h"
 #include "swiftly_bluestein.h"
+#include "swiftly_mixed.h"
 #include <complex>
 
 using namespace swf;
@@ -74,6 +75,13 @@ struct swiftly_hip {
         cx<double>* spec_d = nullptr;
     };
     std::map<int64_t, Blu> blu;
+    // lengths n = Q * 2^k, Q in {3, 5, 7, 9} (swiftly_mixed.h): exp(-2 pi i r / n), r < n
+    struct Mixed {
+        int Q = 0, logM = 0;
+        cx<float>* tw_f = nullptr;
+        cx<double>* tw_d = nullptr;
+    };
+    std::map<int64_t, Mixed> mixed;
     std::vector<void*> allocs;
     // sticky error word of the in-launch hand-offs (swiftly_fourstep.h): pinned host memory the device writes on a
     // timed-out wait; checked at the start of every call that launches such a kernel and by swiftly_hip_async_error

@@ -42,7 +42,12 @@ struct RowsArgs {
     // is the plain full-length index  i*ld_mul + ld_add  on load and
     // i*st_mul + st_add  on store, where *_add = (outer row index) * *_addmul.
     // Plain (non-decomposed) use: mul = 1, addmul = 0, outer = 1.
-    int full_logn;       // log2 of the full transform length the maps refer to
+    int full_logn;       // log2 of the full (power-of-two) transform length of a decomposed transform
+    // Modulus of the load / store maps: 0 = 2^full_logn.  Set to n = Q * 2^k when this launch is one of the Q
+    // power-of-two sub-transforms behind the radix-Q pass of swiftly_mixed.h; the plain output index is then
+    // (e*st_mul + o*st_addmul) + st_add0 with st_mul, st_addmul premultiplied by Q and st_add0 = j.
+    int full_n;
+    int st_add0;
     int ld_mul, ld_addmul;
     int st_mul, st_addmul;
     int outer;           // rows are (inner, outer): row = inner*outer + o  -- see kernel
@@ -107,7 +112,9 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
     const bool live = grow < total;
     const int o = live ? (int)(grow / A.nrows) : 0;
     const long long row = live ? grow % A.nrows : 0;
-    const int FN = 1 << A.full_logn;
+    const int FS = 1 << A.full_logn;            // four-step twiddle period
+    const int FN = A.full_n > 0 ? A.full_n : FS;  // modulus of the maps (any even length)
+    auto wrapn = [FN](int v) { return v >= FN ? v - FN : v; };
     long long in_row = row;
     if (A.rm_mod > 0) {
         int r1 = (int)row + A.rm_inner;
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
             constexpr int v = decltype(vI)::value;
             const int i = t + v * T;
             const int pi = i * A.ld_mul + ld_add;        // plain full-length index
-            const int ci = (pi + (FN >> 1)) & (FN - 1);  // centred index
-            const int q = (ci + ld_a) & (FN - 1);
+            const int ci = wrapn(pi + (FN >> 1));  // centred index
+            const int q = wrapn(ci + ld_a);
             const bool ok = q < A.ld.len;
             const int qs = ok ? q : 0;
             int idx = qs + ld_c;
@@ -170,12 +177,12 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
         });
     }
 
-    const int st_add = o * A.st_addmul;
+    const int st_add = o * A.st_addmul + A.st_add0;
     fft_phases<G, R, 0>(x, t, rb, rowfast, smem, A.tw, [&](int e, cx<R> v) {
         if (!live) return;
         if (A.tw_on_store) {
             // four-step twiddle exp(-/+ 2 pi i * e * o / FN)
-            cx<R> w = A.tw_full[((unsigned)e * (unsigned)o) & (unsigned)(FN - 1)];
+            cx<R> w = A.tw_full[((unsigned)e * (unsigned)o) & (unsigned)(FS - 1)];
             v = cmul(v, w);
         }
         v.x *= A.scale;
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
             return;
         }
         const int pk = e * A.st_mul + st_add;
-        const int ck = (pk + (FN >> 1)) & (FN - 1);
-        const int d = (ck + st_a) & (FN - 1);
+        const int ck = wrapn(pk + (FN >> 1));
+        const int d = wrapn(ck + st_a);
         if (d < A.st.len) {
             int idx = d + st_c;
             if (idx >= A.st.mod) idx -= A.st.mod;

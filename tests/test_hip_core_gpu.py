@@ -274,14 +274,15 @@ def test_fft_lengths_c128(logn):
 def test_unsupported_length_raises():
     from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
 
-    # non-power-of-two lengths run through Bluestein (tests/test_hip_nonpow2_gpu.py) as long as the convolution
-    # length 2^ceil(log2(2n-1)) has a kernel: <= 65536 in complex64, <= 8192 in complex128.  Beyond that the
-    # constructor still works (reference tests/test_core.py:82-90 only constructs) and transforms are refused loudly.
-    core = SwiftlyCoreHip(11.0, 24576, 1024, 12288)  # yN = 3 * 4096 -> L = 32768
+    # lengths Q * 2^k (Q in 3, 5, 7, 9) run natively, any other length that is not a power of two through Bluestein
+    # (tests/test_hip_nonpow2_gpu.py) as long as the convolution length 2^ceil(log2(2n-1)) has a kernel: <= 65536 in
+    # complex64, <= 8192 in complex128.  Beyond that the constructor still works (reference tests/test_core.py:82-90
+    # only constructs) and transforms are refused loudly.
+    core = SwiftlyCoreHip(11.0, 22528, 1024, 11264)  # yN = 11 * 1024 -> L = 32768
     with pytest.raises(NotImplementedError):
         core.prepare_facet(numpy.zeros(500, dtype=complex), 0, axis=0)
     got = core.prepare_facet(numpy.zeros(500, dtype=numpy.complex64), 0, axis=0)  # fine in complex64
-    assert got.shape == (12288,)
+    assert got.shape == (11264,)
 
 
 def test_long_rows_yN32768_c64():
