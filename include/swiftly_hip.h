@@ -30,10 +30,12 @@
  *    swiftly_hip_last_error() (thread local).  Nothing throws across the ABI.
  *  - transform lengths (yN, xM, m = xM*yN/N): powers of two from 4 to 32768 run on native kernels in both
  *    precisions (complex128 up to 8192 along a unit-stride axis); 65536 is supported in complex64 for prepare_* /
- *    finish_* along a unit-stride axis and along the strided axis of contiguous rows.  Any other length (the
- *    3, 5, 7, 9 x 2^k sizes of the reference's parameter catalogue) goes through a Bluestein fallback on the
- *    power-of-two kernels (correct, ~10x the traffic) as long as 2^ceil(log2(2n-1)) <= 65536 (complex64) /
- *    8192 (complex128); beyond that the call returns SWIFTLY_ERR_UNSUPPORTED (handle creation still succeeds).
+ *    finish_* along a unit-stride axis and along the strided axis of contiguous rows.  Lengths Q * 2^k with
+ *    Q in {3, 5, 7, 9} -- every other length of the reference's parameter catalogue, yN up to 57344 -- run natively
+ *    too: one radix-Q pass in front of the power-of-two kernels (2^k <= 32768 in complex64, <= 8192 in complex128;
+ *    rows * length < 2^32 per call).  Any other length goes through a Bluestein fallback on the power-of-two kernels
+ *    (correct, ~10x the traffic) as long as 2^ceil(log2(2n-1)) <= 65536 (complex64) / 8192 (complex128); beyond
+ *    that the call returns SWIFTLY_ERR_UNSUPPORTED (handle creation still succeeds).
  *  - a handle is immutable after creation and may be used concurrently from
  *    several host threads / streams (the reference scatters one core object
  *    to all Dask worker threads, api.py:145-147).  Handles may be created
