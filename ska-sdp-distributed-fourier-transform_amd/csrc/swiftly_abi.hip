@@ -130,12 +130,12 @@ static int make_bluestein(swiftly_hip* h, int64_t n) {
 }
 
 // n = Q * 2^k with Q in {3, 5, 7, 9} and 2^k a length the power-of-two kernels take: Q and k, else false
-static bool mixed_factor(int64_t n, int* Q, int* logM) {
+bool mixed_factor(int64_t n, int* Q, int* logM) {
     if (n <= 0) return false;
     for (int q : {3, 5, 7, 9}) {
         if (n % q) continue;
         const int l = ilog2_exact(n / q);
-        if (l >= kMinLogN && (q != 3 || (n / q) % 3 != 0)) {
+        if (l >= kMinLogN) {
             *Q = q;
             *logM = l;
             return true;
@@ -445,8 +445,11 @@ int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz
 thread_local void* t_call_ws = nullptr;
 thread_local size_t t_call_ws_bytes = 0;
 
+// Sub-transform form (qmul = Q > 0, swiftly_mixed.h): the input is the plain scratch of the radix-Q pass (element y of
+// the length-2^logn sub-transform j = qadd at row y of `c.in`), the store map of `c` refers to the full length full_n
+// with plain output index Q*k + j.
 int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st, void* ws,
-                  size_t ws_bytes) {
+                  size_t ws_bytes, int qmul, int qadd, int full_n) {
     if (!ws && t_call_ws) {
         ws = t_call_ws;
         ws_bytes = t_call_ws_bytes;
@@ -460,6 +463,10 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         ColPassArgs one = c;
         one.tw = twiddles<float>(h, logn);
         if (!one.tw) return -1;
+        if (qmul > 0) {
+            one.full_logn = logn; one.full_n = full_n; one.ld_plain = 1; one.st_qmul = qmul; one.st_qadd = qadd;
+            one.ld_mul = one.st_mul = 1;
+        }
         return launch_col_checked(logn, 2, one, cz, 1, nb, st);
     }
     const int n1 = 1 << l1, n2 = 1 << l2;
@@ -483,7 +490,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     const int fused_env = fused_s ? atoi(fused_s) : 0;
     const int lag_env = lag_s ? std::max(1, atoi(lag_s)) : 4;
     const long long chunks = (long long)nb * ((W + 63) / 64);
-    const bool fused = fused_env && Ws == (long long)W && !c.gs && cz.nb <= kFsZB && chunks < (1 << 24) &&
+    const bool fused = fused_env && Ws == (long long)W && !c.gs && cz.nb <= kFsZB && chunks < (1 << 24) && qmul == 0 &&
                        col_fourstep_supported(l1, l2);
     const size_t scratch_bytes = (size_t)nb * n * (size_t)Ws * sizeof(cx<float>);
     const size_t cnt_bytes = fused ? (((size_t)chunks * sizeof(unsigned) + 255) & ~size_t(255)) : 0;
@@ -532,6 +539,9 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.ld_mul = n2;
         A.out_i_rows = n2; A.out_o_rows = 1;
         A.tw = tw1; A.tw_full = twf;
+        if (qmul > 0) {
+            A.full_logn = logn; A.full_n = 0; A.ld_plain = 1; A.st_qmul = 0;
+        }
         A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
         A.col_win = nullptr; A.st_rowmap = nullptr; A.st_win = nullptr; A.st_win2 = nullptr;
         ColZ za = cz;
@@ -553,6 +563,9 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         B.out = c.out + c0;
         B.st_mul = n1;
         B.tw = tw2; B.tw_full = twf;
+        if (qmul > 0) {
+            B.full_logn = logn; B.full_n = full_n; B.st_qmul = qmul; B.st_qadd = qadd;
+        }
         B.conj_ld = 0;
         if (B.col_win) B.col_win += c0;
         if (!fused) {
@@ -751,14 +764,17 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     a.tw = twiddles<R>(h, logn);
     if (!a.tw) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle table for 2^%d", logn);
     const bool sub = qmul > 1;
+    const bool all_j = sub && qadd < 0;  // all Q sub-transforms in this launch: outer index = j, input at in + j*in_os
     a.full_logn = logn;
     if (!sub) a.full_n = 0;
     a.ld_mul = 1;
     a.st_mul = qmul;
-    a.st_add0 = qadd;
-    a.ld_addmul = a.st_addmul = 0;
-    a.outer = 1;
-    a.in_os = a.out_os = 0;
+    a.st_add0 = all_j ? 0 : qadd;
+    a.ld_addmul = 0;
+    a.st_addmul = all_j ? 1 : 0;
+    a.outer = all_j ? qmul : 1;
+    if (!all_j) a.in_os = 0;
+    a.out_os = 0;
     a.tw_full = nullptr;
     a.tw_on_store = 0;
     a.raw_st = 0;
@@ -952,7 +968,10 @@ static int run_rows_mixed(swiftly_hip* h, int64_t n, const swiftly_hip::Mixed& m
     P.full_n = (int)n;
     int e = launch_mixed_pass(Q, P, tab, X, nb, st);
     int rc = e ? fail(SWIFTLY_ERR_HIP, "kernel launch failed (radix-%d pass): %s", Q, hipGetErrorString((hipError_t)e)) : 0;
-    for (int j = 0; j < Q && !rc; j++) {
+    // the Q sub-transforms: ONE launch with j as the kernel's outer index when the sub-transform is a single pass
+    // (qadd = -1), one four-step pair per j along a strided axis
+    const bool one_launch = !(a.rowfast && logM >= kTwoPassMinLog);
+    for (int j = 0; j < (one_launch ? 1 : Q) && !rc; j++) {
         RowsArgs<R> B = a;
         B.in = (const cx<R>*)scratch + (long long)j * X.s_j;
         B.in_rs = X.s_row;
@@ -963,7 +982,8 @@ static int run_rows_mixed(swiftly_hip* h, int64_t n, const swiftly_hip::Mixed& m
         B.rm_mod = 0;
         B.in_rowmap = nullptr;
         B.full_n = (int)n;
-        rc = run_rows_chunk(h, logM, B, tab, st, Q, j);
+        B.in_os = X.s_j;      // (used by the one-launch form only)
+        rc = run_rows_chunk(h, logM, B, tab, st, Q, one_launch ? -1 : j);
     }
     hipError_t e2 = hipFreeAsync(scratch, st);
     if (!rc && e2 != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e2));
@@ -1328,8 +1348,9 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: complex64 only");
     CHECK_FACET_SIZE();
     const int yN = (int)h->yN;
-    if (h->log_yN < 3 || h->log_yN > 16)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: padded facet size %d not supported (power of two, 8 .. 65536)", yN);
+    const bool mixed_yN = h->log_yN < 0 && h->mixed.count(h->yN) && h->mixed.at(h->yN).tw_f;
+    if (!mixed_yN && (h->log_yN < 3 || h->log_yN > 16))
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: padded facet size %d not supported (power of two 8 .. 65536, or Q * 2^k with Q = 3, 5, 7, 9)", yN);
     if (rows < 0 || rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "bad row count");
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN)
         return fail(SWIFTLY_ERR_PARAM, "band [%lld, +%lld) is not a cyclic range of [0, %d)", (long long)band_start, (long long)band_len, yN);

@@ -141,7 +141,9 @@ struct CallWorkspace {
     ~CallWorkspace() { t_call_ws = nullptr; t_call_ws_bytes = 0; }
 };
 int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz, int W, int nb, hipStream_t st,
-                  void* ws = nullptr, size_t ws_bytes = 0);
+                  void* ws = nullptr, size_t ws_bytes = 0, int qmul = 0, int qadd = 0, int full_n = 0);
+// rows kernels / radix-Q pass (swiftly_abi.hip)
+bool mixed_factor(int64_t n, int* Q, int* logM);
 
 // Facet tables of the row-wise fused kernels (swiftly_sumfinish.h), grouped by off1: entries of one group are adjacent.
 template <class Args>

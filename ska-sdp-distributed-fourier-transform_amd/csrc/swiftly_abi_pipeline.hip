@@ -133,6 +133,107 @@ int64_t swiftly_hip_band_columns_for(const swiftly_hip_t* h, int64_t band_len) {
 }
 
 } // extern "C" (helpers follow)
+// K2 for yN = Q * 2^k (swiftly_mixed.h): per wave, the radix-Q pass over the window columns of every facet (the
+// generic pass kernel with lanes along the columns: window gather through the modular row map, zero padding and facet
+// offset through the load map, one batch item per facet) into a scratch [facet][j][y2][column], then the Q
+// power-of-two sub-transforms along the strided axis with the column-tile passes, whose store side carries the row
+// map of the wave with plain output index Q*k + j.  PLAIN band layout only (the parity-split layout belongs to the
+// power-of-two long-row kernel).
+static int prepare_facet_columns_mixed(swiftly_hip_t* h, const void* in, int64_t rows, int64_t in_row_stride,
+                                       int64_t in_facet_stride, int64_t nfacets, const int64_t* facet_off0s,
+                                       int64_t band_start, int64_t band_len, int64_t nwaves, const int64_t* wave_off1s,
+                                       void* out, int64_t out_row_stride, int64_t out_facet_stride,
+                                       int64_t out_wave_stride, const int32_t* rowmaps, int64_t rowmap_stride,
+                                       void* stream, void* ws, size_t ws_bytes) {
+    const int yN = (int)h->yN, m = (int)h->m;
+    auto it = h->mixed.find(h->yN);
+    if (it == h->mixed.end() || !it->second.tw_f)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: padded facet size %d is neither a power of two nor Q * 2^k (Q = 3, 5, 7, 9)", yN);
+    if (band_is_split(h)) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: internal: split band layout");
+    const int Q = it->second.Q, logM = it->second.logM;
+    const long long M = 1ll << logM;
+    if ((uint64_t)rows * (uint64_t)in_row_stride >= (uint64_t(1) << 32) || (uint64_t)yN * (uint64_t)out_row_stride >= (uint64_t(1) << 32) ||
+        (uint64_t)yN * (uint64_t)m >= (uint64_t(1) << 32))
+        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
+    const int lo = yN / 2 - (int)(rows / 2);
+    hipStream_t st = (hipStream_t)stream;
+    // workspace: [radix-Q scratch: nf * yN * m][four-step scratch of the sub-transforms: nf * M * m]
+    const int per_f_cap = (int)std::min<int64_t>(kMaxBatch, kColZF);
+    for (int64_t f0 = 0; f0 < nfacets; f0 += per_f_cap) {
+        const int nf = (int)std::min<int64_t>(per_f_cap, nfacets - f0);
+        const size_t radix_bytes = (size_t)nf * (size_t)yN * (size_t)m * sizeof(cx<float>);
+        const size_t sub_bytes = (size_t)nf * (size_t)M * (size_t)m * sizeof(cx<float>) + 4096;
+        void* own = nullptr;
+        char* base = (char*)ws;
+        if (!ws || ws_bytes < radix_bytes + sub_bytes) {
+            HIP_TRY(hipMallocAsync(&own, radix_bytes + sub_bytes, st));
+            base = (char*)own;
+        }
+        int rc = 0;
+        for (int64_t w = 0; w < nwaves && !rc; w++) {
+            const int64_t s1 = floordiv(wave_off1s[w] * h->yN, h->N);
+            RowsArgs<float> a;
+            std::memset(&a, 0, sizeof a);
+            a.in = (const cx<float>*)in + f0 * in_facet_stride;
+            a.in_rs = 1;                            // "rows" of the pass = the m window columns (contiguous)
+            a.in_cs = (unsigned)in_row_stride;      // transform index = facet row
+            a.in_bs = in_facet_stride;
+            a.nrows = m;
+            a.nbatch = nf;
+            a.rowfast = 1;
+            a.ld = AxisMap<float>{0, (int)rows, 0, (int)rows, nullptr, nullptr};  // window already applied by prepare_facet_band
+            a.conj_ld = 1;
+            a.scale = 1.f;
+            a.rm_mod = m;
+            a.rm_inner = pmod(-s1, m);
+            a.rm_outer = pmod(yN / 2 - m / 2 + s1 - band_start, yN);  // plain band: physical column = logical - band_start
+            a.rm_full = yN;
+            a.full_n = yN;
+            OffTab tab;
+            tab.use = 1;
+            for (int f = 0; f < nf; f++) tab.ld_a[f] = pmod(-(facet_off0s[f0 + f] + lo), yN);
+            MixedArgs<float> X;
+            std::memset(&X, 0, sizeof X);
+            X.Q = Q; X.M = (int)M; X.n = yN;
+            for (int r = 0; r < Q; r++) {
+                const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)r / (long double)Q;
+                X.wq[r] = cx<float>{(float)cosl(ang), (float)sinl(ang)};
+            }
+            X.tw_n = it->second.tw_f;
+            X.scratch = (cx<float>*)base;
+            X.s_row = 1; X.s_y = m; X.s_j = M * m; X.s_b = (long long)yN * m;
+            int e = launch_mixed_pass(Q, a, tab, X, nf, st);
+            if (e) { rc = fail(SWIFTLY_ERR_HIP, "kernel launch failed (radix-%d pass): %s", Q, hipGetErrorString((hipError_t)e)); break; }
+            for (int j = 0; j < Q && !rc; j++) {
+                ColPassArgs c;
+                std::memset(&c, 0, sizeof c);
+                c.ncols = m;
+                c.in = (const cx<float>*)base + (long long)j * X.s_j;
+                c.in_pitch = (unsigned)m;
+                c.in_bs = X.s_b;
+                c.out = (cx<float>*)out + f0 * out_facet_stride + w * out_wave_stride;
+                c.out_pitch = (unsigned)out_row_stride;
+                c.out_bs = out_facet_stride;
+                c.ld_mul = c.st_mul = 1;
+                c.st_a = 0; c.st_len = yN; c.st_c = 0; c.st_mod = yN;
+                c.scale = (float)(1.0 / yN);
+                c.conj_ld = 0; c.conj_st = 1;
+                c.st_rowmap = rowmaps ? rowmaps + w * rowmap_stride : nullptr;
+                c.st_rowmap_bs = 0;
+                const int r2 = col_transform(h, logM, c, plain_colz(), m, nf, st, base + radix_bytes, sub_bytes, Q, j, yN);
+                if (r2 == -1) rc = fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: sub-transform length %lld not supported", M);
+                else rc = r2;
+            }
+        }
+        if (own) {
+            hipError_t e2 = hipFreeAsync(own, st);
+            if (!rc && e2 != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e2));
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // K2 for `nfacets` facets x `nwaves` waves: item (f, w) gathers the window of wave_off1s[w] from band buffer f and
 // writes out + f*out_facet_stride + w*out_wave_stride through row map  rowmaps + w*rowmap_stride  (or none).
 static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,
@@ -144,10 +245,14 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
     if (!h || !in || !out || !facet_off0s || !wave_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: complex64 only");
     const int yN = (int)h->yN, m = (int)h->m;
-    if (h->log_yN < 0 || h->log_m < 6) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: sizes not supported");
+    if (h->log_m < 6) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_columns: sizes not supported");
     if (rows <= 0 || rows >= yN) return fail(SWIFTLY_ERR_PARAM, "facet size %lld must be in [1, yN_size - 1]", (long long)rows);
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
     if (nfacets <= 0 || nwaves <= 0) return 0;
+    if (h->log_yN < 0)
+        return prepare_facet_columns_mixed(h, in, rows, in_row_stride, in_facet_stride, nfacets, facet_off0s, band_start,
+                                           band_len, nwaves, wave_off1s, out, out_row_stride, out_facet_stride,
+                                           out_wave_stride, rowmaps, rowmap_stride, stream, ws, ws_bytes);
     // only `rows` input rows are ever read (the rest of the padded axis is zero fill)
     if ((uint64_t)rows * (uint64_t)in_row_stride >= (uint64_t(1) << 32) || (uint64_t)yN * (uint64_t)out_row_stride >= (uint64_t(1) << 32))
         return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
@@ -242,7 +347,8 @@ static int transform_contributions_impl(swiftly_hip_t* h, int dtype, const void*
     if (layout < 0 || layout > 2) return fail(SWIFTLY_ERR_PARAM, "bad layout %d", layout);
     if (layout != 2 && !subgrid_offs) return fail(SWIFTLY_ERR_PARAM, "null argument");
     const int m = (int)h->m, yN = (int)h->yN;
-    if (h->log_m < kColPassMinLog || h->log_m > kColPassMaxLog || h->log_yN < 0)
+    // (layout 0 gathers columns with masks of the padded facet size; the row-window layouts take any yN)
+    if (h->log_m < kColPassMinLog || h->log_m > kColPassMaxLog || (layout == 0 && h->log_yN < 0))
         return fail(SWIFTLY_ERR_UNSUPPORTED, "transform_contributions: contribution size %d not supported", m);
     if (nfacets <= 0 || nsub <= 0) return 0;
     if ((uint64_t)yN * (uint64_t)in_row_stride + (uint64_t)yN >= (uint64_t(1) << 32))

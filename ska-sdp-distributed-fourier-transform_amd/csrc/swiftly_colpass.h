@@ -65,7 +65,11 @@ struct ColPassArgs {
     // flag is 0 has not been written yet and is stored plainly (no read-modify-write, no zero fill needed)
     const unsigned char* touched;
     int ncols;                      // columns (= rows of the primitive)
-    int full_logn;                  // log2 of the full transform length the maps refer to
+    int full_logn;                  // log2 of the full (power-of-two) transform length of a decomposed transform
+    // Sub-transform j of a length n = Q * 2^full_logn transform behind the radix-Q pass of swiftly_mixed.h (0 = off):
+    // the input is the plain scratch of that pass (ld_plain: logical row = plain index, no map), the store map refers to
+    // the full length full_n (any even number) with plain output index Q*k + j (st_qmul, st_qadd)
+    int full_n, ld_plain, st_qmul, st_qadd;
     // load: raw -> row = o*in_o_rows + i*in_i_rows ; mapped -> plain index i*ld_mul + o through the map
     int raw_ld;
     int in_i_rows, in_o_rows;
@@ -199,7 +203,9 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
     const int clane = HALF ? (lane & 31) : lane;      // column within the tile
     const int col = bx * G::COLS + clane;
     const bool live = col < A.ncols;
-    const int FN = 1 << A.full_logn;
+    const int FS = 1 << A.full_logn;              // four-step period / power-of-two length
+    const int FN = A.full_n > 0 ? A.full_n : FS;  // modulus of the maps
+    auto wrapn = [FN](int v) { return v >= FN ? v - FN : v; };
     const int zf = z / cz.nb, zb = z - zf * cz.nb;  // uniform
     int scol = col;
     if (cz.flags & (kZColGather | kZColScatter)) {  // uniform
@@ -249,11 +255,11 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
             in_row = o * A.in_o_rows + i * A.in_i_rows;
         } else {
             const int pi = i * A.ld_mul + o;
-            const int ci = (pi + (FN >> 1)) & (FN - 1);
-            const int q = (ci + ld_a) & (FN - 1);
-            int idx = q + ld_c;
-            if (idx >= A.ld_mod) idx -= A.ld_mod;
-            const bool ok = q < A.ld_len;
+            const int ci = wrapn(pi + (FN >> 1));
+            const int q = A.ld_plain ? pi : wrapn(ci + ld_a);
+            int idx = q + (A.ld_plain ? 0 : ld_c);
+            if (!A.ld_plain && idx >= A.ld_mod) idx -= A.ld_mod;
+            const bool ok = A.ld_plain || q < A.ld_len;
             if constexpr (GS) {
                 // (resolved here, outside the load loop's lambda: a by-reference capture of `cz` with a dynamic
                 // index would make the compiler copy the whole table to scratch)
@@ -289,11 +295,12 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
         const int e = ((j - k) << LR) + k + (r << LNS);
         if constexpr (RAW_ST) {
             out_row = o * A.out_o_rows + e * A.out_i_rows;
-            out_tw = tw_full[((unsigned)e * (unsigned)o) & (unsigned)(FN - 1)];
+            out_tw = tw_full[((unsigned)e * (unsigned)o) & (unsigned)(FS - 1)];
         } else {
-            const int pk = e * A.st_mul + o;
-            const int ck = (pk + (FN >> 1)) & (FN - 1);
-            const int d = (ck + st_a) & (FN - 1);
+            int pk = e * A.st_mul + o;
+            if (A.st_qmul > 0) pk = pk * A.st_qmul + A.st_qadd;
+            const int ck = wrapn(pk + (FN >> 1));
+            const int d = wrapn(ck + st_a);
             int idx = d + A.st_c;
             if (idx >= A.st_mod) idx -= A.st_mod;
             const bool ok = d < A.st_len;

@@ -474,13 +474,26 @@ class SwiftlyCoreHip:
         return out
 
     # ------------------------------------------------------------------ contiguous-axis-first pipeline
-    def _logs(self):
+    def _logs(self, need=("yN", "xM", "m")):
+        """log2 of the transform lengths named in ``need``; None unless all of THOSE are powers of two"""
         logs = {}
         for name, n in (("yN", self.yN_size), ("xM", self.xM_size), ("m", self.xM_yN_size)):
+            if name not in need:
+                continue
             if n <= 0 or n & (n - 1):
                 return None
             logs[name] = n.bit_length() - 1
         return logs
+
+    def _mixed_yN(self):
+        """``(Q, k)`` when ``yN_size = Q * 2^k`` with Q in {3, 5, 7, 9} (csrc/swiftly_mixed.h), else None"""
+        n = self.yN_size
+        for q in (3, 5, 7, 9):
+            if n % q == 0:
+                r = n // q
+                if r >= 8 and r & (r - 1) == 0:
+                    return q, r.bit_length() - 1
+        return None
 
     MAX_FUSED_FACETS = 64  # kSumFinishMaxFacets (csrc/swiftly_sumfinish.h): facets summed by one sum_finish_facets call
 
@@ -488,7 +501,7 @@ class SwiftlyCoreHip:
         """True when transform_contributions + sum_finish_facets (include/swiftly_hip.h) exist for these sizes
         (and, when given, for ``n_facets`` facets: the facet sum runs inside one kernel)."""
         torch = _torch()
-        logs = self._logs()
+        logs = self._logs(("xM", "m"))
         if logs is None or (dtype is not None and dtype != torch.complex64):
             return False
         if n_facets is not None and n_facets > self.MAX_FUSED_FACETS:
@@ -500,7 +513,14 @@ class SwiftlyCoreHip:
         """True when the contiguous-axis-first forward kernels (include/swiftly_hip.h) exist for these sizes."""
         # K1: the two-workgroup band kernel for yN = 16384 .. 65536 (band-pruned output), the generic contiguous-axis
         # transform below that (whole padded axis kept)
-        return self.supports_fused_subgrid(dtype, n_facets) and 6 <= self._logs()["yN"] <= 16 and self._logs()["m"] >= 6
+        # yN = Q * 2^k (r3): the radix-Q pass in front of the same kernels, whole padded axis kept, forward only
+        if not self.supports_fused_subgrid(dtype, n_facets) or self._logs(("m",))["m"] < 6:
+            return False
+        logs = self._logs(("yN",))
+        if logs is not None:
+            return 6 <= logs["yN"] <= 16
+        mixed = self._mixed_yN()
+        return mixed is not None and 6 <= mixed[1] <= 15
 
     def supports_backward_band(self, dtype=None):
         """True when accumulate_facet_columns / finish_facet_band (include/swiftly_hip.h) exist for these sizes."""
@@ -511,9 +531,9 @@ class SwiftlyCoreHip:
     def band_for_offsets(self, subgrid_offs):
         """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains
         the ``xM_yN_size`` window of every given subgrid offset (core.py:243-253); ``(0, yN_size)`` = all."""
-        logs = self._logs()
+        logs = self._logs(("yN",))
         if logs is None or not 14 <= logs["yN"] <= 16:
-            return 0, self.yN_size  # short padded facets keep the whole axis (plain band layout, swiftly_hip.h)
+            return 0, self.yN_size  # short / non-power-of-two padded facets keep the whole axis (plain band layout)
         return band_range(self.N, self.yN_size, self.xM_yN_size, subgrid_offs)
 
     def band_columns(self, band):
@@ -554,7 +574,7 @@ class SwiftlyCoreHip:
             out = torch.empty((F, n_rows, m), dtype=bands.dtype, device=self._device)
         # one wave through the multi-wave entry point: it takes the caller-owned four-step scratch (a stream-ordered
         # allocation per call costs host time, see swiftly_hip.h)
-        scr = self.scratch("k2", F * self.yN_size * m * 8)
+        scr = self.scratch("k2", self._k2_scratch_bytes(F))
         cvp = ctypes.c_void_p
         _lib.check(
             self._lib.swiftly_hip_prepare_facet_columns_waves(
@@ -604,6 +624,11 @@ class SwiftlyCoreHip:
         of the opt-in fused four-step transform has timed out.  Synchronise first to check a specific call."""
         return int(self._lib.swiftly_hip_async_error(self._handle))
 
+    def _k2_scratch_bytes(self, F):
+        """four-step scratch of K2 for F facets; yN = Q * 2^k also holds the output of the radix-Q pass"""
+        n = F * self.yN_size * self.xM_yN_size * 8
+        return n if self._mixed_yN() is None else 2 * n + 4096
+
     SCRATCH_TAIL_BYTES = 1 << 16
 
     def scratch(self, name, nbytes):
@@ -628,7 +653,7 @@ class SwiftlyCoreHip:
         ``[F, S, m, m]`` tensor, or a flat send buffer with ``g_layout = (offsets[S], facet_strides[S])``."""
         F, S = Q.shape[0], len(sub_off0s)
         cvp = ctypes.c_void_p
-        scr = self.scratch("k2", F * self.yN_size * self.xM_yN_size * 8) if compute_q else None
+        scr = self.scratch("k2", self._k2_scratch_bytes(F)) if compute_q else None
         if g_layout is None:
             fs, ss, offs, fstr = g_out.stride(0), g_out.stride(1), None, None
         else:

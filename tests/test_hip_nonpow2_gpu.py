@@ -188,3 +188,70 @@ def test_nonpow2_c128_beyond_bluestein():
     got = core.prepare_facet(x, 3 * core.facet_off_step, axis=1)
     want = ref.prepare_facet(x, 3 * core.facet_off_step, 1)
     assert relrms(got, want) < 1e-12
+
+
+def test_forward_band_pipeline_nonpow2_yN():
+    """The contiguous-axis-first forward pipeline (wave_axis=1) at yN = 3 * 256 (catalogue entry
+    1536[1]-n768-512: xM = 512, m = 256 powers of two): K1 through the radix-3 pass of the generic row kernels, K2
+    through the radix-3 pass over the window columns + column-tile sub-transforms, subgrid side unchanged -- all 9
+    facets -> 16 subgrids against the oracle's serial replica of the reference dataflow, and against wave_axis=0."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+    from ska_sdp_exec_swiftly_amd.swift_configs import SWIFT_CONFIGS
+
+    params = SWIFT_CONFIGS["1536[1]-n768-512"]
+    assert (params["N"], params["yN_size"], params["xM_size"]) == (1536, 768, 512)
+    cfg = sw.SwiftlyConfig(backend="hip", **params)
+    assert cfg.core.supports_band_pipeline(torch.complex64, 9) and not cfg.core.supports_backward_band(torch.complex64)
+    assert sw.api.preferred_wave_axis(cfg, torch.complex64, n_facets=9) == 1
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    sg_cfgs = sw.make_full_subgrid_cover(cfg)
+    yB = params["yB_size"]
+    facets = []
+    for j, f in enumerate(facet_cfgs):
+        r = numpy.random.default_rng(700 + j)
+        d = (r.standard_normal((yB, yB)) + 1j * r.standard_normal((yB, yB))).astype(numpy.complex64)
+        facets.append((d * f.mask0[:, None] * f.mask1[None, :]).astype(numpy.complex64))
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs)
+    assert fwd.wave_axis == 1
+    got = [t.cpu().numpy() for t in fwd.get_subgrid_tasks(sg_cfgs)]
+    ref = orc.OracleCore(params["W"], params["N"], params["xM_size"], params["yN_size"])
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    sitems = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in sg_cfgs]
+    want = orc.forward_all(ref, items, [f.astype(complex) for f in facets], sitems)
+    errs = [relrms(g, w) for g, w in zip(got, want)]
+    assert max(errs) < 2e-5, max(errs)
+    fwd0 = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), wave_axis=0)
+    got0 = [t.cpu().numpy() for t in fwd0.get_subgrid_tasks(sg_cfgs)]
+    assert max(relrms(a, b) for a, b in zip(got, got0)) < 2e-5
+
+
+def test_prepare_facet_columns_nonpow2_yN():
+    """K2 primitive at yN = 6144 = 3 * 2048 (catalogue 12k[1]-n6k-512, m = 256): window gather from plain band buffers +
+    strided-axis prepare_facet (four-step sub-transforms of 2048 points) for 2 facets, with and without a row map."""
+    import torch
+
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    W, N, xM, yN = 11.0, 12288, 512, 6144
+    core, ref = SwiftlyCoreHip(W, N, xM, yN), orc.OracleCore(W, N, xM, yN)
+    m = core.xM_yN_size
+    assert m == 256 and core.band_for_offsets([0, 448]) == (0, yN)
+    rng = numpy.random.default_rng(33)
+    yB0, F = 176, 2
+    logical = (rng.standard_normal((F, yB0, yN)) + 1j * rng.standard_normal((F, yB0, yN))).astype(numpy.complex64)
+    bands = torch.from_numpy(logical).cuda()
+    off0s = [0, 4224]
+    for use_rowmap in (False, True):
+        rowmap, n_rows = core.subgrid_column_rows([0, 3 * 448, -5 * 448]) if use_rowmap else (None, yN)
+        rm = rowmap.cpu().numpy() if rowmap is not None else numpy.arange(yN)
+        for off1 in (7 * 448, -11 * 448):
+            got = core.prepare_facet_columns(bands, off0s, (0, yN), off1, rowmap, n_rows).cpu().numpy()
+            assert got.shape == (F, n_rows, m)
+            for f in range(F):
+                win = ref.extract_from_facet(logical[f].astype(complex), off1, axis=1)
+                want = ref.prepare_facet(win / ref.facet_window(yB0)[:, None], off0s[f], axis=0)  # window NOT applied
+                keep = rm >= 0
+                rel = relrms(got[f][rm[keep]], want[keep])
+                assert rel < 2e-6, (use_rowmap, off1, f, rel)
