@@ -98,6 +98,12 @@ WORKLOADS = {
         sparse_radius=None,
         name="12k[1]-n6k-512 (yN = 6144 = 3 * 2^11), 3x3 facets -> 28x28 subgrids",
     ),
+    # the 64k kernels' sizes (m = 512, xM = 1024) behind a facet side of 3 * 2^12
+    "24k": dict(
+        params=dict(W=10.875, fov=1.0, N=24576, yB_size=8448, yN_size=12288, xA_size=928, xM_size=1024),
+        sparse_radius=None,
+        name="24k[1]-n12k-1k (yN = 12288 = 3 * 2^12), 3x3 facets -> 27x27 subgrids",
+    ),
     "1k": dict(
         params=dict(W=13.5625, fov=1.0, N=1024, yB_size=416, yN_size=512, xA_size=228, xM_size=256),
         sparse_radius=None,

@@ -12,7 +12,11 @@ static int launch_one(const RowsArgs<R>& a, const OffTab& tab, hipStream_t s) {
     using G = typename GeoFor<R, LOGN>::type;
     const long long total = (long long)a.nrows * a.outer;
     if (total <= 0) return 0;
-    const unsigned grid = (unsigned)((total + G::RB - 1) / G::RB);
+    unsigned grid = (unsigned)((total + G::RB - 1) / G::RB);
+    if (a.outer_group) {  // row blocks padded to a multiple of 8 (one per XCD), `outer` workgroups each
+        const long long rowblocks = ((long long)a.nrows + G::RB - 1) / G::RB;
+        grid = (unsigned)(((rowblocks + 7) / 8) * 8 * a.outer);
+    }
     hipLaunchKernelGGL((fft_rows_kernel<G, R>), dim3(grid, a.nbatch > 0 ? a.nbatch : 1), dim3(G::NT), G::LDS_BYTES, s, a, tab);
     return (int)hipGetLastError();
 }

@@ -773,6 +773,8 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     a.ld_addmul = 0;
     a.st_addmul = all_j ? 1 : 0;
     a.outer = all_j ? qmul : 1;
+    // SWIFTLY_MIXED_GROUP=0: plain workgroup order for the one-launch form (A/B)
+    a.outer_group = (all_j && !(getenv("SWIFTLY_MIXED_GROUP") && !atoi(getenv("SWIFTLY_MIXED_GROUP")))) ? 1 : 0;
     if (!all_j) a.in_os = 0;
     a.out_os = 0;
     a.tw_full = nullptr;

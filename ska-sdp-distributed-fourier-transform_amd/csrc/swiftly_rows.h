@@ -48,6 +48,10 @@ struct RowsArgs {
     // (e*st_mul + o*st_addmul) + st_add0 with st_mul, st_addmul premultiplied by Q and st_add0 = j.
     int full_n;
     int st_add0;
+    // outer_group: enumerate the workgroups so that the `outer` sub-transforms of one row (which write INTERLEAVED
+    // elements Q*e + j of the same output lines) run 8 block ids apart = on the same XCD at about the same time, where
+    // its L2 merges their partial lines; block id = 8*(outer*rowblock8 + o) + xcd.  (Plain order: o = row / nrows.)
+    int outer_group;
     int ld_mul, ld_addmul;
     int st_mul, st_addmul;
     int outer;           // rows are (inner, outer): row = inner*outer + o  -- see kernel
@@ -107,11 +111,22 @@ __global__ __launch_bounds__(G::NT) void fft_rows_kernel(const RowsArgs<R> A, co
         rb = tid / T;
     }
     // rows are enumerated as (o, inner): consecutive rows share the outer index
-    const long long grow = (long long)blockIdx.x * RB + rb;
-    const long long total = (long long)A.nrows * A.outer;
-    const bool live = grow < total;
-    const int o = live ? (int)(grow / A.nrows) : 0;
-    const long long row = live ? grow % A.nrows : 0;
+    bool live;
+    int o;
+    long long row;
+    if (A.outer_group) {  // uniform
+        const long long x = blockIdx.x & 7, tb = blockIdx.x >> 3;
+        o = (int)(tb % A.outer);
+        row = ((tb / A.outer) * 8 + x) * RB + rb;
+        live = row < A.nrows;
+        if (!live) row = 0;
+    } else {
+        const long long grow = (long long)blockIdx.x * RB + rb;
+        const long long total = (long long)A.nrows * A.outer;
+        live = grow < total;
+        o = live ? (int)(grow / A.nrows) : 0;
+        row = live ? grow % A.nrows : 0;
+    }
     const int FS = 1 << A.full_logn;            // four-step twiddle period
     const int FN = A.full_n > 0 ? A.full_n : FS;  // modulus of the maps (any even length)
     auto wrapn = [FN](int v) { return v >= FN ? v - FN : v; };
