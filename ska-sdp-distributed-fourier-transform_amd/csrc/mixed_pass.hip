@@ -18,6 +18,18 @@ static int launch_any(int Q, const RowsArgs<R>& a, const OffTab& tab, const Mixe
     return (int)hipErrorInvalidValue;
 }
 
+int launch_mixed_gs_pass(int Q, const MixedGsArgs& g, const MixedArgs<float>& x, int nfacets, hipStream_t s) {
+    dim3 grid((unsigned)((g.ncols + 255) / 256), (unsigned)(x.M < 65535 ? x.M : 65535), (unsigned)nfacets);
+#define GS_CASE(QQ)                                                                      \
+    if (Q == QQ) {                                                                       \
+        hipLaunchKernelGGL((mixed_gs_pass_kernel<QQ>), grid, dim3(256), 0, s, g, x);       \
+        return (int)hipGetLastError();                                                   \
+    }
+    GS_CASE(3) GS_CASE(5) GS_CASE(7) GS_CASE(9)
+#undef GS_CASE
+    return (int)hipErrorInvalidValue;
+}
+
 int launch_mixed_pass(int Q, const RowsArgs<float>& a, const OffTab& tab, const MixedArgs<float>& x, int nbatch, hipStream_t s) {
     return launch_any<float>(Q, a, tab, x, nbatch, s);
 }

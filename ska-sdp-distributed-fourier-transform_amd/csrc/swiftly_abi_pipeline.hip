@@ -9,8 +9,10 @@ __global__ void mark_columns_kernel(unsigned char* __restrict__ touched, int m, 
                                     int band_len) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= m) return;
-    const int scol = (base + ((col + rot) & (m - 1))) & (yN - 1);
-    const int d = (scol - band_start) & (yN - 1);
+    int scol = base + ((col + rot) & (m - 1));  // m a power of two, yN any length: base < yN
+    if (scol >= yN) scol -= yN;
+    int d = scol - band_start;
+    if (d < 0) d += yN;
     if (d < band_len) touched[d] = 1;
 }
 // zero the band columns no wave has written (rows x band_len, row stride `pitch`)
@@ -746,8 +748,13 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: complex64 only");
     CHECK_FACET_SIZE();
     const int yN = (int)h->yN, m = (int)h->m;
-    if (h->log_yN < 0 || h->log_m < 0 || h->log_yN > 18)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: sizes not supported (powers of two)");
+    const swiftly_hip::Mixed* mx = nullptr;  // yN = Q * 2^k: radix-Q pass with the gather-sum load + sub-transforms
+    if (h->log_yN < 0) {
+        auto it = h->mixed.find(h->yN);
+        if (it != h->mixed.end() && it->second.tw_f && !band_is_split(h)) mx = &it->second;
+    }
+    if ((h->log_yN < 0 && !mx) || h->log_m < 0 || h->log_yN > 18)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: sizes not supported (yN a power of two or Q * 2^k, m a power of two)");
     if (nchunks <= 0 || nchunks > kColZC) return fail(SWIFTLY_ERR_PARAM, "1..%d source chunks", kColZC);
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN) return fail(SWIFTLY_ERR_PARAM, "bad band");
     if (nfacets <= 0) return 0;
@@ -774,7 +781,8 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
     c.cg_mod = m; c.cg_full = yN;
     c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = 0;
     const int64_t cap = workspace ? workspace_bytes : (int64_t(4) << 30);
-    const int per_f = (int)std::max<int64_t>(1, std::min<int64_t>(kColZF, cap / ((int64_t)yN * m * 8)));
+    const int64_t per_item = mx ? ((int64_t)yN + (int64_t(1) << mx->logM)) * m * 8 + 4096 : (int64_t)yN * m * 8;
+    const int per_f = (int)std::max<int64_t>(1, std::min<int64_t>(kColZF, cap / per_item));
     const int64_t s1 = floordiv(subgrid_off1 * h->yN, h->N);
     for (int64_t f0 = 0; f0 < nfacets; f0 += per_f) {
         const int nf = (int)std::min<int64_t>(per_f, nfacets - f0);
@@ -791,8 +799,58 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
         c.out = (cx<float>*)bands + f0 * band_facet_stride;
         c.out_bs = band_facet_stride;
         if (masks) c.st_win = masks + f0 * facet_size;
-        const int rc = col_transform(h, h->log_yN, c, cz, m, nf, (hipStream_t)stream, workspace,
-                                     workspace ? (size_t)workspace_bytes : 0);
+        int rc = 0;
+        if (!mx) {
+            rc = col_transform(h, h->log_yN, c, cz, m, nf, (hipStream_t)stream, workspace,
+                               workspace ? (size_t)workspace_bytes : 0);
+        } else {
+            // workspace: [radix-Q scratch nf * yN * m][four-step scratch of the sub-transforms nf * M * m]
+            const int Q = mx->Q, logM = mx->logM;
+            const long long M = 1ll << logM;
+            const size_t radix_bytes = (size_t)nf * (size_t)yN * (size_t)m * sizeof(cx<float>);
+            const size_t sub_bytes = (size_t)nf * (size_t)M * (size_t)m * sizeof(cx<float>) + 4096;
+            hipStream_t st = (hipStream_t)stream;
+            void* own = nullptr;
+            char* base = (char*)workspace;
+            if (!workspace || (size_t)workspace_bytes < radix_bytes + sub_bytes) {
+                HIP_TRY(hipMallocAsync(&own, radix_bytes + sub_bytes, st));
+                base = (char*)own;
+            }
+            MixedGsArgs g;
+            std::memset(&g, 0, sizeof g);
+            g.in = (const cx<float>*)parts;
+            g.in_pitch = (unsigned)part_row_stride;
+            g.rowmap = row_sources;
+            g.ncols = m;
+            for (int k = 0; k < nchunks; k++) {
+                g.c_base[k] = cz.c_base[k];
+                g.c_fs[k] = cz.c_fs[k];
+            }
+            MixedArgs<float> X;
+            std::memset(&X, 0, sizeof X);
+            X.Q = Q; X.M = (int)M; X.n = yN;
+            for (int r = 0; r < Q; r++) {
+                const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)r / (long double)Q;
+                X.wq[r] = cx<float>{(float)cosl(ang), (float)sinl(ang)};
+            }
+            X.tw_n = mx->tw_f;
+            X.scratch = (cx<float>*)base;
+            X.s_row = 1; X.s_y = m; X.s_j = M * m; X.s_b = (long long)yN * m;
+            int e = launch_mixed_gs_pass(Q, g, X, nf, st);
+            if (e) rc = fail(SWIFTLY_ERR_HIP, "kernel launch failed (radix-%d gather-sum pass): %s", Q, hipGetErrorString((hipError_t)e));
+            for (int j = 0; j < Q && !rc; j++) {
+                ColPassArgs cs = c;  // the store side of the primitive; plain load from the pass's scratch
+                cs.in = (const cx<float>*)base + (long long)j * X.s_j;
+                cs.in_pitch = (unsigned)m;
+                cs.in_bs = X.s_b; cs.in_bdiv = 0; cs.in_bs_hi = 0;
+                cs.ld_rowmap = nullptr; cs.gs = 0;
+                rc = col_transform(h, logM, cs, cz, m, nf, st, base + radix_bytes, sub_bytes, Q, j, yN);
+            }
+            if (own) {
+                hipError_t e2 = hipFreeAsync(own, st);
+                if (!rc && e2 != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e2));
+            }
+        }
         if (rc == -1) return fail(SWIFTLY_ERR_UNSUPPORTED, "accumulate_facet_columns: padded facet size %d not supported", yN);
         if (rc) return rc;
     }

@@ -209,10 +209,13 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
     const int zf = z / cz.nb, zb = z - zf * cz.nb;  // uniform
     int scol = col;
     if (cz.flags & (kZColGather | kZColScatter)) {  // uniform
+        // (cg_mod = m is a power of two; cg_full = yN any even length: b_base < cg_full, i < cg_mod <= cg_full)
         const int i = (col + cz.b_rot[zb]) & (A.cg_mod - 1);
-        scol = (cz.b_base[zb] + i) & (A.cg_full - 1);
+        scol = cz.b_base[zb] + i;
+        if (scol >= A.cg_full) scol -= A.cg_full;
         if (A.cg_band_len > 0) {
-            int d = (scol - A.cg_band_start) & (A.cg_full - 1);
+            int d = scol - A.cg_band_start;
+            if (d < 0) d += A.cg_full;
             if (d >= A.cg_band_len) d = 0;  // cannot happen for a window of the plan; keeps the access in bounds
             scol = A.cg_band_half > 0 ? (d & 1) * A.cg_band_half + (d >> 1) : d;
         }

@@ -93,6 +93,65 @@ __global__ __launch_bounds__(256) void mixed_radix_pass_kernel(const RowsArgs<R>
     for (long long islow = blockIdx.y; islow < nslow; islow += gridDim.y) mixed_radix_point<R, Q>(A, tab, X, rowfast ? ifast : islow, (int)(rowfast ? islow : ifast), b);
 }
 
+// The radix-Q pass with the GATHER-SUM load of the backward pass (swiftly_colpass.h, template GS: add_to_facet along
+// the strided axis fused into the load of finish_facet, api_helper.py:142-179): logical row idx of the padded axis is the
+// sum of up to two source rows  rowmap[idx], rowmap[n + idx]  (negative = none), each encoded  chunk << 20 | row  and
+// read at  in + c_base[chunk] + facet * c_fs[chunk] + row * in_pitch  (chunks = pieces of a multi-GPU receive buffer).
+// Lanes run over the m columns of the contributions; scratch[facet][j][y2][column].
+constexpr int kMixedGsChunks = 16;
+constexpr int kMixedGsRowBits = 20;
+struct MixedGsArgs {
+    const cx<float>* in;
+    unsigned in_pitch;
+    const int* rowmap;  // [2][n]
+    int ncols;
+    long long c_base[kMixedGsChunks], c_fs[kMixedGsChunks];
+};
+
+template <int Q>
+__global__ __launch_bounds__(256) void mixed_gs_pass_kernel(const MixedGsArgs G, const MixedArgs<float> X) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.z;
+    if (col >= G.ncols) return;
+    const int n = X.n;
+    constexpr int RM = (1 << kMixedGsRowBits) - 1;
+    for (int y2 = blockIdx.y; y2 < X.M; y2 += gridDim.y) {  // uniform per workgroup: the row tables are scalar loads
+        cx<float> x[Q];
+#pragma unroll
+        for (int y1 = 0; y1 < Q; y1++) {
+            const int pi = y2 + X.M * y1;
+            const int idx = wrap_n(pi + (n >> 1), n);  // centred index = logical row (identity load map)
+            cx<float> val = {0.f, 0.f};
+            const int r1 = G.rowmap[idx], r2 = G.rowmap[n + idx];
+            if (r1 >= 0) {
+                const int c = r1 >> kMixedGsRowBits;
+                val = G.in[G.c_base[c] + (long long)f * G.c_fs[c] + (long long)(r1 & RM) * G.in_pitch + col];
+            }
+            if (r2 >= 0) {
+                const int c = r2 >> kMixedGsRowBits;
+                const cx<float> w = G.in[G.c_base[c] + (long long)f * G.c_fs[c] + (long long)(r2 & RM) * G.in_pitch + col];
+                val.x += w.x;
+                val.y += w.y;
+            }
+            x[y1] = val;
+        }
+        cx<float>* __restrict__ out = X.scratch + (long long)f * X.s_b + (long long)y2 * X.s_y + col;
+#pragma unroll
+        for (int j = 0; j < Q; j++) {
+            cx<float> z = x[0];
+#pragma unroll
+            for (int y1 = 1; y1 < Q; y1++) {
+                const cx<float> w = X.wq[(y1 * j) % Q];
+                z.x += x[y1].x * w.x - x[y1].y * w.y;
+                z.y += x[y1].x * w.y + x[y1].y * w.x;
+            }
+            if (j > 0) z = cmul(z, X.tw_n[(unsigned)y2 * (unsigned)j]);
+            out[(long long)j * X.s_j] = z;
+        }
+    }
+}
+
+int launch_mixed_gs_pass(int Q, const MixedGsArgs& g, const MixedArgs<float>& x, int nfacets, hipStream_t s);
 int launch_mixed_pass(int Q, const RowsArgs<float>& a, const OffTab& tab, const MixedArgs<float>& x, int nbatch, hipStream_t s);
 int launch_mixed_pass(int Q, const RowsArgs<double>& a, const OffTab& tab, const MixedArgs<double>& x, int nbatch, hipStream_t s);
 

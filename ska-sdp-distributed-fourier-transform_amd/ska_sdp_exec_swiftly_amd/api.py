@@ -1410,7 +1410,8 @@ class SwiftlyBackward:
             self._touched = torch.zeros((self._band[1],), dtype=torch.uint8, device=core.device)
             self._masks0 = _mask_table(core, self.facets_config_list, "mask0", yB, dtype)
             self._facet_off0s = [cfg.off0 for cfg in self.facets_config_list]
-            self._work = torch.empty((F, core.yN_size, core.xM_yN_size), dtype=dtype, device=core.device)
+            # four-step scratch of accumulate_facet_columns (+ the radix-Q pass's output when yN = Q * 2^k)
+            self._work = torch.empty((core._k2_scratch_bytes(F) // 8,), dtype=dtype, device=core.device)
         return self._bands
 
     def _accumulate_band(self, off1, chunks):

@@ -525,8 +525,14 @@ class SwiftlyCoreHip:
     def supports_backward_band(self, dtype=None):
         """True when accumulate_facet_columns / finish_facet_band (include/swiftly_hip.h) exist for these sizes."""
         torch = _torch()
+        if dtype is not None and dtype != torch.complex64:
+            return False
         logs = self._logs()
-        return logs is not None and (dtype is None or dtype == torch.complex64) and 2 <= logs["yN"] <= 18
+        if logs is not None:
+            return 2 <= logs["yN"] <= 18
+        # yN = Q * 2^k (r3): radix-Q pass with the gather-sum load + column-tile sub-transforms, plain band layout
+        mixed = self._mixed_yN()
+        return self._logs(("xM", "m")) is not None and mixed is not None and 6 <= mixed[1] <= 15
 
     def band_for_offsets(self, subgrid_offs):
         """Smallest cyclic range ``(start, length)`` of centred indices of the padded facet axis that contains

@@ -203,7 +203,7 @@ def test_forward_band_pipeline_nonpow2_yN():
     params = SWIFT_CONFIGS["1536[1]-n768-512"]
     assert (params["N"], params["yN_size"], params["xM_size"]) == (1536, 768, 512)
     cfg = sw.SwiftlyConfig(backend="hip", **params)
-    assert cfg.core.supports_band_pipeline(torch.complex64, 9) and not cfg.core.supports_backward_band(torch.complex64)
+    assert cfg.core.supports_band_pipeline(torch.complex64, 9) and cfg.core.supports_backward_band(torch.complex64)
     assert sw.api.preferred_wave_axis(cfg, torch.complex64, n_facets=9) == 1
     facet_cfgs = sw.make_full_facet_cover(cfg)
     sg_cfgs = sw.make_full_subgrid_cover(cfg)
@@ -255,3 +255,41 @@ def test_prepare_facet_columns_nonpow2_yN():
                 keep = rm >= 0
                 rel = relrms(got[f][rm[keep]], want[keep])
                 assert rel < 2e-6, (use_rowmap, off1, f, rel)
+
+
+def test_backward_band_schedule_nonpow2_yN():
+    """SwiftlyBackward(wave_axis=1) at yN = 3 * 256 (catalogue 1536[1]-n768-512): accumulate_facet_columns through the
+    radix-3 pass with the gather-sum load + column-tile sub-transforms, finish_facet_band through the radix-3 pass of
+    the generic row kernels -- all 16 subgrids -> 9 facets against the oracle's serial replica, and against the
+    reference schedule (wave_axis=0)."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+    from ska_sdp_exec_swiftly_amd.swift_configs import SWIFT_CONFIGS
+
+    params = SWIFT_CONFIGS["1536[1]-n768-512"]
+    cfg = sw.SwiftlyConfig(backend="hip", **params)
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    sg_cfgs = sw.make_full_subgrid_cover(cfg)
+    xA = params["xA_size"]
+    rng = numpy.random.default_rng(77)
+    subgrids = []
+    for c in sg_cfgs:
+        d = (rng.standard_normal((xA, xA)) + 1j * rng.standard_normal((xA, xA))).astype(numpy.complex64)
+        subgrids.append((d * c.mask0[:, None] * c.mask1[None, :]).astype(numpy.complex64))
+    ref = orc.OracleCore(params["W"], params["N"], params["xM_size"], params["yN_size"])
+    items = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs]
+    sitems = [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in sg_cfgs]
+    want = orc.backward_all(ref, items, sitems, [s.astype(complex) for s in subgrids])
+    dev = [torch.from_numpy(s).cuda() for s in subgrids]
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
+    by1 = sorted(range(len(sg_cfgs)), key=lambda k: sg_cfgs[k].off1)
+    bwd.add_new_subgrid_tasks([sg_cfgs[k] for k in by1], [dev[k] for k in by1])
+    assert bwd.wave_axis == 1
+    got = [f.cpu().numpy() for f in bwd.finish()]
+    errs = [relrms(g, w) for g, w in zip(got, want)]
+    assert max(errs) < 4e-5, max(errs)
+    bwd0 = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=0)
+    bwd0.add_new_subgrid_tasks(sg_cfgs, dev)
+    got0 = [f.cpu().numpy() for f in bwd0.finish()]
+    assert max(relrms(a, b) for a, b in zip(got, got0)) < 4e-5
