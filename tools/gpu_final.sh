@@ -15,10 +15,10 @@ db=$(find "$out/kt" -name '*.db' | head -1); [ -n "$db" ] && python tools/rocpd_
 db=$(find "$out/kb" -name '*.db' | head -1); [ -n "$db" ] && python tools/rocpd_stats.py "$db" > "$out/kernel_stats_backward_64k_sparse.txt" 2>&1; rm -rf "$out/kb"
 tools/gpu_pmc.sh "$out/pmc" > "$out/pmc.log" 2>&1
 cp "$out/pmc/pmc_kernels.json" "$out/pmc_kernels.json"; cp "$out/pmc/pmc_kernels.txt" "$out/pmc_kernels.txt"; rm -rf "$out/pmc"
-for w in 8k 32k-8x8 64k-sparse-4x4 128k 128k-8x8; do
+for w in 8k 12k 24k 32k-8x8 64k-sparse-4x4 128k 128k-8x8; do
   timeout 500 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > "$out/bench_$w.json" 2> "$out/bench_$w.err"
 done
-for w in 8k 32k-8x8 128k; do tools/gpu_trace.sh "$out" $w > /dev/null 2>&1; done
+for w in 8k 24k 32k-8x8 128k; do tools/gpu_trace.sh "$out" $w > /dev/null 2>&1; done
 python - "$out" <<'PY'
 import glob, json, sys
 for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
