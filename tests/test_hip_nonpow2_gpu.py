@@ -293,3 +293,65 @@ def test_backward_band_schedule_nonpow2_yN():
     bwd0.add_new_subgrid_tasks(sg_cfgs, dev)
     got0 = [f.cpu().numpy() for f in bwd0.finish()]
     assert max(relrms(a, b) for a, b in zip(got, got0)) < 4e-5
+
+
+def test_distributed_virtual_ranks_nonpow2_yN():
+    """The multi-rank classes on the fused pipelines at yN = 3 * 256 (two virtual ranks in one process, the all-to-all
+    replaced by an in-process shuffle of the flat buffers): DistributedForward(wave_axis=1) and
+    DistributedBackward(wave_axis=1) against the single-process classes."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+    from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
+    from ska_sdp_exec_swiftly_amd.swift_configs import SWIFT_CONFIGS
+
+    world = 2
+    params = SWIFT_CONFIGS["1536[1]-n768-512"]
+    cfg = sw.SwiftlyConfig(backend="hip", **params)
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    sg_cfgs = sw.make_full_subgrid_cover(cfg)
+    yB = params["yB_size"]
+    dev_facets = []
+    for j, f in enumerate(facet_cfgs):
+        r = numpy.random.default_rng(300 + j)
+        d = (r.standard_normal((yB, yB)) + 1j * r.standard_normal((yB, yB))).astype(numpy.complex64)
+        dev_facets.append(torch.from_numpy((d * f.mask0[:, None] * f.mask1[None, :]).astype(numpy.complex64)).cuda())
+    ref_fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, dev_facets)), subgrid_configs=sg_cfgs)
+    assert ref_fwd.wave_axis == 1
+    fwds = [DistributedForward(cfg, facet_cfgs, dev_facets, subgrid_configs=sg_cfgs, wave_axis=1, dtype=torch.complex64,
+                               rank_world=(r, world)) for r in range(world)]
+    bwds = [DistributedBackward(cfg, facet_cfgs, rank_world=(r, world), wave_axis=1, subgrid_configs=sg_cfgs,
+                                dtype=torch.complex64) for r in range(world)]
+    ref_bwd = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
+
+    def shuffle(sends, in_counts):
+        starts = [numpy.concatenate([[0], numpy.cumsum(c)]) for c in in_counts]
+        return [torch.cat([sends[s][int(starts[s][r]) : int(starts[s][r + 1])] for s in range(world)]) for r in range(world)]
+
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off1, []).append(c)
+    for wave in waves.values():
+        want = ref_fwd.get_wave(wave)
+        packed = [f.pack_wave(wave) for f in fwds]
+        recvs = shuffle([p[0] for p in packed], [p[1] for p in packed])
+        got = {}
+        for r, f in enumerate(fwds):
+            mine, res = f.unpack_wave(wave, recvs[r])
+            for k, i in enumerate(mine):
+                got[i] = res[k]
+        assert sorted(got) == list(range(len(wave)))
+        scale = float(want.abs().max())
+        for i in range(len(wave)):
+            assert float((got[i] - want[i]).abs().max()) <= 2e-5 * scale
+        ref_bwd.add_new_subgrid_tasks(wave, [want[i] for i in range(len(wave))])
+        packed = [b.pack_wave(wave, [want[i] for i in b.sharding.subgrids_of(len(wave))]) for b in bwds]
+        recvs = shuffle([p[0] for p in packed], [p[1] for p in packed])
+        for r, b in enumerate(bwds):
+            b.unpack_wave(wave, recvs[r])
+    assert ref_bwd.wave_axis == 1
+    ref = ref_bwd.finish()
+    for b in bwds:
+        idx, out = b.finish()
+        for j, o in zip(idx, out):
+            assert float((o - ref[j]).abs().pow(2).mean().sqrt()) <= 3e-5 * float(ref[j].abs().pow(2).mean().sqrt())
