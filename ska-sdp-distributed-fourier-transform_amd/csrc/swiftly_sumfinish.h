@@ -196,7 +196,10 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
     // Per off1 group: the rows of the group's facets whose band covers this workgroup's rows are requested SF_NB at a
     // time (a wave pays the HBM latency once per batch, not once per facet; r2: one facet at a time -- 4.5 dependent
     // round trips per row on the 3x3 cover, SQ_WAIT_ANY 58 % of the wave cycles at 12 waves per CU) and summed in
-    // registers; the sum is transformed, weighted and scattered into the accumulator row once.
+    // registers; the sum is transformed, weighted and scattered into the accumulator row once.  (Requesting the NEXT
+    // batch before the current group is transformed -- measured r3 on the 4096-point rows of the N = 32768 workload,
+    // whose 8 groups per row are 8 dependent load -> transform steps: 114.5 vs 111-113 ms for the subgrid side, no
+    // gain; the 4-points-per-lane m-point transforms with their 9 workgroup barriers each are the cost there.)
     constexpr int NB = SWF_SF_NB;
     for (int g = 0; g < A.ngroups; g++) {  // workgroup-uniform
         cx<float> xs[PM];
