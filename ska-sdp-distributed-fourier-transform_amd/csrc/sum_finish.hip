@@ -21,28 +21,28 @@ template <int LOGM, int LOGX>
 static int launch_one_f(const SumFinishFacetArgs& a, int nbatch, hipStream_t s) {
     using S = SFGeo<LOGM, LOGX>;
     dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
-    hipLaunchKernelGGL((sum_finish_facets_kernel<LOGM, LOGX>), grid, dim3(S::NT), S::LDS_BYTES, s, a);
+    constexpr size_t lds = sum_finish_facets_lds<LOGM, LOGX>();
+    hipLaunchKernelGGL((sum_finish_facets_kernel<LOGM, LOGX>), grid, dim3(S::NT), lds, s, a);
     return (int)hipGetLastError();
 }
 template <int LOGM, int LOGX>
 static int init_one_f() {
-    using S = SFGeo<LOGM, LOGX>;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&sum_finish_facets_kernel<LOGM, LOGX>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sum_finish_facets_lds<LOGM, LOGX>()));
 }
 
 template <int LOGM, int LOGX>
 static int launch_one_s(const SplitFacetArgs& a, int nbatch, hipStream_t s) {
     using S = SFGeo<LOGM, LOGX>;
     dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
-    hipLaunchKernelGGL((split_prepare_facets_kernel<LOGM, LOGX>), grid, dim3(S::NT), S::LDS_BYTES, s, a);
+    constexpr size_t lds = sum_finish_facets_lds<LOGM, LOGX>();  // (the same wave-parallel geometry)
+    hipLaunchKernelGGL((split_prepare_facets_kernel<LOGM, LOGX>), grid, dim3(S::NT), lds, s, a);
     return (int)hipGetLastError();
 }
 template <int LOGM, int LOGX>
 static int init_one_s() {
-    using S = SFGeo<LOGM, LOGX>;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_prepare_facets_kernel<LOGM, LOGX>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sum_finish_facets_lds<LOGM, LOGX>()));
 }
 
 #define SF_PAIRS(X) X(7, 8) X(7, 10) X(8, 9) X(8, 10) X(9, 10) X(9, 11) X(10, 11) X(10, 12)

@@ -168,6 +168,35 @@ static inline void fill_facet_groups(Args& a, const swiftly_hip* h, int64_t nfac
     a.gstart[a.ngroups] = (int)nfacets;
 }
 
+// Rounds of the wave-parallel sum_finish_facets (SFWide): groups whose placement windows [start, start + m) on the ring
+// of xM positions are mutually disjoint share a round (greedy, in group order: deterministic).
+static inline void fill_group_rounds(SumFinishFacetArgs& a, const swiftly_hip* h) {
+    const int xM = (int)h->xM, m = (int)h->m;
+    std::vector<std::vector<int>> rounds;
+    auto overlap = [&](int g1, int g2) {
+        const int s1 = pmod(xM / 2 - m / 2 + a.gsp1[g1], xM), s2 = pmod(xM / 2 - m / 2 + a.gsp1[g2], xM);
+        const int d = pmod(s2 - s1, xM);
+        return d < m || xM - d < m;
+    };
+    for (int g = 0; g < a.ngroups; g++) {
+        size_t r = 0;
+        for (; r < rounds.size(); r++) {
+            bool ok = true;
+            for (int o : rounds[r]) ok = ok && !overlap(g, o);
+            if (ok) break;
+        }
+        if (r == rounds.size()) rounds.emplace_back();
+        rounds[r].push_back(g);
+    }
+    a.nrounds = (int)rounds.size();
+    int k = 0;
+    for (size_t r = 0; r < rounds.size(); r++) {
+        a.rstart[r] = k;
+        for (int g : rounds[r]) a.rgroup[k++] = g;
+    }
+    a.rstart[rounds.size()] = k;
+}
+
 #define CHECK_COMMON()                                                                       \
     if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");                  \
     DeviceGuard device_guard_(h->device);                                                    \

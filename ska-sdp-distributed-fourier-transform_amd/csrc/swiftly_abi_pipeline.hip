@@ -451,6 +451,7 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
     a.nfacets = (int)nfacets;
     a.xA = xA;
     fill_facet_groups(a, h, nfacets, facet_off0s, facet_off1s);
+    fill_group_rounds(a, h);
     a.fn = h->fn_f;
     a.mask_bs = mask ? mask_batch_stride : 0;
     a.tw_m = twiddles<float>(h, h->log_m);
@@ -708,6 +709,7 @@ int swiftly_hip_wave_subgrid_side_grouped(swiftly_hip_t* h, int dtype, const voi
         sf.gsp1[g] = (int)floordiv(goff[(size_t)g] * h->xM, h->N);
     }
     sf.gstart[ng] = (int)ng;
+    fill_group_rounds(sf, h);
     sf.fn = h->fn_f;
     sf.mask_bs = mask1 ? mask1_bs : 0;
     sf.tw_m = a.tw_m; sf.tw_x = a.tw_x;

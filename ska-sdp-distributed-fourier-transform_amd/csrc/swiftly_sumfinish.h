@@ -65,6 +65,26 @@ struct SFGeo {
     static constexpr size_t LDS_BYTES = LDS_M + LDS_X;
 };
 
+// Wave-parallel m-point transforms for the rows that are worked on by several waves (4096 points: 256 threads).  With
+// all 256 threads on ONE m-point transform a lane holds 4 points: five radix-4 phases, four exchanges, nine workgroup
+// barriers per group, eight groups per row on an 8x8 cover (measured r3, N = 32768 workload: 3.45 ms per wave = 2.8 TB/s,
+// unchanged by prefetching the next group's rows -- the barriers, not the loads, are the cost).  Here each WAVE
+// transforms a different group (16 points per lane, radix 16 x 16 x 4, wave-local exchanges in its own quarter of the
+// buffer, no workgroup barrier) and the four results are added into the accumulator row together; groups whose
+// placement windows overlap are put into different rounds by the host (SumFinishFacetArgs::rgroup), one barrier per round.
+template <int LOGM, int LOGX>
+struct SFWide {
+    using S = SFGeo<LOGM, LOGX>;
+    static constexpr bool ON = LOGX >= 12 && LOGM >= 7;
+    using GM = Geo<float, LOGM, (LOGM >= 7 ? LOGM - 6 : 1), S::NT, false>;  // 64 threads per transform
+    static constexpr size_t LDS_M = GM::LDS_BYTES;
+    static constexpr size_t LDS_BYTES = LDS_M + S::LDS_X;
+};
+template <int LOGM, int LOGX>
+constexpr size_t sum_finish_facets_lds() {
+    return SFWide<LOGM, LOGX>::ON ? SFWide<LOGM, LOGX>::LDS_BYTES : SFGeo<LOGM, LOGX>::LDS_BYTES;
+}
+
 template <int LOGM, int LOGX>
 __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_rows_kernel(const SumFinishArgs A) {
     using S = SFGeo<LOGM, LOGX>;
@@ -167,6 +187,12 @@ struct SumFinishFacetArgs {
     long long mask_bs;
     const cx<float>* tw_m;
     const cx<float>* tw_x;
+    // Wave-parallel form (4096-point rows, SFWide): the groups in ROUNDS of mutually disjoint placement windows
+    // (rgroup[rstart[r] .. rstart[r+1]) = the groups of round r); the waves of a workgroup transform different groups of
+    // a round at the same time and add them into the shared accumulator row without conflicts
+    int nrounds;
+    int rstart[kSumFinishMaxFacets + 1];
+    int rgroup[kSumFinishMaxFacets];
     // direct-row mode (the axis-0 half is finished already, swiftly_groupfinish.h): the `nfacets` inputs are off1
     // GROUPS, every one of them covers every row, and row r of the output reads row r of each (nrows = xA)
     int direct_rows;
@@ -175,11 +201,12 @@ struct SumFinishFacetArgs {
 template <int LOGM, int LOGX>
 __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
-    using GM = typename S::GM;
     using GX = typename S::GX;
+    using W = SFWide<LOGM, LOGX>;
+    using GM = std::conditional_t<W::ON, typename W::GM, typename S::GM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cx<float>* ex_m = reinterpret_cast<cx<float>*>(smem);
-    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + S::LDS_M);
+    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + (W::ON ? W::LDS_M : S::LDS_M));
     constexpr int M = GM::N, X = GX::N, PM = GM::P, PX = GX::P, TR = S::TR;
     const int t = threadIdx.x % TR, rb = threadIdx.x / TR;
     const int b = blockIdx.y;
@@ -192,6 +219,77 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
         acc[lds_pos<GX>(rb, t + v * TR, false)] = cx<float>{0.f, 0.f};
     });
     row_sync<GX>(false);
+
+    if constexpr (W::ON) {
+        static_assert(S::RB == 1, "one row per workgroup");
+        constexpr int NBW = 2;  // rows of one group in flight per wave (16 points per lane each)
+        const int lane = threadIdx.x & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        constexpr int NW = S::NT / 64;
+        for (int r = 0; r < A.nrounds; r++) {  // workgroup-uniform
+            for (int i0 = A.rstart[r]; i0 < A.rstart[r + 1]; i0 += NW) {
+                const int i = i0 + wv;  // wave-uniform
+                if (i < A.rstart[r + 1]) {
+                    const int g = A.rgroup[i];
+                    cx<float> xs[PM];
+                    static_for<0, PM>([&](auto vI) { xs[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
+                    bool anyg = false;
+                    int n = A.gstart[g];
+                    const int ne = A.gstart[g + 1];
+                    while (n < ne) {
+                        int fs[NBW];
+                        int cnt = 0;
+                        for (; n < ne && cnt < NBW; n++) {
+                            const bool any = A.direct_rows != 0 || (live && ((row - A.base0[n]) & (X - 1)) < M);
+                            if (any) fs[cnt++] = n;
+                        }
+                        if (cnt == 0) break;
+                        anyg = true;
+                        cx<float> x[NBW][PM];
+                        static_for<0, NBW>([&](auto sI) {
+                            constexpr int sl = decltype(sI)::value;
+                            if (sl < cnt) {  // wave-uniform
+                                const int nn = fs[sl];
+                                const int k = A.direct_rows ? row : ((row - A.base0[nn]) & (X - 1));
+                                const cx<float>* __restrict__ in = A.in + (long long)A.fidx[nn] * A.in_fs +
+                                                                   (long long)b * A.in_bs + (long long)(live ? k : 0) * A.in_rs;
+                                static_for<0, PM>([&](auto vI) {
+                                    constexpr int v = decltype(vI)::value;
+                                    x[sl][v] = in[(lane + v * 64) ^ (M >> 1)];  // plain index -> centred element
+                                });
+                            }
+                        });
+                        const float lw = live ? 1.f : 0.f;
+                        static_for<0, NBW>([&](auto sI) {
+                            constexpr int sl = decltype(sI)::value;
+                            if (sl < cnt) {
+                                static_for<0, PM>([&](auto vI) {
+                                    constexpr int v = decltype(vI)::value;
+                                    xs[v].x += x[sl][v].x * lw;
+                                    xs[v].y += x[sl][v].y * lw;
+                                });
+                            }
+                        });
+                    }
+                    if (anyg) {
+                        const int sp = A.gsp1[g];
+                        fft_phases<GM, float, 0>(xs, lane, wv, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+                            const int ck = e ^ (M >> 1);
+                            const int kk = (ck - sp) & (M - 1);
+                            const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);
+                            const float w = A.fn[kk];
+                            cx<float>* p = acc + lds_pos<GX>(0, dest ^ (X >> 1), false);
+                            cx<float> o = *p;
+                            o.x += v.x * w;
+                            o.y += v.y * w;
+                            *p = o;
+                        });
+                    }
+                }
+            }
+            __syncthreads();  // the next round's windows overlap this round's
+        }
+    } else {
 
     // Per off1 group: the rows of the group's facets whose band covers this workgroup's rows are requested SF_NB at a
     // time (a wave pays the HBM latency once per batch, not once per facet; r2: one facet at a time -- 4.5 dependent
@@ -262,6 +360,8 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
         row_sync<GX>(false);  // also protects ex_m reuse by the next group
     }
 
+    }  // !W::ON
+
     cx<float> y[PX];
     static_for<0, PX>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
@@ -318,11 +418,12 @@ struct SplitFacetArgs {
 template <int LOGM, int LOGX>
 __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_kernel(const SplitFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
-    using GM = typename S::GM;
     using GX = typename S::GX;
+    using W = SFWide<LOGM, LOGX>;  // 4096-point rows: every wave extracts a different group (see SFWide)
+    using GM = std::conditional_t<W::ON, typename W::GM, typename S::GM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cx<float>* ex_m = reinterpret_cast<cx<float>*>(smem);
-    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + S::LDS_M);
+    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + (W::ON ? W::LDS_M : S::LDS_M));
     constexpr int M = GM::N, X = GX::N, PM = GM::P, PX = GX::P, TR = S::TR;
     const int t = threadIdx.x % TR, rb = threadIdx.x / TR;
     const int b = blockIdx.y;
@@ -348,6 +449,51 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_
     }
     const float scale = 1.f / (float)M;
     constexpr int NS = 4;  // facets of a group served by one transform (more: the transform is repeated)
+    if constexpr (W::ON) {
+        static_assert(S::RB == 1, "one row per workgroup");
+        const int lane = threadIdx.x & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        constexpr int NW = S::NT / 64;
+        for (int g = wv; g < A.ngroups; g += NW) {  // wave-uniform; the prepared row in `acc` is only read
+            int n = A.gstart[g];
+            const int ne = A.gstart[g + 1];
+            const int sp = A.gsp1[g];
+            const int c1 = ((X >> 1) - (M >> 1) + sp) & (X - 1);
+            while (n < ne) {
+                cx<float>* outp[NS];
+                int cnt = 0;
+                static_for<0, NS>([&](auto sI) { outp[decltype(sI)::value] = nullptr; });
+                for (; n < ne && cnt < NS; n++) {
+                    const int k = (row - A.base0[n]) & (X - 1);
+                    if (live && k < M) {
+                        cx<float>* q = A.out + (long long)A.fidx[n] * A.out_fs + (long long)b * A.out_bs + (long long)k * A.out_rs;
+                        static_for<0, NS>([&](auto sI) {
+                            if (decltype(sI)::value == cnt) outp[decltype(sI)::value] = q;
+                        });
+                        cnt++;
+                    }
+                }
+                if (cnt == 0) break;
+                cx<float> x[PM];
+                static_for<0, PM>([&](auto vI) {
+                    constexpr int v = decltype(vI)::value;
+                    const int q = (((lane + v * 64) ^ (M >> 1)) - sp) & (M - 1);
+                    const cx<float> val = acc[lds_pos<GX>(0, (q + c1) & (X - 1), false)];
+                    const float w = A.fn[q];
+                    x[v] = cx<float>{val.x * w, -val.y * w};  // inverse transform = conj(FFT(conj(.)))
+                });
+                fft_phases<GM, float, 0>(x, lane, wv, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+                    const cx<float> o = cx<float>{v.x * scale, -v.y * scale};
+                    static_for<0, NS>([&](auto sI) {
+                        constexpr int sl = decltype(sI)::value;
+                        if (outp[sl]) outp[sl][e ^ (M >> 1)] = o;
+                    });
+                });
+                __builtin_amdgcn_wave_barrier();  // this wave's quarter of ex_m is reused by its next transform
+            }
+        }
+        return;
+    }
     for (int g = 0; g < A.ngroups; g++) {  // workgroup-uniform
         int n = A.gstart[g];
         const int ne = A.gstart[g + 1];
