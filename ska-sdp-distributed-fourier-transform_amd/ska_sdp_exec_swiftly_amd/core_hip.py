@@ -75,6 +75,19 @@ def band_range(N, yN, m, subgrid_offs, align=32):
     return (0, yN) if length >= yN else (start, length)
 
 
+def mixed_factor(n):
+    """``(Q, k)`` when ``n = Q * 2^k`` with Q in {3, 5, 7, 9} and ``2^k >= 8`` -- the lengths that run through one
+    radix-Q pass in front of the power-of-two kernels (csrc/swiftly_mixed.h; the same rule as ``mixed_factor`` in
+    csrc/swiftly_abi.hip) -- else None (powers of two included: they need no pass)."""
+    n = int(n)
+    for q in (3, 5, 7, 9):
+        if n > 0 and n % q == 0:
+            r = n // q
+            if r >= 8 and r & (r - 1) == 0:
+                return q, r.bit_length() - 1
+    return None
+
+
 def build_row_sources(N, yN, m, sub_off0s, locations, max_chunks=16):
     """Host tables of the gather-sum load (see :py:meth:`SwiftlyCoreHip.column_row_sources`; pure numpy, unit-tested
     on CPU against the oracle's ``add_to_facet``): list of ``(subgrid indices, int32 table [2, yN])``.  Row ``big``
@@ -486,14 +499,8 @@ class SwiftlyCoreHip:
         return logs
 
     def _mixed_yN(self):
-        """``(Q, k)`` when ``yN_size = Q * 2^k`` with Q in {3, 5, 7, 9} (csrc/swiftly_mixed.h), else None"""
-        n = self.yN_size
-        for q in (3, 5, 7, 9):
-            if n % q == 0:
-                r = n // q
-                if r >= 8 and r & (r - 1) == 0:
-                    return q, r.bit_length() - 1
-        return None
+        """``(Q, k)`` when ``yN_size = Q * 2^k`` with Q in {3, 5, 7, 9} (:py:func:`mixed_factor`), else None"""
+        return mixed_factor(self.yN_size)
 
     MAX_FUSED_FACETS = 64  # kSumFinishMaxFacets (csrc/swiftly_sumfinish.h): facets summed by one sum_finish_facets call
 

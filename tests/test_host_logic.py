@@ -187,3 +187,22 @@ def test_band_range_is_the_smallest_cyclic_cover():
     offs = [i * 928 for i in range(-12, 13)]
     assert band_range(N, yN, m, offs, align=1)[1] == 24 * 464 + 512
     assert band_range(N, yN, m, [i * 928 for i in range(71)]) == (0, yN)
+
+
+def test_mixed_factor_covers_every_catalogue_length():
+    """the lengths that take the radix-Q pass (csrc/swiftly_mixed.h): every transform length of the 244 catalogue
+    entries is a power of two or Q * 2^k with Q in {3, 5, 7, 9}"""
+    from ska_sdp_exec_swiftly_amd.core_hip import mixed_factor
+    from ska_sdp_exec_swiftly_amd.swift_configs import SWIFT_CONFIGS
+
+    assert mixed_factor(6144) == (3, 11) and mixed_factor(57344) == (7, 13) and mixed_factor(36864) == (9, 12)
+    assert mixed_factor(160) == (5, 5) and mixed_factor(224) == (7, 5)
+    assert mixed_factor(4096) is None and mixed_factor(11264) is None and mixed_factor(15 * 64) is None
+    assert mixed_factor(24) == (3, 3) and mixed_factor(12) is None  # sub-transforms of at least 8 points
+    kinds = set()
+    for c in SWIFT_CONFIGS.values():
+        for n in (c["yN_size"], c["xM_size"], c["xM_size"] * c["yN_size"] // c["N"]):
+            f = mixed_factor(n)
+            assert f is not None or n & (n - 1) == 0, n
+            kinds.add(1 if f is None else f[0])
+    assert kinds == {1, 3, 5, 7, 9}
