@@ -75,6 +75,8 @@ struct SFGeo {
 template <int LOGM, int LOGX>
 struct SFWide {
     using S = SFGeo<LOGM, LOGX>;
+    // (2048-point rows as two waves per row + this form: measured r3 on the N = 8192 workload, subgrid side 5.0 -> 5.55 ms
+    // forward, 8.6 -> 8.4 ms for the backward pass: not adopted, one wave per row stays)
     static constexpr bool ON = LOGX >= 12 && LOGM >= 7;
     using GM = Geo<float, LOGM, (LOGM >= 7 ? LOGM - 6 : 1), S::NT, false>;  // 64 threads per transform
     static constexpr size_t LDS_M = GM::LDS_BYTES;
@@ -460,19 +462,20 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_
             const int sp = A.gsp1[g];
             const int c1 = ((X >> 1) - (M >> 1) + sp) & (X - 1);
             while (n < ne) {
+                // (slots filled through compile-time indices: a runtime index would put the pointers into scratch memory)
                 cx<float>* outp[NS];
                 int cnt = 0;
-                static_for<0, NS>([&](auto sI) { outp[decltype(sI)::value] = nullptr; });
-                for (; n < ne && cnt < NS; n++) {
-                    const int k = (row - A.base0[n]) & (X - 1);
-                    if (live && k < M) {
-                        cx<float>* q = A.out + (long long)A.fidx[n] * A.out_fs + (long long)b * A.out_bs + (long long)k * A.out_rs;
-                        static_for<0, NS>([&](auto sI) {
-                            if (decltype(sI)::value == cnt) outp[decltype(sI)::value] = q;
-                        });
-                        cnt++;
+                static_for<0, NS>([&](auto sI) {
+                    constexpr int sl = decltype(sI)::value;
+                    outp[sl] = nullptr;
+                    for (; n < ne && cnt == sl; n++) {  // the next covering facet of the group, if any
+                        const int k = (row - A.base0[n]) & (X - 1);
+                        if (live && k < M) {
+                            outp[sl] = A.out + (long long)A.fidx[n] * A.out_fs + (long long)b * A.out_bs + (long long)k * A.out_rs;
+                            cnt++;
+                        }
                     }
-                }
+                });
                 if (cnt == 0) break;
                 cx<float> x[PM];
                 static_for<0, PM>([&](auto vI) {
