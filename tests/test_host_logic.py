@@ -206,3 +206,37 @@ def test_mixed_factor_covers_every_catalogue_length():
             assert f is not None or n & (n - 1) == 0, n
             kinds.add(1 if f is None else f[0])
     assert kinds == {1, 3, 5, 7, 9}
+
+
+def test_band_range_and_row_sources_for_a_padded_facet_of_3_times_2_to_the_k():
+    """The host tables of the band schedules carry no power-of-two assumption (yN = 3 * 256, catalogue entry
+    1536[1]-n768-512: the backward band accumulators are pruned bands for every yN): band_range covers every window and
+    is tight; the gather-sum tables reproduce the oracle's add_to_facet."""
+    from ska_sdp_exec_swiftly_amd.core_hip import band_range, build_row_sources
+
+    W, N, xM, yN = 11.0, 1536, 512, 768
+    ref = orc.OracleCore(W, N, xM, yN)
+    m = ref.xM_yN_size
+    assert m == 256 and ref.subgrid_off_step == 2
+    offs = [0, 448, 2 * 448, -448, 1536 + 448]
+    band_offs = [0, 448, -448]  # three windows: 704 of the 768 columns
+    start, length = band_range(N, yN, m, band_offs, align=1)
+    used = numpy.zeros(yN, dtype=bool)
+    for off in band_offs:
+        used[(yN // 2 - m // 2 + numpy.arange(m) + off * yN // N) % yN] = True
+    inside = numpy.zeros(yN, dtype=bool)
+    inside[(start + numpy.arange(length)) % yN] = True
+    assert inside[used].all() and used[start] and used[(start + length - 1) % yN] and length < yN
+    rng = numpy.random.default_rng(9)
+    blocks = rng.standard_normal((len(offs), m, 3)) + 1j * rng.standard_normal((len(offs), m, 3))
+    want = numpy.zeros((yN, 3), dtype=complex)
+    for b, off in enumerate(offs):
+        ref.add_to_facet(blocks[b], off, axis=0, out=want)
+    got = numpy.zeros((yN, 3), dtype=complex)
+    flat = blocks.reshape(-1, 3)
+    for members, tab in build_row_sources(N, yN, m, offs, [(0, b) for b in range(len(offs))]):
+        assert tab.shape == (2, yN)
+        for lvl in range(2):
+            rows = numpy.flatnonzero(tab[lvl] >= 0)
+            got[rows] += flat[tab[lvl, rows] & 0xFFFFF]
+    numpy.testing.assert_array_equal(got, want)
