@@ -9,6 +9,9 @@ template <int LOGN, int MODE>
 static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     using G = typename CGeoFor<LOGN>::type;
     dim3 grid((unsigned)((a.ncols + G::COLS - 1) / G::COLS), (unsigned)outer, (unsigned)nbatch);
+    if constexpr (MODE == 1 || G::HALF) {
+        if (a.gs) return (int)hipErrorInvalidConfiguration;  // no gather-sum instance of this geometry: never fall through to the plain load
+    }
     if constexpr (MODE != 1 && !G::HALF) {
         if (a.gs) {  // gather-sum load (backward pass); the source contributions are small and re-read: cacheable
             hipLaunchKernelGGL((col_pass_kernel<G, MODE, true, true>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in, a.out,

@@ -5,6 +5,13 @@
 
 namespace swf {
 
+#if SWF_TRACE
+__device__ unsigned long long swf_trace_buf[kTraceBlocks * kTracePoints];
+extern "C" int swiftly_hip_trace_fetch(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(swf_trace_buf), bytes);
+}
+#endif
+
 template <int LOGN>
 struct RGeoFor {
     // 1024 threads, 8 / 16 / 32 points per thread; N = 32768 needs the split re/im exchange
@@ -73,13 +80,74 @@ int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<
 }
 using BandGeo5 = RGeo<14, 5, true>;  // 2 x 16384 points, 512 threads x 32, 66 KB LDS: two workgroups per CU
 using BandGeo4 = RGeo<14, 4, true>;  // 2 x 16384 points, 1024 threads x 16, one workgroup per CU
+// Cyclic run of input segments (seglen consecutive points of the n-point transform input) that can hold data under
+// the load map of a prepare_* primitive: q = (j + n/2 + ld_a) mod n < ld_len.  Returns the length of the run and its
+// first segment (0, all segments: the row has no empty segment).
+static int data_segment_run(const RowPassArgs& a, int n, int seglen, int* first) {
+    const int nseg = n / seglen, base = (int)(((long long)a.ld_a + n / 2) % n);
+    int valid[64];
+    int count = 0;
+    for (int r = 0; r < nseg; r++) {
+        const int lo = (int)(((long long)seglen * r + base) % n);
+        valid[r] = a.ld_len > 0 && (lo < a.ld_len || lo + seglen > n);
+        count += valid[r];
+    }
+    *first = 0;
+    if (count == nseg || count == 0) return count == 0 ? 1 : nseg;
+    for (int r = 0; r < nseg; r++)
+        if (valid[r] && !valid[(r + nseg - 1) % nseg]) *first = r;
+    int run = 0;
+    while (run < nseg && valid[(*first + run) % nseg]) run++;
+    return run == count ? run : nseg;  // two runs cannot happen for one cyclic range; be safe
+}
+
+template <class G, bool PAIR, bool WIN, int ST, int NSEG>
+static void launch_band_inst(const RowPassArgs& a, unsigned blocks, const cx<float>* tw14, const cx<float>* tw_full,
+                             hipStream_t s) {
+    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, NSEG>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in,
+                       a.out, a.ld_win, tw14, tw_full);
+}
+// tuning knob SWIFTLY_ROW_SEGSKIP=0: always the all-segments kernel
+static bool segskip_enabled() {
+    static const bool on = !(getenv("SWIFTLY_ROW_SEGSKIP") && atoi(getenv("SWIFTLY_ROW_SEGSKIP")) == 0);
+    return on;
+}
 template <class G, bool PAIR = false>
-static int launch_band_geo(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
+static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
+    RowPassArgs a = a0;
+    a.seg_rot = 0;
     const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
     const bool band = a.band_len > 0;
-#define SWF_LAUNCH_BAND(WIN, ST)                                                                                        \
-    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in, \
-                       a.out, a.ld_win, tw14, tw_full)
+    // instances with empty segments compiled out (PAIR geometry of the 32768-point rows, 65536-point geometry): the
+    // forward K1 (window, band store) and the backward finish (no load window, mapped store)
+    constexpr bool SEGS = PAIR || (G::LOGN == 15 && G::LOGP == 5);
+    if constexpr (SEGS) {
+        constexpr int SEGLEN = PAIR ? 2 * G::T : G::T, NSEGTOT = 2 * G::N / SEGLEN;
+        int first = 0;
+        const int run = segskip_enabled() ? data_segment_run(a, 2 * G::N, SEGLEN, &first) : NSEGTOT;
+#define SWF_TRY_SEG(WIN, ST, NS)                                       \
+    if (run <= NS) {                                                   \
+        a.seg_rot = first;                                             \
+        launch_band_inst<G, PAIR, WIN, ST, NS>(a, blocks, tw14, tw_full, s); \
+        return (int)hipGetLastError();                                 \
+    }
+        if constexpr (PAIR) {
+            if (a.band_len > 0 && a.ld_win) {
+                SWF_TRY_SEG(true, 1, 16)
+                SWF_TRY_SEG(true, 1, 22)
+                SWF_TRY_SEG(true, 1, 24)
+            } else if (a.band_len < 0) {
+                SWF_TRY_SEG(false, 2, 13)
+                SWF_TRY_SEG(false, 2, 16)
+            }
+        } else {
+            if (a.band_len > 0 && a.ld_win) {
+                SWF_TRY_SEG(true, 1, 44)
+            }
+        }
+#undef SWF_TRY_SEG
+    }
+#define SWF_LAUNCH_BAND(WIN, ST) launch_band_inst<G, PAIR, WIN, ST, 0>(a, blocks, tw14, tw_full, s)
     if (a.band_len < 0) {  // mapped (crop + window) store: finish_* primitives
         SWF_LAUNCH_BAND(false, 2);
     } else if (a.ld_win) {
@@ -128,9 +196,9 @@ static int init_band() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
-template <class G, bool WIN, int ST>
+template <class G, bool WIN, int ST, int NSEG = 0, bool PAIR = true>
 static int init_band_pair() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, true>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, PAIR, NSEG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 template <class G>
@@ -165,6 +233,12 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 1>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 16>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 22>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 24>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16>();
+        if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false>();
         if (!rcb) rcb = init_band_geo<BandGeo4>();
         if (!rcb) rcb = init_band_geo<BandGeo64k>();
         if (!rcb) rcb = init_band_geo<BandGeo16k>();

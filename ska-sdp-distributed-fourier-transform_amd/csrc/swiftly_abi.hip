@@ -454,7 +454,10 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         ws = t_call_ws;
         ws_bytes = t_call_ws_bytes;
     }
-    const bool two = logn > kColPassMaxLog;  // single pass up to 512 points (1024 threads x 32 points)
+    // single pass up to 1024 points; the gather-sum load (c.gs, backward pass) exists for 64-column tiles only, i.e. up to
+    // 512 points: longer gather-sum transforms go through the four-step, whose pass A carries the load (r3 bug: a
+    // 1024-point gather-sum transform ran the plain 32-column kernel, which read the encoded table as a row map)
+    const bool two = logn > (c.gs ? 9 : kColPassMaxLog);
     static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
     const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
     if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return -1;

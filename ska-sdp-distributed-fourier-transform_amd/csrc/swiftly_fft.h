@@ -133,6 +133,25 @@ __device__ __forceinline__ f32x2 pk_rot24(f32x2 d) {
     return r;
 }
 
+// Timeline tracing of a kernel (diagnostic builds only, -DSWF_TRACE=1; tools/k1_trace.py): thread 0 of the first
+// kTraceBlocks workgroups stamps the shader clock at fixed points into a device array.
+#ifndef SWF_TRACE
+#define SWF_TRACE 0
+#endif
+#if SWF_TRACE
+constexpr int kTraceBlocks = 49152, kTracePoints = 12;
+extern __device__ unsigned long long swf_trace_buf[kTraceBlocks * kTracePoints];
+__device__ __forceinline__ void trace_point(int id) {
+    asm volatile("" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < (unsigned)kTraceBlocks)
+        swf_trace_buf[blockIdx.x * kTracePoints + id] = __builtin_readcyclecounter();
+    asm volatile("" ::: "memory");
+}
+#define SWF_TRACE_POINT(id) trace_point(id)
+#else
+#define SWF_TRACE_POINT(id) ((void)0)
+#endif
+
 // compile-time loop: f(std::integral_constant<int, i>) for i in [I0, I1)
 template <int I0, int I1, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -482,7 +501,15 @@ __device__ __forceinline__ void row_sync(bool rowfast) {
 }
 
 template <class G, typename R, int LOGNS, int LOGR, bool PAIRJ = false>
+__device__ __forceinline__ void phase_exchange_impl(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds);
+template <class G, typename R, int LOGNS, int LOGR, bool PAIRJ = false>
 __device__ __forceinline__ void phase_exchange(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds) {
+    SWF_TRACE_POINT(LOGNS > 0 ? 5 : 3);
+    phase_exchange_impl<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, lds);
+    SWF_TRACE_POINT(LOGNS > 0 ? 6 : 4);
+}
+template <class G, typename R, int LOGNS, int LOGR, bool PAIRJ>
+__device__ __forceinline__ void phase_exchange_impl(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds) {
     if constexpr (!G::SPLIT) {
         cx<R>* buf = reinterpret_cast<cx<R>*>(lds);
         exchange_pass<G, R, LOGNS, LOGR, PAIRJ>(x, t, rb, rowfast, buf, [](cx<R> v) { return v; }, true);

@@ -53,6 +53,10 @@ struct RowPassArgs {
     // (d & 1) * band_half + (d >> 1).  (The two workgroups of a row produce the even / odd outputs; with this
     // layout each of them writes one contiguous run instead of every other element.)  band_len = 0: plain row.
     int band_start, band_len, band_half;
+    // zero-segment skipping (NSEG instances of row_pass_band_kernel, set by the launcher): the transform input is taken
+    // cyclically rotated by seg_rot segments so that every segment that can hold data is one of the first NSEG ones;
+    // the outputs get the compensating phase W_nseg^(seg_rot k)
+    int seg_rot;
 };
 
 // physical column of logical (centred) column ck in a parity-split band buffer, or -1
@@ -330,7 +334,19 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // invariants kept out of the loop so that nothing spills -- were measured SLOWER than one workgroup per row half:
 // K1 1.95 / 1.93 / 1.88 ms per facet against 1.82 ms.  The hardware dispatcher refills a CU the moment one of its two
 // workgroups retires, which also keeps the two residents out of phase; a static loop does neither.  Not kept.)
-template <class G, bool HAS_WIN, int ST, bool PAIR = false>
+// NSEG (r4): the padded row is 2P (PAIR: 32) segments of T (PAIR: 2T) consecutive points, and the lane's loads are one
+// per segment.  A zero-padded row leaves whole segments empty (prepare_facet of a 22528-point facet in a 32768-point
+// row: 10 of 32), but which ones depends on the facet offset.  The launcher therefore rotates the input cyclically by
+// seg_rot segments so that the segments that can hold data are the first NSEG (compile time: their loads, window
+// products and first-stage additions simply do not exist) and the kernel multiplies output k by W_nseg^(seg_rot k),
+// which is ONE complex constant per lane (k = 2 e0 + h modulo the segment count for every output of the lane).
+// NSEG = 0: all segments, no rotation (the r2/r3 kernel).  Measured (r4, same box): K1 1.79 -> 1.73 ms per facet -- the
+// range-checked loads of the empty segments were already nearly free (no memory access), what goes away is their
+// issue slots and the arithmetic on zeros.  (s_setprio 3 during the load phase: 1.95 ms; during the butterflies
+// instead: 1.80 ms; neither kept.  tools/k1_trace.py + -DSWF_TRACE=1: a workgroup lives 46 k cycles -- loads 20 %,
+// window products / first stage / inter-half twiddle 18 %, the three butterfly phases 35 %, the two exchanges 25 %
+// -- with two workgroups per CU, i.e. the SIMDs issue about 55 % of the time.)
+template <class G, bool HAS_WIN, int ST, bool PAIR = false, int NSEG = 0>
 __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                  cx<float>* __restrict__ gout,
                                                                  const float* __restrict__ ld_win,
@@ -341,11 +357,26 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     constexpr bool BAND = ST == 1;
     static_assert(64 % (N / T) == 0, "the inter-half twiddle uses W_64 constants: j = t + T v, W_N^(T v) = W_64^(v 64 T / N)");
     constexpr int WSTEP = 64 / (N / T);
+    // segments: PAIR: 32 of 2T points (lane: one 16-byte load each), else 2P of T points
+    constexpr int SEGLEN = PAIR ? 2 * T : T, NSEGTOT = N / SEGLEN;
+    constexpr bool SEGSKIP = NSEG > 0;
+    constexpr int NS = SEGSKIP ? NSEG : NSEGTOT;
+    static_assert(NS <= NSEGTOT, "segment count");
+    static_assert(!SEGSKIP || G::LOGN % G::LOGP == 0 || PAIR, "one output phase per lane needs a single block in the last phase");
+    static_assert(!SEGSKIP || (T % P) == 0, "rotation phase must not depend on the last radix digit");
     const int t = threadIdx.x;
     const int b = blockIdx.x;
     const int h = (b >> 3) & 1;
     const int row = ((b >> 4) << 3) + (b & 7);  // uniform; both halves of a row on the same XCD (b mod 8)
     if (row >= A.nrows) return;
+#if SWF_TRACE
+    SWF_TRACE_POINT(0);
+    if (threadIdx.x == 0 && blockIdx.x < (unsigned)kTraceBlocks) {
+        swf_trace_buf[blockIdx.x * kTracePoints + 10] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                                                       (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    }
+#endif
+    const int rot = SEGSKIP ? A.seg_rot * SEGLEN : 0;  // cyclic rotation of the transform input (points)
     int in_row = row;
     if (A.rm_mod > 0) {
         int r1 = row + A.rm_inner;
@@ -382,28 +413,39 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         const unsigned valid = dead ? 0u : (unsigned)A.ld_len;
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
-        const unsigned base8 = (unsigned)((2 * t + A.ld_a + (N >> 1)) & (N - 1)) << 3;
+        const unsigned base8 = (unsigned)((2 * t + A.ld_a + (N >> 1) + rot) & (N - 1)) << 3;
         static_for<0, R1>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
             cx<float> a[2][2];  // [q][u]
             static_for<0, 2>([&](auto qI) {
                 constexpr int q = decltype(qI)::value;
-                const unsigned off8 = (base8 + (unsigned)((r * SEG + q * H) << 3)) & (unsigned)((N << 3) - 1);
-                const f32x4 val = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off8, 0, 0));
-                if constexpr (HAS_WIN) {
-                    const f32x2 w = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(off8 >> 1), 0, 0));
-                    a[q][0] = cx<float>{val.x * w.x, val.y * w.x};
-                    a[q][1] = cx<float>{val.z * w.y, val.w * w.y};
-                } else {
-                    a[q][0] = cx<float>{val.x, val.y};
-                    a[q][1] = cx<float>{val.z, val.w};
+                if constexpr (r + R1 * q < NS) {  // segment r + 16 q can hold data
+                    const unsigned off8 = (base8 + (unsigned)((r * SEG + q * H) << 3)) & (unsigned)((N << 3) - 1);
+                    const f32x4 val = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off8, 0, 0));
+                    if constexpr (HAS_WIN) {
+                        const f32x2 w = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(off8 >> 1), 0, 0));
+                        a[q][0] = cx<float>{val.x * w.x, val.y * w.x};
+                        a[q][1] = cx<float>{val.z * w.y, val.w * w.y};
+                    } else {
+                        a[q][0] = cx<float>{val.x, val.y};
+                        a[q][1] = cx<float>{val.z, val.w};
+                    }
                 }
             });
             static_for<0, 2>([&](auto uI) {
                 constexpr int u = decltype(uI)::value;
-                x[u + 2 * r] = cx<float>{a[0][u].x + sgn * a[1][u].x, (a[0][u].y + sgn * a[1][u].y) * sg_ld};
+                if constexpr (r + R1 < NS)
+                    x[u + 2 * r] = cx<float>{a[0][u].x + sgn * a[1][u].x, (a[0][u].y + sgn * a[1][u].y) * sg_ld};
+                else if constexpr (r < NS)
+                    x[u + 2 * r] = cx<float>{a[0][u].x, a[0][u].y * sg_ld};
+                else
+                    x[u + 2 * r] = cx<float>{0.f, 0.f};
             });
         });
+#if SWF_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SWF_TRACE_POINT(1);
+#endif
         if (h) {  // uniform: odd outputs need W_N^j, j = 2t + u + SEG r:  W_N^(2t+u) * W_64^(2r)
             const f32x4 wt = *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
             const cx<float> w0 = {wt.x, wt.y}, w1 = {wt.z, wt.w};
@@ -419,24 +461,32 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
     // byte offset of plain index j = t (centred index j ^ N/2 = j + N/2 mod N), then + (v T + q H) * 8 mod 8 N
-    const unsigned base8 = (unsigned)((t + A.ld_a + (N >> 1)) & (N - 1)) << 3;
+    const unsigned base8 = (unsigned)((t + A.ld_a + (N >> 1) + rot) & (N - 1)) << 3;
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         cx<float> a[2];
         static_for<0, 2>([&](auto qI) {
             constexpr int q = decltype(qI)::value;
-            const unsigned off8 = (base8 + (unsigned)((v * T + q * H) << 3)) & (unsigned)((N << 3) - 1);
-            const f32x2 val = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)off8, 0, 0));
-            if constexpr (HAS_WIN) {
-                const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, (int)(off8 >> 1), 0, 0));
-                a[q] = cx<float>{val.x * w, val.y * w};
-            } else {
-                a[q] = cx<float>{val.x, val.y};
+            if constexpr (v + P * q < NS) {  // segment v + P q can hold data
+                const unsigned off8 = (base8 + (unsigned)((v * T + q * H) << 3)) & (unsigned)((N << 3) - 1);
+                const f32x2 val = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)off8, 0, 0));
+                if constexpr (HAS_WIN) {
+                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, (int)(off8 >> 1), 0, 0));
+                    a[q] = cx<float>{val.x * w, val.y * w};
+                } else {
+                    a[q] = cx<float>{val.x, val.y};
+                }
             }
         });
-        x[v] = cx<float>{a[0].x + sgn * a[1].x, (a[0].y + sgn * a[1].y) * sg_ld};
+        if constexpr (v + P < NS)
+            x[v] = cx<float>{a[0].x + sgn * a[1].x, (a[0].y + sgn * a[1].y) * sg_ld};
+        else if constexpr (v < NS)
+            x[v] = cx<float>{a[0].x, a[0].y * sg_ld};
+        else
+            x[v] = cx<float>{0.f, 0.f};
     });
 #else
+    static_assert(!SEGSKIP, "segment skipping is implemented on the buffer-load path");
     const int base = (t + A.ld_a + (N >> 1)) & (N - 1);  // q of plain index j = t (centred index j ^ N/2 = j + N/2 mod N)
     const float alive = dead ? 0.f : 1.f;
     static_for<0, P>([&](auto vI) {
@@ -467,6 +517,10 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     }
 
     }
+    SWF_TRACE_POINT(2);
+    // rotated input: output k = 2 e + h, e = t + (last radix digit) * H / P, carries W_N^(rot k) = W_N^(rot (2 t + h))
+    cx<float> rphi = {1.f, 0.f};
+    if constexpr (SEGSKIP) rphi = tw_full[(unsigned)(rot * (2 * t + h)) & (unsigned)(N - 1)];
     auto run_phases = [&](auto&& fin) {
         if constexpr (PAIR)
             fft_phases_pair<G, float>(x, t, smem, tw, fin);
@@ -511,6 +565,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
             const int ck = (2 * e + h) ^ (N >> 1);
             const int d = (ck + A.st_a) & (N - 1);
             const float w = scale * wv[s % CH];
+            if constexpr (SEGSKIP) v = cmul(v, rphi);
             if (d < A.st_len) {
                 f32x2 val = {v.x * w, v.y * w * sg_st};
                 if (A.accumulate) {
@@ -524,6 +579,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     }
     run_phases([&](int e, cx<float> v) {
         const int ck = (2 * e + h) ^ (N >> 1);
+        if constexpr (SEGSKIP) v = cmul(v, rphi);
         const f32x2 val = {v.x * scale, v.y * scale_im};
 #if SWF_ROW_BUFFER_ST
         unsigned off;
@@ -544,6 +600,11 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         }
 #endif
     });
+#if SWF_TRACE
+    SWF_TRACE_POINT(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SWF_TRACE_POINT(8);
+#endif
 }
 
 constexpr int kRowPassMinLog = 13;

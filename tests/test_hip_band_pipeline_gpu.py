@@ -53,7 +53,9 @@ def test_prepare_facet_band(band):
     x = (rng.standard_normal((rows, yB64)) + 1j * rng.standard_normal((rows, yB64))).astype(numpy.complex64)
     xt = torch.from_numpy(x).cuda()
     pc = band_cols(yN64, band)
-    for off, fold in ((0, False), (64 * 352, True), (-64 * 320, True)):
+    # offsets: the three of the 3x3 cover (22 of the 32 input segments hold data, three rotations: the NSEG = 22 kernel),
+    # one that is not a multiple of the 1024-point segment (23 segments: NSEG = 24), an odd one (8-byte load path)
+    for off, fold in ((0, False), (64 * 352, True), (-64 * 352, False), (-64 * 320, True), (64 * 351, False), (64 * 352 + 2, True), (4097, False)):
         got = core.prepare_facet_band(xt, off, band, fold_other_axis_window=fold).cpu().numpy()
         want = ref.prepare_facet(x.astype(complex), off, 1)
         if fold:

@@ -18,13 +18,14 @@ core = cfg.core
 sgs = bench.select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
 band = core.band_for_offsets([c.off1 for c in sgs])
 facet = torch.randn((p["yB_size"], p["yB_size"]), device="cuda", dtype=torch.complex64)
-out = core.prepare_facet_band(facet, 22528, band)
 n = 9
-for rep in range(3):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        core.prepare_facet_band(facet, 22528, band, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-print(os.environ.get("SWIFTLY_HIP_LIB", "default"), f"K1 {e0.elapsed_time(e1) / n:.4f} ms per facet")
+for off in (0, 22528, -22528):
+    out = core.prepare_facet_band(facet, off, band)
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            core.prepare_facet_band(facet, off, band, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+    print(os.environ.get("SWIFTLY_HIP_LIB", "default"), os.environ.get("SWIFTLY_ROW_SEGSKIP", ""), f"off {off}: K1 {e0.elapsed_time(e1) / n:.4f} ms per facet")
