@@ -80,12 +80,17 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN_size, int64_t 
                        const double* pswf, int device);
 void swiftly_hip_destroy(swiftly_hip_t* h);
 int64_t swiftly_hip_contribution_size(const swiftly_hip_t* h); /* xM*yN/N, core.py:48 */
-/* Sticky device-side error of the handle: non-zero once a bounded in-launch wait (the fused four-step column
- * transform hands its intermediate from pass-A to pass-B workgroups inside one launch) has timed out.  Results produced
- * since then are invalid; every later call that launches such a kernel fails with SWIFTLY_ERR_HIP.  Reads a pinned
- * host word: no synchronisation, so synchronise the stream first when checking a specific call.  (No reference
- * counterpart: numpy has no asynchronous failure mode.) */
-int swiftly_hip_async_error(const swiftly_hip_t* h);
+/* Arithmetic of the column passes of the band pipelines on complex64 data (K2 = prepare_facet along the strided axis of
+ * a wave, K3 = the m-point transform of add_to_subgrid behind it, and their backward mirrors): 32 (default) = float32
+ * throughout; 64 = loads and stores in complex64, windows / butterflies / exchanges / four-step twiddles in float64.
+ * These are the transforms whose rounding errors are amplified by BOTH facet windows (1/pswf, up to 90 per axis) before
+ * anything cancels them; in float64 the end-to-end complex64 error against the numpy reference drops from 1.0e-5 to
+ * 2.8e-6 forward and from 2.1e-5 to 5.1e-6 backward on the N = 65536 workload (storage floor 3.3e-6 on the probe
+ * configuration of tests/accuracy_model.py), for 1.5x the pass time.  Initial value from the
+ * environment variable SWIFTLY_COL_F64 (0 | 1).  (No reference counterpart: numpy computes in complex128 throughout,
+ * core.py:212-222.) */
+int swiftly_hip_set_column_precision(swiftly_hip_t* h, int bits);
+int swiftly_hip_get_column_precision(const swiftly_hip_t* h);
 
 /* -- facet -> subgrid ------------------------------------------------------ */
 
@@ -379,22 +384,6 @@ int swiftly_hip_wave_split_subgrids(swiftly_hip_t* h, int dtype, const void* sub
                                     const int64_t* facet_off0s, const int64_t* facet_off1s, void* work,
                                     int64_t work_elems, void* out, int64_t out_facet_stride, int64_t out_sub_stride,
                                     void* stream);
-
-/* Forward subgrid side with the axis-0 half finished FIRST (r3; replaces transform_contributions + sum_finish_facets +
- * finish_subgrid_batch(axis 0) on one GPU): the same reference calls -- extract_from_facet, add_to_subgrid along both
- * axes, the facet sums and finish_subgrid + masks, api_helper.py:73-112 -- re-associated by facet off1 GROUP so that the
- * only intermediate is V[g][b] = [subgrid_size, m] per group (finished along axis 0, not yet transformed along axis 1):
- *   q + f*q_facet_stride = Q_f[rows kept, m] (output of prepare_facet_columns), rowmap as there;
- *   v_work: device scratch of >= n_groups * nsub * subgrid_size * m complex64 elements (n_groups = distinct facet off1);
- *   out[b] = finished, masked subgrid [subgrid_size, subgrid_size], contiguous.
- * Available when swiftly_hip_grouped_subgrid_side_supported(h) != 0 (m < xM <= 1024 with a kernel instance), <= 64 facets. */
-int swiftly_hip_grouped_subgrid_side_supported(const swiftly_hip_t* h);
-int swiftly_hip_wave_subgrid_side_grouped(swiftly_hip_t* h, int dtype, const void* q, int64_t q_row_stride,
-                                          int64_t q_facet_stride, const int32_t* rowmap, int64_t nfacets,
-                                          const int64_t* facet_off0s, const int64_t* facet_off1s, int64_t nsub,
-                                          const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
-                                          const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
-                                          void* v_work, int64_t v_work_elems, void* out, void* stream);
 
 /* Backward pass with the contiguous-axis transform LAST (mirror of prepare_facet_band / prepare_facet_columns;
  * waves = subgrids sharing off1).  Replaces, for all facets of a wave, api_helper.accumulate_column +

@@ -27,8 +27,63 @@ static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbat
                            a.out, a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
     return (int)hipGetLastError();
 }
+// float64 arithmetic (ColPassArgs::f64): lengths 32 .. 512
+constexpr int kColF64MinLog = 5;
+template <int LOGN, int MODE>
+static int launch_mode_f64(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
+    if constexpr (LOGN < kColF64MinLog || LOGN > kColPassMaxLogF64) {
+        return (int)hipErrorInvalidConfiguration;
+    } else {
+        using G = typename CGeoFor<LOGN, double>::type;
+        if (!a.twd || (MODE == 0 && !a.twd_full)) return (int)hipErrorInvalidValue;
+        dim3 grid((unsigned)((a.ncols + G::COLS - 1) / G::COLS), (unsigned)outer, (unsigned)nbatch);
+        if (a.gs) {
+            if constexpr (MODE != 1 && !G::HALF) {
+                hipLaunchKernelGGL((col_pass_kernel<G, MODE, true, true, double>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in,
+                                   a.out, a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.twd, a.twd_full, cz);
+                return (int)hipGetLastError();
+            } else {
+                return (int)hipErrorInvalidConfiguration;
+            }
+        }
+        if (MODE == 2 || a.scratch_nt)
+            hipLaunchKernelGGL((col_pass_kernel<G, MODE, true, false, double>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in,
+                               a.out, a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.twd, a.twd_full, cz);
+        else
+            hipLaunchKernelGGL((col_pass_kernel<G, (MODE == 2 ? 0 : MODE), false, false, double>), grid, dim3(G::NT),
+                               G::LDS_BYTES, s, a, a.in, a.out, a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.twd,
+                               a.twd_full, cz);
+        return (int)hipGetLastError();
+    }
+}
+template <int LOGN, int MODE>
+static int init_mode_f64() {
+    if constexpr (LOGN < kColF64MinLog || LOGN > kColPassMaxLogF64) {
+        return 0;
+    } else {
+        using G = typename CGeoFor<LOGN, double>::type;
+        int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE, true, false, double>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (!rc && MODE != 2)
+            rc = (int)hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&col_pass_kernel<G, (MODE == 2 ? 0 : MODE), false, false, double>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if constexpr (MODE != 1 && !G::HALF) {
+            if (!rc)
+                rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE, true, true, double>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        }
+        return rc;
+    }
+}
+
 template <int LOGN>
 static int launch_one(int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
+    if (a.f64) {
+        if (mode == 0) return launch_mode_f64<LOGN, 0>(a, cz, outer, nbatch, s);
+        if (mode == 1) return launch_mode_f64<LOGN, 1>(a, cz, outer, nbatch, s);
+        return launch_mode_f64<LOGN, 2>(a, cz, outer, nbatch, s);
+    }
     if (mode == 0) return launch_mode<LOGN, 0>(a, cz, outer, nbatch, s);
     if (mode == 1) return launch_mode<LOGN, 1>(a, cz, outer, nbatch, s);
     return launch_mode<LOGN, 2>(a, cz, outer, nbatch, s);
@@ -54,6 +109,9 @@ static int init_one() {
     int rc = init_mode<LOGN, 0>();
     if (!rc) rc = init_mode<LOGN, 1>();
     if (!rc) rc = init_mode<LOGN, 2>();
+    if (!rc) rc = init_mode_f64<LOGN, 0>();
+    if (!rc) rc = init_mode_f64<LOGN, 1>();
+    if (!rc) rc = init_mode_f64<LOGN, 2>();
     return rc;
 }
 
@@ -76,5 +134,6 @@ int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColZ& cz, in
     return CDispatch<kColPassMinLog, kColPassMaxLog>::launch(logn, mode, a, cz, outer, nbatch, s);
 }
 int init_col_pass() { return CDispatch<kColPassMinLog, kColPassMaxLog>::init(); }
+bool col_pass_f64_supported(int logn) { return logn >= kColF64MinLog && logn <= kColPassMaxLogF64; }
 
 }  // namespace swf

@@ -55,7 +55,8 @@ static int make_twiddles(swiftly_hip* h, int logn) {
         if (int rc = upload(h, &d, t)) return rc;
         h->tw_f[logn] = d;
     }
-    if (logn <= kMaxLogNDouble && !h->tw_d.count(logn)) {
+    // (double tables up to 2^16: the float64-arithmetic column passes need the four-step twiddles of the whole length)
+    if (logn <= kMaxLogNFloat + 1 && !h->tw_d.count(logn)) {
         std::vector<cx<double>> t(n);
         for (int k = 0; k < n; k++) {
             long double a = -2.0L * 3.14159265358979323846264338327950288L * k / n;
@@ -214,8 +215,6 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         if (int rc = init_col_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (col pass): %d", rc);
         if (int rc = init_row_pass()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (row pass): %d", rc);
         if (int rc = init_sum_finish_rows()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (sum finish): %d", rc);
-        if (int rc = init_group_finish()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (group finish): %d", rc);
-        if (int rc = init_col_fourstep()) return fail(SWIFTLY_ERR_HIP, "kernel attribute setup failed (fused four-step): %d", rc);
         // keep freed scratch (the four-step intermediate, up to yN*yB*8 bytes) in the stream-ordered pool instead of
         // returning it to the driver at every synchronisation point
         hipMemPool_t pool;
@@ -237,6 +236,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
     h->log_yN = ilog2_exact(yN);
     h->log_xM = ilog2_exact(xM);
     h->log_m = ilog2_exact(h->m);
+    if (const char* e = getenv("SWIFTLY_COL_F64")) h->col_f64 = atoi(e) != 0;
     // windows: 1/pswf (Fb, core.py:104-108) and Fn (core.py:110-117)
     std::vector<double> ip(yN);
     std::vector<float> ipf(yN);
@@ -270,18 +270,6 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
         if (!rc) rc = make_bluestein(h, len);
     for (int64_t len : {yN, xM, h->m})
         if (!rc) rc = make_mixed(h, len);
-    if (!rc) {
-        void* hp = nullptr;
-        void* dp = nullptr;
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
-            if (hp) (void)hipHostFree(hp);
-            rc = fail(SWIFTLY_ERR_HIP, "hipHostMalloc(error word) failed");
-        } else {
-            h->async_err = (unsigned*)hp;
-            h->async_err_dev = (unsigned*)dp;
-            *(volatile unsigned*)h->async_err = 0;
-        }
-    }
     if (rc) {
         swiftly_hip_destroy(h);
         return rc;
@@ -294,14 +282,9 @@ void swiftly_hip_destroy(swiftly_hip_t* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
-    if (h->async_err) (void)hipHostFree(h->async_err);
     delete h;
 }
 
-int swiftly_hip_async_error(const swiftly_hip_t* h) {
-    if (!h || !h->async_err) return 0;
-    return (int)*(volatile const unsigned*)h->async_err;
-}
 
 int64_t swiftly_hip_contribution_size(const swiftly_hip_t* h) { return h ? h->m : -1; }
 
@@ -406,24 +389,6 @@ ColZ plain_colz() {
     return z;
 }
 
-// the tables of a fused four-step launch (at most kFsZB subgrids per facet, no gather-sum chunks)
-static ColZS slim_colz(const ColZ& z) {
-    ColZS s;
-    std::memset(&s, 0, sizeof s);
-    s.flags = z.flags;
-    s.nb = z.nb;
-    for (int b = 0; b < kFsZB; b++) {
-        s.b_rot[b] = z.b_rot[b]; s.b_base[b] = z.b_base[b];
-        s.b_lda[b] = z.b_lda[b]; s.b_ldc[b] = z.b_ldc[b]; s.b_sta[b] = z.b_sta[b];
-        s.b_out_off[b] = z.b_out_off[b]; s.b_out_fs[b] = z.b_out_fs[b];
-    }
-    for (int f = 0; f < kColZF; f++) {
-        s.f_lda[f] = z.f_lda[f];
-        s.f_sta[f] = z.f_sta[f];
-    }
-    return s;
-}
-
 int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz, int outer, int nb, hipStream_t st) {
     int e = launch_col_pass(lg, mode, args, cz, outer, nb, st);
     if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -462,10 +427,18 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
     if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return -1;
     const uint64_t n = uint64_t(1) << logn;
+    // float64 arithmetic where the caller asks for it and the instances exist (else float32, silently: same results to
+    // float32 rounding)
+    const bool f64 = c.f64 && (two ? (col_pass_f64_supported(l1) && col_pass_f64_supported(l2))
+                                   : (col_pass_f64_supported(logn) && !(c.gs && logn > 8)));
     if (!two) {
         ColPassArgs one = c;
         one.tw = twiddles<float>(h, logn);
         if (!one.tw) return -1;
+        one.f64 = f64 ? 1 : 0;
+        one.twd = f64 ? twiddles<double>(h, logn) : nullptr;
+        one.twd_full = one.twd;
+        if (f64 && !one.twd) return -1;
         if (qmul > 0) {
             one.full_logn = logn; one.full_n = full_n; one.ld_plain = 1; one.st_qmul = qmul; one.st_qadd = qadd;
             one.ld_mul = one.st_mul = 1;
@@ -477,6 +450,10 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     const cx<float>* tw2 = twiddles<float>(h, l2);
     const cx<float>* twf = twiddles<float>(h, logn);
     if (!tw1 || !tw2 || !twf) return -1;
+    const cx<double>* twd1 = f64 ? twiddles<double>(h, l1) : nullptr;
+    const cx<double>* twd2 = f64 ? twiddles<double>(h, l2) : nullptr;
+    const cx<double>* twdf = f64 ? twiddles<double>(h, logn) : nullptr;
+    if (f64 && (!twd1 || !twd2 || !twdf)) return -1;
     if (n * (uint64_t)W >= (uint64_t(1) << 32)) return -1;
     // Column slabs (tuning knob SWIFTLY_SLAB_COLS, 0 = off): both passes of a slab run back to back so that the
     // four-step intermediate of the slab is re-read while it may still sit in the 256 MiB Infinity Cache.
@@ -484,52 +461,24 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     const bool gathered = (cz.flags & kZColGather) != 0;
     const long long slab = (slab_env >= 64 && nb == 1 && !gathered) ? (slab_env / 64) * 64 : (long long)W;
     const long long Ws = std::min<long long>(slab, (long long)W);  // scratch row width
-    // both passes in one launch with the intermediate handed over in flight (swiftly_fourstep.h; measured slower than
-    // the two launches, see there): opt-in with SWIFTLY_FOURSTEP_FUSED=1 (read per call), SWIFTLY_FOURSTEP_LAG = distance
-    // in chunks between a chunk's pass A and its pass B.  Needs one arrival counter per (batch item, 64-column tile),
-    // taken from the tail of the scratch.
-    const char* fused_s = getenv("SWIFTLY_FOURSTEP_FUSED");
-    const char* lag_s = getenv("SWIFTLY_FOURSTEP_LAG");
-    const int fused_env = fused_s ? atoi(fused_s) : 0;
-    const int lag_env = lag_s ? std::max(1, atoi(lag_s)) : 4;
-    const long long chunks = (long long)nb * ((W + 63) / 64);
-    const bool fused = fused_env && Ws == (long long)W && !c.gs && cz.nb <= kFsZB && chunks < (1 << 24) && qmul == 0 &&
-                       col_fourstep_supported(l1, l2);
     const size_t scratch_bytes = (size_t)nb * n * (size_t)Ws * sizeof(cx<float>);
-    const size_t cnt_bytes = fused ? (((size_t)chunks * sizeof(unsigned) + 255) & ~size_t(255)) : 0;
     void* scratch = nullptr;
-    unsigned* counters = nullptr;
-    bool own_counters = false;
     hipError_t he = hipSuccess;
     // caller-provided workspace (deterministic; the stream-ordered pool reuses memory across STREAMS only
     // opportunistically, which made the two-stream schedule fall back to fresh multi-GB allocations on some runs)
     const bool own = !(ws && ws_bytes >= scratch_bytes);
     if (own) {
-        he = hipMallocAsync(&scratch, scratch_bytes + cnt_bytes, st);
+        he = hipMallocAsync(&scratch, scratch_bytes, st);
         if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(two-pass scratch): %s", hipGetErrorString(he));
-        if (fused) counters = (unsigned*)((char*)scratch + scratch_bytes);
     } else {
         scratch = ws;
-        if (fused) {
-            if (ws_bytes >= scratch_bytes + cnt_bytes) {
-                counters = (unsigned*)((char*)scratch + scratch_bytes);
-            } else {  // a fixed-size request: served from the pool without a driver call after the first time
-                void* p = nullptr;
-                he = hipMallocAsync(&p, std::max<size_t>(cnt_bytes, size_t(64) << 10), st);
-                if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipMallocAsync(hand-off counters): %s", hipGetErrorString(he));
-                counters = (unsigned*)p;
-                own_counters = true;
-            }
-        }
     }
     int rc = 0;
-    if (swiftly_hip_async_error(h))
-        rc = fail(SWIFTLY_ERR_HIP, "an in-launch hand-off of an earlier call on this handle timed out (results since then are invalid)");
     // scratch accesses: a small intermediate is left cacheable so that pass B finds it in the 256 MiB Infinity
     // Cache (measured: the 160 MB of a K5b wave, K3-5 12.5 -> 11.6 ms per pass); a large one is streamed
     // non-temporally (measured: K2, 1.2 GB per wave, 18.5 ms vs 19.6 ms cacheable).  SWIFTLY_SCRATCH_NT forces.
     static const int scratch_nt_env = getenv("SWIFTLY_SCRATCH_NT") ? atoi(getenv("SWIFTLY_SCRATCH_NT")) : -1;
-    const int scratch_nt = scratch_nt_env >= 0 ? scratch_nt_env : (!fused && scratch_bytes > (size_t(192) << 20) ? 1 : 0);
+    const int scratch_nt = scratch_nt_env >= 0 ? scratch_nt_env : (scratch_bytes > (size_t(192) << 20) ? 1 : 0);
     for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
         const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
         // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
@@ -542,6 +491,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.ld_mul = n2;
         A.out_i_rows = n2; A.out_o_rows = 1;
         A.tw = tw1; A.tw_full = twf;
+        A.f64 = f64 ? 1 : 0; A.twd = twd1; A.twd_full = twdf;
         if (qmul > 0) {
             A.full_logn = logn; A.full_n = 0; A.ld_plain = 1; A.st_qmul = 0;
         }
@@ -549,10 +499,8 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.col_win = nullptr; A.st_rowmap = nullptr; A.st_win = nullptr; A.st_win2 = nullptr;
         ColZ za = cz;
         za.flags &= ~kZColScatter;  // the scratch is written plainly
-        if (!fused) {
-            rc = launch_col_checked(l1, 0, A, za, n2, nb, st);
-            if (rc) break;
-        }
+        rc = launch_col_checked(l1, 0, A, za, n2, nb, st);
+        if (rc) break;
         // pass B: length n2 over y2, outer = k1; output index k1 + n1*k2
         ColPassArgs B = c;
         B.scratch_nt = scratch_nt;
@@ -566,26 +514,13 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         B.out = c.out + c0;
         B.st_mul = n1;
         B.tw = tw2; B.tw_full = twf;
+        B.f64 = f64 ? 1 : 0; B.twd = twd2; B.twd_full = twdf;
         if (qmul > 0) {
             B.full_logn = logn; B.full_n = full_n; B.st_qmul = qmul; B.st_qadd = qadd;
         }
         B.conj_ld = 0;
         if (B.col_win) B.col_win += c0;
-        if (!fused) {
-            rc = launch_col_checked(l2, 1, B, zb, n1, nb, st);
-            continue;
-        }
-        he = hipMemsetAsync(counters, 0, (size_t)chunks * sizeof(unsigned), st);
-        if (he != hipSuccess) {
-            rc = fail(SWIFTLY_ERR_HIP, "hipMemsetAsync(hand-off counters): %s", hipGetErrorString(he));
-            break;
-        }
-        const int e = launch_col_fourstep(l1, l2, A, B, slim_colz(za), slim_colz(zb), nb, lag_env, counters, h->async_err_dev, st);
-        if (e) rc = fail(SWIFTLY_ERR_HIP, "fused four-step launch failed: %s", e < 0 ? "no instance" : hipGetErrorString((hipError_t)e));
-    }
-    if (own_counters) {
-        he = hipFreeAsync(counters, st);
-        if (!rc && he != hipSuccess) rc = fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(he));
+        rc = launch_col_checked(l2, 1, B, zb, n1, nb, st);
     }
     if (own) {
         he = hipFreeAsync(scratch, st);

@@ -18,10 +18,8 @@
 
 #include "../../include/swiftly_hip.h"
 #include "swiftly_colpass.h"
-#include "swiftly_fourstep.h"
 #include "swiftly_rowpass.h"
 #include "swiftly_sumfinish.h"
-#include "swiftly_groupfinish.h"
 #include "swiftly_rows.h"
 #include "swiftly_bluestein.h"
 #include "swiftly_mixed.h"
@@ -83,10 +81,9 @@ struct swiftly_hip {
     };
     std::map<int64_t, Mixed> mixed;
     std::vector<void*> allocs;
-    // sticky error word of the in-launch hand-offs (swiftly_fourstep.h): pinned host memory the device writes on a
-    // timed-out wait; checked at the start of every call that launches such a kernel and by swiftly_hip_async_error
-    unsigned* async_err = nullptr;      // host view
-    unsigned* async_err_dev = nullptr;  // device view of the same word
+    // float64 arithmetic in the column passes of the band pipelines (K2, K3 and their backward mirrors; complex64 data):
+    // 0 (default: float32 arithmetic everywhere) | 1 (swiftly_hip_set_column_precision, env SWIFTLY_COL_F64)
+    int col_f64 = 0;
 };
 
 template <typename R>
@@ -132,6 +129,16 @@ static const int kTwoPassMinLog = 9;
 
 // column-tile passes (swiftly_abi.hip)
 ColZ plain_colz();
+// single-pass launch of length 2^logn: float64 arithmetic when the handle asks for it and the instance exists
+inline void set_col_precision(const swiftly_hip* h, ColPassArgs& c, int logn) {
+    c.f64 = 0;
+    if (!h->col_f64 || !col_pass_f64_supported(logn) || c.gs) return;
+    const cx<double>* t = twiddles<double>(h, logn);
+    if (!t) return;
+    c.f64 = 1;
+    c.twd = t;
+    c.twd_full = t;
+}
 int launch_col_checked(int lg, int mode, const ColPassArgs& args, const ColZ& cz, int outer, int nb, hipStream_t st);
 // scratch handed down by an entry point for the duration of one ABI call on this host thread (see col_transform)
 extern thread_local void* t_call_ws;

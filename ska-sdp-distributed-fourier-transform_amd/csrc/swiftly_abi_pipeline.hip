@@ -272,6 +272,7 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
     c.conj_ld = c.conj_st = 1;
     c.cg_mod = m; c.cg_full = yN;
     c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = band_half_of(h, band_len);
+    c.f64 = h->col_f64;  // (col_transform falls back to float32 where the instances do not exist)
     // tuning knob: facets per launch group (both passes of a group run back to back)
     static const int per_env = getenv("SWIFTLY_K2_FACETS") ? atoi(getenv("SWIFTLY_K2_FACETS")) : kColZF;
     const int per_f = std::max(1, std::min(per_env, (int)kColZF));
@@ -408,6 +409,7 @@ static int transform_contributions_impl(swiftly_hip_t* h, int dtype, const void*
                     cz.b_out_off[b] = out_offs[b0 + b] + f0 * out_fstrides[b0 + b];
                 }
             }
+            set_col_precision(h, c, h->log_m);
             if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, nf * nb, (hipStream_t)stream)) return rc;
         }
     }
@@ -533,6 +535,7 @@ int swiftly_hip_split_prepare_facets(swiftly_hip_t* h, int dtype, const void* in
             c.in_bdiv = nb; c.in_bs_hi = out_facet_stride; c.in_bs = out_sub_stride;
             c.out = (cx<float>*)out + f0 * out_facet_stride + b0 * out_sub_stride;
             c.out_bdiv = nb; c.out_bs_hi = out_facet_stride; c.out_bs = out_sub_stride;
+            set_col_precision(h, c, h->log_m);
             if (int rc = launch_col_checked(h->log_m, 2, c, cz, 1, nf * nb, (hipStream_t)stream)) return rc;
         }
     }
@@ -631,110 +634,6 @@ int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, in
                                             xM * xA, xA * xA, sub_off0s, mask0 ? mask0_bs : 0, stream);
 }
 
-/* Forward subgrid side with the axis-0 half finished first (swiftly_groupfinish.h): the wave's facet
- * buffers Q_f -> V[g][b] = [xA, m] per off1 group g of the facet list (gather + add_to_subgrid axis 0 + sum over the
- * facets of the group + finish_subgrid axis 0 + mask0, ONE kernel) -> out[b] = [xA, xA] (add_to_subgrid axis 1 + sum over
- * the groups + finish_subgrid axis 1 + mask1, sum_finish_facets in direct-row mode).  78.8 -> 48.6 MB of HBM traffic
- * per subgrid for the 3x3 cover of the 64k workload. */
-int swiftly_hip_grouped_subgrid_side_supported(const swiftly_hip_t* h) {
-    return h && h->log_m >= 0 && h->log_xM >= 0 && group_finish_supported(h->log_m, h->log_xM) &&
-           sum_finish_supported(h->log_m, h->log_xM);
-}
-
-int swiftly_hip_wave_subgrid_side_grouped(swiftly_hip_t* h, int dtype, const void* q, int64_t q_row_stride,
-                                          int64_t q_facet_stride, const int32_t* rowmap, int64_t nfacets,
-                                          const int64_t* facet_off0s, const int64_t* facet_off1s, int64_t nsub,
-                                          const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
-                                          const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
-                                          void* v_work, int64_t v_work_elems, void* out, void* stream) {
-    if (!h || !q || !v_work || !out || !facet_off0s || !facet_off1s || !sub_off0s || !sub_off1s)
-        return fail(SWIFTLY_ERR_PARAM, "null argument");
-    DeviceGuard device_guard_(h->device);
-    CHECK_SUBGRID_SIZE();
-    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_subgrid_side_grouped: complex64 only");
-    if (!swiftly_hip_grouped_subgrid_side_supported(h))
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_subgrid_side_grouped: (m, xM) = (%lld, %lld) not instantiated", (long long)h->m,
-                    (long long)h->xM);
-    if (nfacets <= 0 || nfacets > kGroupFinishMaxFacets)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_subgrid_side_grouped: 1..%d facets supported", kGroupFinishMaxFacets);
-    if (nsub <= 0) return 0;
-    const int m = (int)h->m, xM = (int)h->xM, yN = (int)h->yN, xA = (int)subgrid_size;
-    if ((uint64_t)yN * (uint64_t)q_row_stride >= (uint64_t(1) << 32))
-        return fail(SWIFTLY_ERR_PARAM, "strides too large for 32-bit offsets");
-    // off1 groups in order of first appearance
-    std::vector<int64_t> goff;
-    std::vector<int> gof((size_t)nfacets);
-    for (int64_t f = 0; f < nfacets; f++) {
-        size_t g = 0;
-        while (g < goff.size() && goff[g] != facet_off1s[f]) g++;
-        if (g == goff.size()) goff.push_back(facet_off1s[f]);
-        gof[(size_t)f] = (int)g;
-    }
-    const int64_t ng = (int64_t)goff.size();
-    const int64_t v_sub = (int64_t)xA * m, v_grp = nsub * v_sub;
-    if (v_work_elems < ng * v_grp)
-        return fail(SWIFTLY_ERR_PARAM, "v_work holds %lld elements, %lld needed", (long long)v_work_elems, (long long)(ng * v_grp));
-    GroupFinishArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.in_fs = q_facet_stride;
-    a.in_pitch = (unsigned)q_row_stride;
-    a.out_gs = v_grp; a.out_bs = v_sub;
-    a.rowmap = rowmap;
-    a.yN = yN; a.xA = xA; a.ncols = m; a.ngroups = (int)ng;
-    int n = 0;
-    for (int64_t g = 0; g < ng; g++) {
-        a.gstart[g] = n;
-        for (int64_t f = 0; f < nfacets; f++)
-            if (gof[(size_t)f] == (int)g) {
-                a.fidx[n] = (int)f;
-                a.sp0[n] = (int)floordiv(facet_off0s[f] * h->xM, h->N);
-                n++;
-            }
-    }
-    a.gstart[ng] = n;
-    a.fn = h->fn_f;
-    a.mask_bs = mask0 ? mask0_bs : 0;
-    a.tw_m = twiddles<float>(h, h->log_m);
-    a.tw_x = twiddles<float>(h, h->log_xM);
-    if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    SumFinishFacetArgs sf;
-    std::memset(&sf, 0, sizeof sf);
-    sf.in_fs = v_grp; sf.in_bs = v_sub; sf.in_rs = m;
-    sf.out_bs = (int64_t)xA * xA; sf.out_rs = xA;
-    sf.nrows = xA; sf.nfacets = (int)ng; sf.xA = xA; sf.direct_rows = 1;
-    sf.ngroups = (int)ng;  // direct-row mode: every input is a group of its own
-    for (int64_t g = 0; g < ng; g++) {
-        sf.gstart[g] = (int)g;
-        sf.fidx[g] = (int)g;
-        sf.gsp1[g] = (int)floordiv(goff[(size_t)g] * h->xM, h->N);
-    }
-    sf.gstart[ng] = (int)ng;
-    fill_group_rounds(sf, h);
-    sf.fn = h->fn_f;
-    sf.mask_bs = mask1 ? mask1_bs : 0;
-    sf.tw_m = a.tw_m; sf.tw_x = a.tw_x;
-    for (int64_t b0 = 0; b0 < nsub; b0 += kGroupFinishMaxBatch) {
-        const int nb = (int)std::min<int64_t>(kGroupFinishMaxBatch, nsub - b0);
-        a.in = (const cx<float>*)q;
-        a.out = (cx<float>*)v_work + b0 * v_sub;
-        a.mask = mask0 ? (const float*)mask0 + b0 * mask0_bs : nullptr;
-        for (int b = 0; b < nb; b++) {
-            const int64_t s = floordiv(sub_off0s[b0 + b] * h->yN, h->N);
-            a.lda[b] = pmod(-s, m);
-            a.ldc[b] = pmod(yN / 2 - m / 2 + s, yN);
-            a.st_a[b] = pmod(-(xM / 2 - xA / 2 + sub_off0s[b0 + b]), xM);
-        }
-        int e = launch_group_finish(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
-        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-        sf.in = (const cx<float>*)v_work + b0 * v_sub;
-        sf.out = (cx<float>*)out + b0 * sf.out_bs;
-        sf.mask = mask1 ? (const float*)mask1 + b0 * mask1_bs : nullptr;
-        for (int b = 0; b < nb; b++) sf.st_a[b] = pmod(-(xM / 2 - xA / 2 + sub_off1s[b0 + b]), xM);
-        e = launch_sum_finish_facets(h->log_m, h->log_xM, sf, nb, (hipStream_t)stream);
-        if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    }
-    return 0;
-}
 
 int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void* parts, int64_t part_row_stride,
                                          int64_t nchunks, const int64_t* chunk_offsets,
@@ -774,6 +673,7 @@ int swiftly_hip_accumulate_facet_columns(swiftly_hip_t* h, int dtype, const void
     c.ld_mul = c.st_mul = 1;
     c.ld_a = 0; c.ld_len = yN; c.ld_c = 0; c.ld_mod = yN;
     c.ld_rowmap = row_sources; c.gs = 1;
+    c.f64 = h->col_f64;
     c.st_a = 0; c.st_len = (int)facet_size; c.st_c = 0; c.st_mod = (int)facet_size;
     c.st_win = masks; c.st_win_bs = masks ? facet_size : 0;
     c.st_win2 = h->invp_f + lo;

@@ -17,6 +17,14 @@ __global__ void cu_census_kernel(int* __restrict__ out) {
 
 extern "C" {
 
+int swiftly_hip_set_column_precision(swiftly_hip_t* h, int bits) {
+    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    if (bits != 32 && bits != 64) return fail(SWIFTLY_ERR_PARAM, "column precision must be 32 or 64");
+    h->col_f64 = bits == 64;
+    return 0;
+}
+int swiftly_hip_get_column_precision(const swiftly_hip_t* h) { return h ? (h->col_f64 ? 64 : 32) : -1; }
+
 int swiftly_hip_debug_row_band_occupancy(void) { return swf::row_pass_band_occupancy(); }
 
 int swiftly_hip_debug_occupancy(int lds_bytes) { return swf::row_pass_half_occupancy(lds_bytes); }

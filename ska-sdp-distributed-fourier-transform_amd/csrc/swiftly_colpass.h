@@ -88,6 +88,14 @@ struct ColPassArgs {
     const float* col_win;  // optional real factor per column applied on store (see RowsArgs::row_win)
     const cx<float>* tw;       // exp(-2 pi i k / n), this pass's length
     const cx<float>* tw_full;  // exp(-2 pi i k / 2^full_logn)
+    // float64 ARITHMETIC (r4): complex64 loads and stores, everything in between -- windows, butterflies, LDS
+    // exchange, four-step twiddle -- in double, with double tables.  For the two transforms whose rounding errors are
+    // amplified by BOTH facet windows before anything cancels them (K2 = the yN-point transform along the strided
+    // axis, K3 = the m-point transform behind it, and their backward mirrors; tests/accuracy_model.py): end-to-end
+    // complex64 error 1.3e-5 -> 3.5e-6 on the probe configuration, storage floor 3.3e-6.
+    int f64;
+    const cx<double>* twd;
+    const cx<double>* twd_full;
     int tw_on_store;
     float scale;
     int conj_ld, conj_st, accumulate;
@@ -125,7 +133,7 @@ using ColZ = ColZT<kColZB, kColZF, kColZC>;
 // columns wide and a wave works on TWO rows, lanes 0-31 / 32-63 -- half the LDS per point, which lets a 1024-point
 // transform run in a single pass (1024 x 32 x 4 B = 128 KiB with the re/im-split exchange) instead of a four-step
 // through HBM; the row bookkeeping is per half-wave (two v_readlane + a select instead of one v_readlane).
-template <int LOGN_, int LOGP_, bool SPLIT_, int COLS_ = 64>
+template <int LOGN_, int LOGP_, bool SPLIT_, int COLS_ = 64, int RSZ_ = 4>
 struct CGeo {
     static constexpr int LOGN = LOGN_, LOGP = LOGP_;
     static constexpr bool SPLIT = SPLIT_;
@@ -133,10 +141,11 @@ struct CGeo {
     static constexpr bool WAVE_ROWS = false;  // a column's points are spread over the T thread-rows
     static constexpr int COLS = COLS_;
     static constexpr bool HALF = COLS_ == 32;
-    static_assert(COLS_ == 64 || (COLS_ == 32 && P == 32 && T % 2 == 0), "32-column tiles: one row slot per lane of a half-wave");
+    static_assert(COLS_ == 64 || (COLS_ == 32 && P <= 32 && T % 2 == 0), "32-column tiles: one row slot per lane of a half-wave");
     static constexpr int NT = COLS * T;
     static constexpr int RB = COLS;  // columns per tile
-    static constexpr int ELEM = SPLIT ? 4 : 8;
+    static constexpr int ELEM = SPLIT ? RSZ_ : 2 * RSZ_;  // RSZ_ = size of the real type of the exchange
+    static constexpr bool LEAN_TW = RSZ_ == 8;            // double: inter-phase twiddles in the register-lean form
     static constexpr int PITCH = 0;  // unused (interleaved-rows layout)
     static constexpr int LOGPAD = 4;  // unused
     static constexpr size_t LDS_BYTES = T > 1 ? (size_t)N * RB * ELEM : 0;
@@ -144,8 +153,8 @@ struct CGeo {
     static constexpr int MINW = NT >= 256 ? 4 : 1;
 };
 
-// the geometry used for a LOGN-point pass
-template <int LOGN>
+// the geometry used for a LOGN-point pass (float arithmetic)
+template <int LOGN, typename RC = float>
 struct CGeoFor {
     static constexpr int LOGP = LOGN < 5 ? LOGN : 5;
     // exchange re and im separately from 128 rows on: 32 KiB (n = 128) / 64 KiB (n = 256) of LDS per
@@ -154,6 +163,14 @@ struct CGeoFor {
     // 1024 points: 32-column tiles (two rows per wave), 128 KiB.  (The same tiles for 512 points -- 64 KiB, two
     // workgroups per CU instead of one -- were measured r3 on the 64k pass: 43.37 vs 43.29 ms, no gain; not kept.)
     using type = CGeo<LOGN, LOGP, (LOGN >= 7), (LOGN >= 10 ? 32 : 64)>;
+};
+// double arithmetic: 16 points per lane (64 VGPRs of data), re / im exchanged separately; 128 points: 512 threads and
+// 64 KiB (two workgroups per CU), 256 points: 1024 threads and 128 KiB, 512 points: 32-column tiles, 1024 threads, 128 KiB
+constexpr int kColPassMaxLogF64 = 9;
+template <int LOGN>
+struct CGeoFor<LOGN, double> {
+    static constexpr int LOGP = LOGN < 4 ? LOGN : 4;
+    using type = CGeo<LOGN, LOGP, true, (LOGN >= 9 ? 32 : 64), 8>;
 };
 
 // value of `val` held by the lane that describes row slot v of THIS lane's half-wave (HALF) / of the wave
@@ -171,6 +188,13 @@ __device__ __forceinline__ float slot_bcast_f(float val, int v, int hw) {
     return __builtin_bit_cast(float, slot_bcast<HALF>(__builtin_bit_cast(int, val), v, hw));
 }
 
+template <bool HALF>
+__device__ __forceinline__ double slot_bcast_f(double val, int v, int hw) {
+    const long long b = __builtin_bit_cast(long long, val);
+    const unsigned lo = (unsigned)slot_bcast<HALF>((int)b, v, hw), hi = (unsigned)slot_bcast<HALF>((int)(b >> 32), v, hw);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // MODE: 0 = pass A (mapped load, four-step twiddle, raw store to scratch)
 //       1 = pass B (raw load from scratch, mapped store)
 //       2 = single pass (mapped load, mapped store)
@@ -181,12 +205,12 @@ __device__ __forceinline__ float slot_bcast_f(float val, int v, int hw) {
 // coalesced vector load per table instead of P dependent scalar loads), and
 // the main loops fetch the values with v_readlane.  The output-side
 // bookkeeping is issued before the butterflies so its latency hides under them.
-template <class G, int MODE, bool SNT, bool GS, class CZ>
+template <class G, int MODE, bool SNT, bool GS, class CZ, typename RC = float>
 __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<float>* __restrict__ gin,
                                               cx<float>* __restrict__ gout, const float* __restrict__ ld_win,
                                               const float* __restrict__ ld_win2, const float* __restrict__ st_win,
                                               const float* __restrict__ st_win2, const int* __restrict__ st_rowmap,
-                                              const cx<float>* __restrict__ tw, const cx<float>* __restrict__ tw_full,
+                                              const cx<RC>* __restrict__ tw, const cx<RC>* __restrict__ tw_full,
                                               const CZ& cz, const int wave, const int lane, const int bx, const int o,
                                               const int z, unsigned char* smem) {
     constexpr int P = G::P, T = G::T;
@@ -241,9 +265,9 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
         : A.out_bdiv > 0 ? (long long)(z / A.out_bdiv) * A.out_bs_hi + (long long)(z % A.out_bdiv) * A.out_bs
                          : (long long)z * A.out_bs;
     cx<float>* __restrict__ out = gout + out_off + ocol;
-    const float sg_ld = A.conj_ld ? -1.f : 1.f;
-    const float sg_st = A.conj_st ? -1.f : 1.f;
-    const float col_w = (A.col_win && live) ? A.col_win[col] : 1.f;
+    const RC sg_ld = A.conj_ld ? (RC)-1 : (RC)1;
+    const RC sg_st = A.conj_st ? (RC)-1 : (RC)1;
+    const RC col_w = (A.col_win && live) ? (RC)A.col_win[col] : (RC)1;
     bool rmw = A.accumulate != 0;
     if (!RAW_ST && A.accumulate && A.touched && live) rmw = A.touched[ocol] != 0;
     const int slot = lane & (P - 1);
@@ -251,7 +275,7 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
     // ---- input rows: lane `slot` describes row i = t + slot*T
     int in_row;         // element offset row*pitch is formed later; -1 = zero (padding)
     long long gs_off1 = -1, gs_off2 = -1;  // GS: element offsets of the (up to) two source rows, -1 = none
-    float in_w = 1.f;
+    RC in_w = (RC)1;
     {
         const int i = t + slot * T;
         if constexpr (RAW_LD) {
@@ -283,14 +307,14 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
                 in_row = ok ? idx : -1;
             }
             const int qs = ok ? q : 0;
-            if (ld_win) in_w *= ld_win[qs];
-            if (ld_win2) in_w *= ld_win2[qs];
+            if (ld_win) in_w *= (RC)ld_win[qs];
+            if (ld_win2) in_w *= (RC)ld_win2[qs];
         }
     }
     // ---- output rows: lane `slot` describes the output the scatter calls slot (u, r)
     int out_row;  // -1 = not stored
-    float out_w = A.scale;
-    cx<float> out_tw = {1.f, 0.f};
+    RC out_w = (RC)A.scale;
+    cx<RC> out_tw = {(RC)1, (RC)0};
     {
         const int u = slot >> LR, r = slot & ((1 << LR) - 1);
         const int j = t + u * T;
@@ -308,8 +332,8 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
             if (idx >= A.st_mod) idx -= A.st_mod;
             const bool ok = d < A.st_len;
             const int ds = ok ? d : 0;
-            if (st_win) out_w *= st_win[(long long)z * A.st_win_bs + ds];
-            if (st_win2) out_w *= st_win2[ds];
+            if (st_win) out_w *= (RC)st_win[(long long)z * A.st_win_bs + ds];
+            if (st_win2) out_w *= (RC)st_win2[ds];
             int row = idx;
             if (st_rowmap) row = st_rowmap[(long long)zb * A.st_rowmap_bs + (ok ? idx : 0)];
             out_row = ok ? row : -1;
@@ -318,7 +342,7 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
 
     // Issue ALL loads first (nothing in this loop consumes a loaded value, so the
     // P loads of a lane are in flight together), then apply windows / conjugation.
-    cx<float> x[P];
+    cx<RC> x[P];
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         const int row = slot_bcast<HALF>(in_row, v, hw);
@@ -334,6 +358,10 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
                 const long long o2 = ((long long)hi2 << 32) | (unsigned)lo2;
                 if (live) {
                     const cx<float> w2 = cp_load<NT_LD>(in + o2);
+                    if constexpr (sizeof(RC) == 8) {  // the sum of the two source rows in double
+                        x[v] = cx<RC>{(RC)val.x + (RC)w2.x, (RC)val.y + (RC)w2.y};
+                        return;
+                    }
                     val.x += w2.x;
                     val.y += w2.y;
                 }
@@ -343,12 +371,12 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
                 if (live) val = cp_load<NT_LD>(in + (unsigned)row * A.in_pitch);
             }
         }
-        x[v] = val;
+        x[v] = cx<RC>{(RC)val.x, (RC)val.y};
     });
     static_for<0, P>([&](auto vI) {
         constexpr int v = decltype(vI)::value;
         if constexpr (!RAW_LD) {
-            const float w = slot_bcast_f<HALF>(in_w, v, hw);
+            const RC w = slot_bcast_f<HALF>(in_w, v, hw);
             x[v].x *= w;
             x[v].y *= w * sg_ld;
         } else {
@@ -356,37 +384,37 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
         }
     });
 
-    fft_phases<G, float, 0>(x, t, clane, true, smem, tw, [&](int, cx<float> v, auto sI) {
+    fft_phases<G, RC, 0>(x, t, clane, true, smem, tw, [&](int, cx<RC> v, auto sI) {
         constexpr int s = decltype(sI)::value;
         const int row = slot_bcast<HALF>(out_row, s, hw);
         if (row < 0) return;  // uniform (per half-wave with 32-column tiles)
         if constexpr (RAW_ST) {
-            cx<float> w;
+            cx<RC> w;
             w.x = slot_bcast_f<HALF>(out_tw.x, s, hw);
             w.y = slot_bcast_f<HALF>(out_tw.y, s, hw);
             v = cmul(v, w);
             v.y *= sg_st;
-            if (live) cp_store<NT_ST>(out + (unsigned)row * A.out_pitch, v);
+            if (live) cp_store<NT_ST>(out + (unsigned)row * A.out_pitch, cx<float>{(float)v.x, (float)v.y});
         } else {
-            const float w = slot_bcast_f<HALF>(out_w, s, hw) * col_w;
+            const RC w = slot_bcast_f<HALF>(out_w, s, hw) * col_w;
             v.x *= w;
             v.y *= w * sg_st;
             cx<float>* p = out + (unsigned)row * A.out_pitch;
             if (A.accumulate) {
                 if (live && rmw) {
                     const cx<float> old = *p;
-                    v.x += old.x;
-                    v.y += old.y;
+                    v.x += (RC)old.x;
+                    v.y += (RC)old.y;
                 }
             }
-            if (live) cp_store<NT_ST>(p, v);
+            if (live) cp_store<NT_ST>(p, cx<float>{(float)v.x, (float)v.y});
         }
     });
 }
 
 // (wave = workgroup-uniform wave index, lane; bx / o / z = column tile, outer index, batch item: the grid of the plain
-// kernel, a schedule of its own in the fused four-step kernel of swiftly_fourstep.h)
-template <class G, int MODE, bool SNT, bool GS = false>
+// kernel; tools/experiments/swiftly_fourstep.h calls the body with a schedule of its own)
+template <class G, int MODE, bool SNT, bool GS = false, typename RC = float>
 __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassArgs A, const cx<float>* __restrict__ gin,
                                                          cx<float>* __restrict__ gout,
                                                          const float* __restrict__ ld_win,
@@ -394,10 +422,10 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
                                                          const float* __restrict__ st_win,
                                                          const float* __restrict__ st_win2,
                                                          const int* __restrict__ st_rowmap,
-                                                         const cx<float>* __restrict__ tw,
-                                                         const cx<float>* __restrict__ tw_full, const ColZ cz) {
+                                                         const cx<RC>* __restrict__ tw,
+                                                         const cx<RC>* __restrict__ tw_full, const ColZ cz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    col_pass_body<G, MODE, SNT, GS>(A, gin, gout, ld_win, ld_win2, st_win, st_win2, st_rowmap, tw, tw_full, cz,
+    col_pass_body<G, MODE, SNT, GS, ColZ, RC>(A, gin, gout, ld_win, ld_win2, st_win, st_win2, st_rowmap, tw, tw_full, cz,
                                     __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, blockIdx.x,
                                     blockIdx.y, blockIdx.z, smem);
 }
@@ -407,5 +435,6 @@ constexpr int kColPassMaxLog = 10;  // 1024 points: 32-column tiles
 
 int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s);
 int init_col_pass();
+bool col_pass_f64_supported(int logn);  // float64-arithmetic instances (ColPassArgs::f64)
 
 }  // namespace swf

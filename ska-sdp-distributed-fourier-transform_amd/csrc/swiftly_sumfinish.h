@@ -195,9 +195,6 @@ struct SumFinishFacetArgs {
     int nrounds;
     int rstart[kSumFinishMaxFacets + 1];
     int rgroup[kSumFinishMaxFacets];
-    // direct-row mode (the axis-0 half is finished already, swiftly_groupfinish.h): the `nfacets` inputs are off1
-    // GROUPS, every one of them covers every row, and row r of the output reads row r of each (nrows = xA)
-    int direct_rows;
 };
 
 template <int LOGM, int LOGX>
@@ -242,7 +239,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
                         int fs[NBW];
                         int cnt = 0;
                         for (; n < ne && cnt < NBW; n++) {
-                            const bool any = A.direct_rows != 0 || (live && ((row - A.base0[n]) & (X - 1)) < M);
+                            const bool any = live && ((row - A.base0[n]) & (X - 1)) < M;
                             if (any) fs[cnt++] = n;
                         }
                         if (cnt == 0) break;
@@ -252,7 +249,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
                             constexpr int sl = decltype(sI)::value;
                             if (sl < cnt) {  // wave-uniform
                                 const int nn = fs[sl];
-                                const int k = A.direct_rows ? row : ((row - A.base0[nn]) & (X - 1));
+                                const int k = (row - A.base0[nn]) & (X - 1);
                                 const cx<float>* __restrict__ in = A.in + (long long)A.fidx[nn] * A.in_fs +
                                                                    (long long)b * A.in_bs + (long long)(live ? k : 0) * A.in_rs;
                                 static_for<0, PM>([&](auto vI) {
@@ -312,7 +309,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
             int cnt = 0;
             for (; n < ne && cnt < NB; n++) {  // workgroup-uniform scan
                 const int base = A.base0[n];
-                bool any = A.direct_rows != 0;
+                bool any = false;
                 for (int q = 0; q < S::RB; q++) any = any || (((row0 + q - base) & (X - 1)) < M && row0 + q < A.nrows);
                 if (any) fs[cnt++] = n;
             }
@@ -324,8 +321,8 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
                 constexpr int sl = decltype(sI)::value;
                 if (sl < cnt) {  // uniform
                     const int nn = fs[sl];
-                    const int k = A.direct_rows ? row : ((row - A.base0[nn]) & (X - 1));
-                    const bool on = live && (A.direct_rows || k < M);
+                    const int k = (row - A.base0[nn]) & (X - 1);
+                    const bool on = live && k < M;
                     const cx<float>* __restrict__ in =
                         A.in + (long long)A.fidx[nn] * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
                     wgt[sl] = on ? 1.f : 0.f;

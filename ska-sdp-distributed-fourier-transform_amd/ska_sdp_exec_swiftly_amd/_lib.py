@@ -35,8 +35,10 @@ def _declare(lib):
     lib.swiftly_hip_destroy.argtypes = [vp]
     lib.swiftly_hip_contribution_size.restype = i64
     lib.swiftly_hip_contribution_size.argtypes = [vp]
-    lib.swiftly_hip_async_error.restype = ctypes.c_int
-    lib.swiftly_hip_async_error.argtypes = [vp]
+    lib.swiftly_hip_set_column_precision.restype = ctypes.c_int
+    lib.swiftly_hip_set_column_precision.argtypes = [vp, ctypes.c_int]
+    lib.swiftly_hip_get_column_precision.restype = ctypes.c_int
+    lib.swiftly_hip_get_column_precision.argtypes = [vp]
     # (h, dtype, in, rows, [size,] in_rs, in_cs, out, out_rs, out_cs, off, [size, mask,] stream)
     sized_in = [vp, c_int, vp, i64, i64, i64, i64, vp, i64, i64, i64, vp]
     plain = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, vp]
@@ -77,12 +79,6 @@ def _declare(lib):
     lib.swiftly_hip_add_to_subgrid_from_columns.argtypes = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, pi64, vp]
     lib.swiftly_hip_band_columns.restype = i64
     lib.swiftly_hip_band_columns.argtypes = [i64]
-    lib.swiftly_hip_grouped_subgrid_side_supported.restype = c_int
-    lib.swiftly_hip_grouped_subgrid_side_supported.argtypes = [vp]
-    lib.swiftly_hip_wave_subgrid_side_grouped.restype = c_int
-    lib.swiftly_hip_wave_subgrid_side_grouped.argtypes = [
-        vp, c_int, vp, i64, i64, vp, i64, pi64, pi64, i64, pi64, pi64, i64, vp, i64, vp, i64, vp, i64, vp, vp,
-    ]
     lib.swiftly_hip_band_columns_for.restype = i64
     lib.swiftly_hip_band_columns_for.argtypes = [vp, i64]
     lib.swiftly_hip_prepare_facet_band.restype = c_int

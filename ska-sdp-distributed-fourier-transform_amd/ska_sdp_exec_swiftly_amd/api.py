@@ -136,7 +136,8 @@ class SwiftlyConfig:
 
     # pylint: disable=too-many-arguments,too-many-instance-attributes
     def __init__(
-        self, W, fov, N, yB_size, yN_size, xA_size, xM_size, dask_client=None, backend="hip", **_other_args
+        self, W, fov, N, yB_size, yN_size, xA_size, xM_size, dask_client=None, backend="hip", column_precision=None,
+        **_other_args
     ):
         self._W = W
         self._fov = fov
@@ -147,7 +148,7 @@ class SwiftlyConfig:
         self._xM_size = xM_size
         self.dask_client = dask_client  # unused: there is no Dask in this backend
         if backend == "hip":
-            self._core = SwiftlyCoreHip(W, N, xM_size, yN_size)
+            self._core = SwiftlyCoreHip(W, N, xM_size, yN_size, column_precision=column_precision)
         elif backend in ("numpy", "ska_sdp_func"):
             # reference api.py:137-141 -- those cores live in the reference package; this one is GPU only
             raise ValueError(
@@ -838,12 +839,9 @@ class SwiftlyForward:
         """K1: band buffers ``[F, yB, band columns]`` -- prepare_facet along axis 1 of every facet row, only the
         columns some planned subgrid window reads, axis-0 window pre-applied.
 
-        Optional "facet-major schedule" (``SWIFTLY_PRECOMPUTE=1``, needs a plan): K2 of ALL planned waves is issued
-        facet by facet on a second HIP stream right behind each facet's K1, so that the bandwidth-bound K2 of facet j
-        can run in the memory bandwidth the issue-bound K1 of facet j+1 leaves unused; the per-wave results stay in
-        HBM (``[F, W, rows, m]``: 10.7 GB for the 64k-sparse workload; skipped above ``SWIFTLY_PRECOMPUTE_GB``,
-        default 48).  Measured on MI355X: 45.8-46.9 ms per pass against 46.1 ms for the plain wave loop -- the two
-        kernels do not overlap enough to pay for the extra memory, so it is off by default."""
+        (r2's "facet-major schedule" -- K2 of all planned waves per facet on a second stream behind its K1 -- was measured
+        no faster than the plain wave loop, K1 and K2 contend for the same HBM / fabric; removed in r4, numbers in
+        DESIGN.md section 4.)"""
         if self.BF_Fs_persist is None:
             self._check_band_pipeline()
             torch = _torch()
@@ -852,45 +850,14 @@ class SwiftlyForward:
                 core.band_for_offsets([sg.off1 for sg in self._plan]) if self._plan is not None else (0, core.yN_size)
             )
             F, yB = len(self._facet_info), self._facet_info[0][1][0]
-            m = core.xM_yN_size
             bands = torch.empty((F, yB, core.band_columns(self._band)), dtype=self.dtype, device=core.device)
-            pre = None
-            if self._plan is not None and timer is None and os.environ.get("SWIFTLY_PRECOMPUTE") == "1":
-                keys = list(dict.fromkeys(int(sg.off1) for sg in self._plan))
-                maps = [self._wave_rows(k) for k in keys]
-                max_rows = max(n for _, n in maps)
-                budget = float(os.environ.get("SWIFTLY_PRECOMPUTE_GB", "48")) * 2**30
-                if F * len(keys) * max_rows * m * 8 <= budget:
-                    rowmaps = core.stacked_rowmaps(tuple(keys), [rm for rm, _ in maps])
-                    Qall = torch.empty((F, len(keys), max_rows, m), dtype=self.dtype, device=core.device)
-                    # four-step scratch of one facet's waves (launch groups of <= 4 GB), owned here: see the ABI note
-                    n_group = max(1, min(len(keys), (4 << 30) // (core.yN_size * m * 8)))
-                    work = torch.empty((n_group, core.yN_size, m), dtype=self.dtype, device=core.device)
-                    side = core.side_stream()
-                    Qall.record_stream(side)
-                    work.record_stream(side)
-                    pre = (keys, rowmaps, Qall, side, work)
-            main = torch.cuda.current_stream(core.device)
             for j, cfg in enumerate(self.facet_configs):
                 data = self._ingest.ready(j)
                 t0 = timer.start() if timer is not None else None
                 core.prepare_facet_band(data, cfg.off1, self._band, out=bands[j])
                 if timer is not None:
                     timer.stop("K1_full_facet_transform", t0)
-                if pre is not None:
-                    keys, rowmaps, Qall, side, work = pre
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ev)
-                        core.prepare_facet_columns_waves(
-                            bands[j : j + 1], [cfg.off0], self._band, keys, Qall[j : j + 1], rowmaps, workspace=work
-                        )
                 self._ingest.prefetch(j + 1)
-            if pre is not None:
-                keys, rowmaps, Qall, side, _ = pre
-                main.wait_stream(side)
-                self._Qall = (Qall, {k: (i, maps[i][0], maps[i][1]) for i, k in enumerate(keys)})
             self.BF_Fs_persist = bands
         return self.BF_Fs_persist
 
@@ -906,10 +873,6 @@ class SwiftlyForward:
 
     def _get_wave_columns(self, off1):
         """K2: ``Q[F, rows, m]`` for the subgrid wave ``off1`` (LRU cached like the reference's per-off0 columns)."""
-        pre = getattr(self, "_Qall", None)
-        if pre is not None and int(off1) in pre[1]:
-            i, rowmap, _ = pre[1][int(off1)]
-            return pre[0][:, i], rowmap
         hit = self.lru.get(("b", off1))
         if hit is None:
             if self._plan is not None and int(off1) not in self._planned_keys:
@@ -938,10 +901,6 @@ class SwiftlyForward:
     def _wave_Q(self, off1):
         """(Q workspace, rowmap, n_rows, needs computing) of wave ``off1`` (LRU cached like _get_wave_columns)"""
         torch = _torch()
-        pre = getattr(self, "_Qall", None)
-        if pre is not None and int(off1) in pre[1]:
-            i, rowmap, n_rows = pre[1][int(off1)]
-            return pre[0][:, i], rowmap, n_rows, False  # precomputed by the facet-major schedule
         hit = self.lru.get(("b", off1))
         if hit is not None:
             return hit[0], hit[1], hit[0].shape[1], False
@@ -954,31 +913,15 @@ class SwiftlyForward:
         return Q, rowmap, n_rows, True
 
     def _wave_b(self, sgs):
-        """One wave = two native calls: facet side (K2 + K3 + K4a) and subgrid side (K4b + K5).  ``SWIFTLY_GROUPED=1``
-        (where the facets form off1 groups) selects K2 + the grouped subgrid side that finishes axis 0 first instead:
-        79 -> 49 MB of HBM traffic per subgrid at the same speed (measured r3: 42.5 vs 42.4 ms per 64k pass; the fused
-        column kernel is register-bound), so it is not the default."""
+        """One wave = two native calls: facet side (K2 + K3 + K4a) and subgrid side (K4b + K5).  (r3's grouped subgrid
+        side -- axis 0 finished first per off1 group, 79 -> 49 MB per subgrid at the same speed -- lives in
+        tools/experiments/ since r4.)"""
         torch = _torch()
         core = self.core
         self._check_planned(sgs)
         bands = self.prepare_all_facets()
         Q, rowmap, n_rows, compute = self._wave_Q(sgs[0].off1)
         m = core.xM_yN_size
-        off1s = [cfg.off1 for cfg in self.facet_configs]
-        if os.environ.get("SWIFTLY_GROUPED", "0") == "1" and core.supports_grouped_subgrid_side(self.dtype, off1s, sgs[0].size):
-            off0s = [cfg.off0 for cfg in self.facet_configs]
-            xA, S = sgs[0].size, len(sgs)
-            try:
-                if compute:
-                    core.prepare_facet_columns(bands, off0s, self._band, sgs[0].off1, rowmap, n_rows, out=Q)
-            except Exception:
-                self.lru._items.pop(("b", sgs[0].off1), None)  # pylint: disable=protected-access
-                raise
-            mask1 = _mask_table(core, sgs, "mask1", xA, self.dtype)
-            mask0 = _mask_table(core, sgs, "mask0", xA, self.dtype)
-            res = torch.empty((S, xA, xA), dtype=self.dtype, device=core.device)
-            return core.wave_subgrid_side_grouped(Q, rowmap, off0s, off1s, [sg.off0 for sg in sgs], [sg.off1 for sg in sgs],
-                                                  xA, mask0, mask1, res)
         G = torch.empty((len(self.facet_configs), len(sgs), m, m), dtype=self.dtype, device=core.device)
         try:
             core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,

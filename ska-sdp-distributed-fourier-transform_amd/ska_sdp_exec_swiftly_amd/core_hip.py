@@ -132,7 +132,7 @@ class SwiftlyCoreHip:
 
     # pylint: disable=too-many-public-methods,too-many-arguments
 
-    def __init__(self, W, N, xM_size, yN_size, device=None):
+    def __init__(self, W, N, xM_size, yN_size, device=None, column_precision=None):
         self.W = W
         self.N = N
         self.xM_size = xM_size
@@ -162,6 +162,19 @@ class SwiftlyCoreHip:
             )
         )
         self._handle = handle
+        if column_precision is not None:
+            self.column_precision = column_precision
+
+    @property
+    def column_precision(self):
+        """Arithmetic of the column passes of the band pipelines on complex64 data (include/swiftly_hip.h,
+        swiftly_hip_set_column_precision): 32 (default, or 64 when SWIFTLY_COL_F64=1) | 64 = float64 butterflies
+        between complex64 loads and stores: 3.7x smaller end-to-end error, 1.5x the pass time."""
+        return int(self._lib.swiftly_hip_get_column_precision(self._handle))
+
+    @column_precision.setter
+    def column_precision(self, bits):
+        _lib.check(self._lib.swiftly_hip_set_column_precision(self._handle, int(bits)))
 
     def __del__(self):
         handle = getattr(self, "_handle", None)
@@ -176,7 +189,8 @@ class SwiftlyCoreHip:
     # parameters travel, the native handle is rebuilt on the receiving side.
     def __getstate__(self):
         # no device pointers, no caches
-        return {"W": self.W, "N": self.N, "xM_size": self.xM_size, "yN_size": self.yN_size}
+        return {"W": self.W, "N": self.N, "xM_size": self.xM_size, "yN_size": self.yN_size,
+                "column_precision": self.column_precision}
 
     def __setstate__(self, state):
         self.__init__(**state)
@@ -632,11 +646,6 @@ class SwiftlyCoreHip:
     def _i64(values):
         return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
 
-    def async_error(self):
-        """Sticky device-side error of this core (``swiftly_hip_async_error``): non-zero once a bounded in-launch wait
-        of the opt-in fused four-step transform has timed out.  Synchronise first to check a specific call."""
-        return int(self._lib.swiftly_hip_async_error(self._handle))
-
     def _k2_scratch_bytes(self, F):
         """four-step scratch of K2 for F facets; yN = Q * 2^k also holds the output of the radix-Q pass"""
         n = F * self.yN_size * self.xM_yN_size * 8
@@ -734,40 +743,6 @@ class SwiftlyCoreHip:
                 cvp(mask0.data_ptr()) if mask0 is not None else None, mask0.stride(0) if mask0 is not None else 0,
                 cvp(mask1.data_ptr()) if mask1 is not None else None, mask1.stride(0) if mask1 is not None else 0,
                 cvp(tmp.data_ptr()), cvp(out.data_ptr()), cvp(scr.data_ptr()), scr.numel(), self._stream(),
-            )
-        )
-        return out
-
-    def supports_grouped_subgrid_side(self, dtype, facet_off1s, subgrid_size):
-        """True when the forward subgrid side can finish axis 0 first, per facet ``off1`` group
-        (``swiftly_hip_wave_subgrid_side_grouped``): kernels instantiated for these sizes, complex64, <= 64 facets, and
-        the per-group intermediate ``[groups, S, xA, m]`` smaller than the per-facet one ``[F, S, m, m]`` it replaces (a
-        facet list with few facets per off1 -- a sparse plus-shaped cover, a two-facet subset -- stays on the per-facet
-        route)."""
-        torch = _torch()
-        if dtype != torch.complex64 or not self._lib.swiftly_hip_grouped_subgrid_side_supported(self._handle):
-            return False
-        F = len(facet_off1s)
-        groups = len({int(o) for o in facet_off1s})
-        return 0 < F <= self.MAX_FUSED_FACETS and 4 * groups * int(subgrid_size) <= 3 * F * self.xM_yN_size
-
-    def wave_subgrid_side_grouped(self, Q, rowmap, facet_off0s, facet_off1s, sub_off0s, sub_off1s, subgrid_size, mask0,
-                                  mask1, out):
-        """K3..K5 of one wave with the axis-0 half finished first (``swiftly_hip_wave_subgrid_side_grouped``):
-        ``Q[F, rows, m]`` (prepare_facet_columns) -> ``out[S, xA, xA]``."""
-        F, S = Q.shape[0], len(sub_off0s)
-        cvp = ctypes.c_void_p
-        groups = len({int(o) for o in facet_off1s})
-        nwork = groups * S * int(subgrid_size) * self.xM_yN_size
-        work = self.scratch("grouped", nwork * 8)
-        _lib.check(
-            self._lib.swiftly_hip_wave_subgrid_side_grouped(
-                self._handle, self._code(Q), cvp(Q.data_ptr()), Q.stride(1), Q.stride(0),
-                cvp(rowmap.data_ptr()) if rowmap is not None else None, F, self._i64(facet_off0s), self._i64(facet_off1s), S,
-                self._i64(sub_off0s), self._i64(sub_off1s), int(subgrid_size),
-                cvp(mask0.data_ptr()) if mask0 is not None else None, mask0.stride(0) if mask0 is not None else 0,
-                cvp(mask1.data_ptr()) if mask1 is not None else None, mask1.stride(0) if mask1 is not None else 0,
-                cvp(work.data_ptr()), nwork, cvp(out.data_ptr()), self._stream(),
             )
         )
         return out

@@ -111,33 +111,6 @@ def test_prepare_facet_columns(band, use_rowmap):
             assert rel < 2e-6, (off1, f, rel)
 
 
-@pytest.mark.parametrize("lag", [1, 4])
-def test_prepare_facet_columns_fused_four_step_is_bit_identical(lag, monkeypatch):
-    """Opt-in single-launch four-step (csrc/swiftly_fourstep.h: pass-A workgroups hand the intermediate to pass-B
-    workgroups of the same grid through agent-scope release / acquire): same arithmetic as the two launches, so the
-    result must be identical to the last bit, on every column tile of every facet, and no wait may time out."""
-    import torch
-
-    core, _ = core64()
-    band = (10736, 11472)
-    rng = numpy.random.default_rng(23)
-    yB0, F = 22528, 3  # full-size columns: 3 facets x 8 column tiles = 24 hand-over chunks of 16.8 MB
-    ncols = core.band_columns(band)
-    bands = torch.from_numpy(rng.standard_normal((F, yB0, ncols, 2)).astype(numpy.float32)).cuda()
-    bands = torch.view_as_complex(bands)
-    off0s = [0, 22528, -22528]
-    rowmap, n_rows = core.subgrid_column_rows([0, 3 * 928, -5 * 928, 20 * 928])
-    monkeypatch.delenv("SWIFTLY_FOURSTEP_FUSED", raising=False)
-    want = core.prepare_facet_columns(bands, off0s, band, 7 * 928, rowmap, n_rows).clone()
-    monkeypatch.setenv("SWIFTLY_FOURSTEP_FUSED", "1")
-    monkeypatch.setenv("SWIFTLY_FOURSTEP_LAG", str(lag))
-    for _ in range(3):  # repeated: a stale line or a missed arrival would not show every time
-        got = core.prepare_facet_columns(bands, off0s, band, 7 * 928, rowmap, n_rows)
-        torch.cuda.synchronize()
-        assert core.async_error() == 0
-        assert torch.equal(torch.view_as_real(got), torch.view_as_real(want))
-
-
 P11 = dict(W=11.0, N=1024, yB=352, yN=512, xA=192, xM=256)  # m = 128: sum_finish instance (7, 8)
 
 
@@ -224,17 +197,14 @@ def test_sum_finish_facets():
         assert rel < 3e-6, (b, rel)
 
 
-@pytest.mark.parametrize("axis", [0, 1, "1-facet-major"])
-def test_forward_pipelines_match_oracle_small_rows(axis, monkeypatch):
+@pytest.mark.parametrize("axis", [0, 1])
+def test_forward_pipelines_match_oracle_small_rows(axis):
     """Both forward pipelines through SwiftlyForward at yN = 32768 with SMALL facets (yB = 352 so that the
     2-D oracle is cheap): 4 facets, planned sparse subgrid set, complex64."""
     import torch
 
     import ska_sdp_exec_swiftly_amd as sw
 
-    if axis == "1-facet-major":  # optional schedule: K2 of all planned waves per facet on a second stream
-        monkeypatch.setenv("SWIFTLY_PRECOMPUTE", "1")
-        axis = 1
     yB, xA = 352, 928
     P = dict(W=W64, fov=1.0, N=N64, yB_size=yB, yN_size=yN64, xA_size=xA, xM_size=xM64)
     cfg = sw.SwiftlyConfig(backend="hip", **P)
@@ -361,84 +331,3 @@ def test_backward_default_axis_with_plan_stages_single_adds(lru_backward):
     b128 = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
     b128.add_new_subgrid_task(sg_cfgs[0], data[0].to(torch.complex128))
     assert b128.wave_axis == 0
-
-
-@pytest.mark.parametrize("params", [P11, dict(W=11.0, N=2048, yB=704, yN=1024, xA=448, xM=512)], ids=["m128_xM256", "m256_xM512"])
-def test_wave_subgrid_side_grouped(params):
-    """The forward subgrid side with the axis-0 half finished first (swiftly_hip_wave_subgrid_side_grouped: gather from
-    Q + add_to_subgrid axis 0 + sum over the facets of an off1 group + finish_subgrid axis 0 in one kernel, then
-    sum_finish_facets in direct-row mode) against the oracle's add_to_subgrid / finish_subgrid, facets on a 3 x 2 grid
-    plus one extra, with and without a row map, masks on both axes."""
-    import torch
-
-    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
-
-    core = SwiftlyCoreHip(params["W"], params["N"], params["xM"], params["yN"])
-    ref = orc.OracleCore(params["W"], params["N"], params["xM"], params["yN"])
-    m, xM, xA, yN, N = core.xM_yN_size, params["xM"], params["xA"], params["yN"], params["N"]
-    rng = numpy.random.default_rng(26)
-    fstep, sstep = core.facet_off_step, core.subgrid_off_step
-    step = (params["yB"] // fstep) * fstep
-    f_offs = [(a * step, b * step) for a in (0, 1, -1) for b in (0, 1)] + [(2 * step, step)]
-    s_offs = [(0, 0), (xA // sstep * sstep, -3 * sstep), (-5 * sstep, 7 * sstep), (N // 2 + 4 * sstep, 2 * sstep)]
-    F, S = len(f_offs), len(s_offs)
-    assert core.supports_grouped_subgrid_side(torch.complex64, [o[1] for o in f_offs], xA)
-    full = (rng.standard_normal((F, yN, m)) + 1j * rng.standard_normal((F, yN, m))).astype(numpy.complex64)
-    mask0 = (rng.random((S, xA)) > 0.2).astype(numpy.float32)
-    mask1 = (rng.random((S, xA)) > 0.2).astype(numpy.float32)
-    want = []
-    for b, (o0, o1) in enumerate(s_offs):
-        acc = numpy.zeros((xM, xM), dtype=complex)
-        for f, (fo0, fo1) in enumerate(f_offs):
-            C = ref.extract_from_facet(full[f].astype(complex), o0, axis=0)  # [m, m]: the columns are the off1 window already
-            acc += ref.add_to_subgrid(ref.add_to_subgrid(C, fo0, 0), fo1, 1)
-        want.append(ref.finish_subgrid(acc, [o0, o1], xA) * mask0[b][:, None] * mask1[b][None, :])
-    rowmap, n_rows = core.subgrid_column_rows([o[0] for o in s_offs])
-    rm = rowmap.cpu().numpy()
-    compact = numpy.zeros((F, n_rows, m), dtype=numpy.complex64)
-    compact[:, rm[rm >= 0]] = full[:, rm >= 0]
-    for Q, rmap in ((torch.from_numpy(full).cuda(), None), (torch.from_numpy(compact).cuda(), rowmap)):
-        out = torch.empty((S, xA, xA), dtype=torch.complex64, device="cuda")
-        core.wave_subgrid_side_grouped(Q, rmap, [o[0] for o in f_offs], [o[1] for o in f_offs], [o[0] for o in s_offs],
-                                       [o[1] for o in s_offs], xA, torch.from_numpy(mask0).cuda(), torch.from_numpy(mask1).cuda(), out)
-        got = out.cpu().numpy()
-        for b in range(S):
-            rel = relrms(got[b], want[b])
-            assert rel < 3e-6, (rmap is not None, b, rel)
-            assert not got[b][mask0[b] == 0].any() and not got[b][:, mask1[b] == 0].any()
-
-
-def test_forward_grouped_subgrid_side_matches_oracle(monkeypatch):
-    """SwiftlyForward with the opt-in grouped subgrid side (SWIFTLY_GROUPED=1) on a 3 x 3 facet grid at the kernel sizes of
-    the 64k configuration (small facets so that the separable oracle is cheap): same subgrids as the oracle and, to
-    float32 rounding, as the default per-facet route."""
-    import torch
-
-    import ska_sdp_exec_swiftly_amd as sw
-
-    yB, xA = 352, 928
-    P = dict(W=W64, fov=1.0, N=N64, yB_size=yB, yN_size=yN64, xA_size=xA, xM_size=xM64)
-    cfg = sw.SwiftlyConfig(backend="hip", **P)
-    fstep = cfg.facet_off_step
-    rng = numpy.random.default_rng(27)
-    offs = [0, 50 * fstep, -70 * fstep]
-    facet_cfgs = [sw.FacetConfig(o0, o1, yB, (rng.random(yB) > 0.1).astype(float), None) for o0 in offs for o1 in offs]
-    vectors = [sep.facet_vectors(600 + j, yB, rank=2) for j in range(len(facet_cfgs))]
-    facets = [bench.separable_facet(torch, vectors[j], c) for j, c in enumerate(facet_cfgs)]
-    sg_cfgs = [
-        sw.SubgridConfig(i0 * xA, i1 * xA, xA, (rng.random(xA) > 0.1).astype(float), (rng.random(xA) > 0.1).astype(float))
-        for i0, i1 in ((0, 0), (2, 0), (69, 0), (0, 3), (2, 3), (69, 70))
-    ]
-    assert cfg.core.supports_grouped_subgrid_side(torch.complex64, [c.off1 for c in facet_cfgs], xA)
-    got = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("SWIFTLY_GROUPED", flag)
-        fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs)
-        assert fwd.wave_axis == 1
-        got[flag] = [t.cpu().numpy() for t in fwd.get_subgrid_tasks(sorted(sg_cfgs, key=lambda c: c.off1))]
-    ref = core64()[1]
-    so = sep.SeparableOracle(ref, [orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in facet_cfgs], vectors)
-    for k, c in enumerate(sorted(sg_cfgs, key=lambda c: c.off1)):
-        w = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size, c.mask0, c.mask1))
-        assert relrms(got["1"][k], w) < 2e-5 and relrms(got["0"][k], w) < 2e-5
-        assert relrms(got["1"][k], got["0"][k]) < 3e-6
