@@ -315,8 +315,11 @@ class DeviceTask:
         self.tensor = tensor
         self._event = None
         if getattr(tensor, "is_cuda", False):
-            self._event = _torch().cuda.Event()
-            self._event.record()
+            # on the current stream of the TENSOR's device (where the producing kernels were enqueued), which need not
+            # be the process's current device
+            torch = _torch()
+            self._event = torch.cuda.Event()
+            self._event.record(torch.cuda.current_stream(tensor.device))
 
     def done(self):
         """True once the producing kernels have completed"""
@@ -622,6 +625,11 @@ class SwiftlyForward:
     # -- stage 2: per subgrid column (api.py:300-324)
     def get_NMBF_BFs_off0(self, off0, BF_Fs=None):
         """prepared facet columns for subgrid column ``off0`` (LRU cached)"""
+        if self.wave_axis != 0:
+            raise ValueError(
+                "get_NMBF_BFs_off0 belongs to the reference schedule (wave_axis=0); this SwiftlyForward runs the "
+                "contiguous-axis-first pipeline (wave_axis=1, the default with a subgrid plan): construct it with wave_axis=0"
+            )
         if BF_Fs is None:
             BF_Fs = self._get_BF_Fs()
         elif BF_Fs is not self.BF_Fs_persist:
@@ -680,44 +688,63 @@ class SwiftlyForward:
 
     @staticmethod
     def _rid(sg):
-        return (int(sg.off0), int(sg.off1), int(sg.size), id(sg))
+        """identity of a request: its VALUE (equal configs of a rebuilt cover match the plan, r3 advice)"""
+        return (int(sg.off0), int(sg.off1), int(sg.size))
 
     def _planned_wave_of(self, sg):
-        """the planned subgrids that share ``sg``'s wave key and size, in plan order (None without a plan or when
-        ``sg`` is not one of the plan's config objects)"""
+        """the planned subgrids that share ``sg``'s wave key and size, in plan order, duplicates dropped (None without
+        a plan or when ``sg`` is not in the plan)"""
         if self._plan is None:
             return None
         if self._plan_waves is None:
-            waves = {}
+            waves, seen = {}, set()
             for c in self._plan:
+                r = self._rid(c)
+                if r in seen:
+                    continue
+                seen.add(r)
                 waves.setdefault((int(self._key(c)), int(c.size)), []).append(c)
-            self._plan_waves = (waves, {id(c) for c in self._plan})
-        waves, ids = self._plan_waves
-        if id(sg) not in ids:
+            self._plan_waves = (waves, seen)
+        waves, seen = self._plan_waves
+        if self._rid(sg) not in seen:
             return None
         return waves.get((int(self._key(sg)), int(sg.size)))
+
+    def _drop_result(self, rid):
+        hit = self._results.pop(rid, None)
+        if hit is not None:
+            self._result_bytes -= hit.numel() * hit.element_size()
+        return hit
 
     def _serve_group(self, group):
         """results for consecutive requests sharing the wave key: cache hits, a whole planned wave computed ahead,
         or just the group"""
-        hits = [self._results.get(self._rid(sg)) for sg in group]
-        if all(h is not None for h in hits):
-            for sg, h in zip(group, hits):
-                del self._results[self._rid(sg)]
-                self._result_bytes -= h.numel() * h.element_size()
-            return hits
+        rids = [self._rid(sg) for sg in group]
+        distinct = len(set(rids)) == len(rids)
+        if distinct and all(r in self._results for r in rids):
+            return [self._drop_result(r) for r in rids]  # each cached subgrid is handed out once
+        # partial hits: the whole group is recomputed below, so the cached copies of its members are released
+        # (r3 advice: they used to stay behind and shrink the budget for good)
+        for r in set(rids):
+            self._drop_result(r)
         full = self._planned_wave_of(group[0])
-        asked = {id(sg) for sg in group}
-        if full is not None and len(asked) == len(group) and all(id(sg) in {id(c) for c in full} for sg in group):
-            extra = [c for c in full if id(c) not in asked and self._rid(c) not in self._results]
-            nbytes = sum(c.size * c.size for c in extra) * 8
-            if extra and self._result_bytes + nbytes <= self._result_budget:
-                res = self.get_wave(full)
-                by_id = {id(c): res[k] for k, c in enumerate(full)}
-                for c in extra:
-                    self._results[self._rid(c)] = by_id[id(c)]
-                self._result_bytes += nbytes
-                return [by_id[id(sg)] for sg in group]
+        if full is not None and distinct:
+            in_full = {self._rid(c) for c in full}
+            if all(r in in_full for r in rids):
+                asked = set(rids)
+                extra = [c for c in full if self._rid(c) not in asked and self._rid(c) not in self._results]
+                esize = _torch().empty((), dtype=self.dtype).element_size()
+                nbytes = sum(c.size * c.size for c in extra) * esize
+                if extra and self._result_bytes + nbytes <= self._result_budget:
+                    # (the requested config objects take the place of their plan twins: their masks are the ones asked for)
+                    req = dict(zip(rids, group))
+                    full = [req.get(self._rid(c), c) for c in full]
+                    res = self.get_wave(full)
+                    by_rid = {self._rid(c): res[k] for k, c in enumerate(full)}
+                    for c in extra:
+                        self._results[self._rid(c)] = by_rid[self._rid(c)]
+                    self._result_bytes += nbytes
+                    return [by_rid[r] for r in rids]
         res = self.get_wave(group)
         return [res[k] for k in range(len(group))]
 
@@ -745,6 +772,11 @@ class SwiftlyForward:
         ``off0``): tensor ``[F, S, m, m]`` -- the data the reference ships
         between Dask workers (api.py:263-277) and the multi-GPU path ships
         through the all-to-all."""
+        if self.wave_axis != 0:
+            raise ValueError(
+                "wave_contributions belongs to the reference schedule (wave_axis=0); with wave_axis=1 use "
+                "distributed.DistributedForward.pack_wave / core.wave_facet_side"
+            )
         torch = _torch()
         core = self.core
         m, yN = core.xM_yN_size, core.yN_size
@@ -1103,6 +1135,10 @@ class SwiftlyBackward:
         return self.add_new_subgrid_tasks([subgrid_config], [new_subgrid_task])
 
     def _resolve_axis(self, first_subgrid):
+        """Fix the automatic schedule on the FIRST data this object sees, whichever public entry point it arrives
+        through (add_new_subgrid_task(s), wave_contributions, accumulate_wave / accumulate_chunks); it never changes
+        afterwards (r3 advice: the low-level entry points used to leave it open, and a later add flipped the schedule
+        under accumulators of the other kind)."""
         if not self._auto_axis:
             return
         self._auto_axis = False
@@ -1215,6 +1251,8 @@ class SwiftlyBackward:
         to every facet -- what the reference ships from the subgrid's worker to
         the facets' workers (api.py:357-364).  On the fused route the result lives in one of two alternating
         workspaces of this object: it stays valid until the second-next call."""
+        if self._auto_axis and len(subgrids):
+            self._resolve_axis(_unwrap(subgrids[0]))
         torch = _torch()
         core = self.core
         m, xM = core.xM_yN_size, core.xM_size
@@ -1278,6 +1316,7 @@ class SwiftlyBackward:
         add the contributions ``parts[F, S, m, m]`` of subgrids sharing ``off0``
         into that column's partial sums (LRU cache keyed by ``off0``, reference
         api.py:402-438); evicted columns go to the facet accumulators."""
+        self._resolve_axis(parts)
         torch = _torch()
         core = self.core
         m, yN = core.xM_yN_size, core.yN_size
@@ -1301,6 +1340,8 @@ class SwiftlyBackward:
     def accumulate_chunks(self, off0, chunks):
         """:py:meth:`accumulate_wave` for contributions that arrive in several pieces (one per source rank of
         the multi-GPU exchange): ``chunks = [(subgrid configs, parts[F, S_c, m, m]), ...]``, all of column ``off0``."""
+        if self._auto_axis and len(chunks):
+            self._resolve_axis(chunks[0][1])
         torch = _torch()
         core = self.core
         m, yN = core.xM_yN_size, core.yN_size

@@ -331,3 +331,62 @@ def test_backward_default_axis_with_plan_stages_single_adds(lru_backward):
     b128 = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
     b128.add_new_subgrid_task(sg_cfgs[0], data[0].to(torch.complex128))
     assert b128.wave_axis == 0
+
+
+def test_forward_plan_is_matched_by_value_and_partial_hits_release_their_bytes():
+    """r3 advice: (i) requests with EQUAL but distinct config objects (a rebuilt cover) hit the planned-wave path;
+    (ii) a group that is only partly cached is recomputed and the cached copies of its members are released, so the
+    byte budget does not shrink; (iii) the wave_axis=0-only entry points say so when the object runs wave_axis=1."""
+    torch, sw, cfg, facet_cfgs, facets, sg_cfgs = _small_rows_problem()
+    if not cfg.core.supports_band_pipeline(torch.complex64):
+        pytest.skip("band pipeline not available")
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs)
+    clones = [sw.SubgridConfig(c.off0, c.off1, c.size, c.mask0, c.mask1) for c in sg_cfgs]
+    assert all(a is not b for a, b in zip(clones, sg_cfgs))
+    calls = []
+    inner = fwd.get_wave
+    fwd.get_wave = lambda sgs, timer=None: (calls.append(len(sgs)), inner(sgs, timer))[1]
+    first = fwd.get_subgrid_task(clones[0])
+    assert calls == [3] and len(fwd._results) == 2  # the whole planned wave, two subgrids kept for later
+    held = fwd._result_bytes
+    assert held == 2 * clones[0].size ** 2 * 8
+    # a group of the same wave with one cached and one already handed-out member: recomputed, nothing left behind
+    wave = [c for c in clones if c.off1 == clones[0].off1]
+    got = fwd.get_subgrid_tasks([wave[0], wave[1]])
+    assert len(calls) == 2
+    assert fwd._result_bytes == sum(t.numel() * t.element_size() for t in fwd._results.values())
+    assert fwd._result_bytes <= held
+    assert relrms(got[0].cpu().numpy(), first.cpu().numpy()) < 1e-6
+    with pytest.raises(ValueError, match="wave_axis=0"):
+        fwd.wave_contributions([sg_cfgs[0]])
+    with pytest.raises(ValueError, match="wave_axis=0"):
+        fwd.get_NMBF_BFs_off0(sg_cfgs[0].off0)
+
+
+def test_backward_axis_is_fixed_by_the_first_entry_point():
+    """r3 advice: SwiftlyBackward(subgrid_configs=plan) resolves its automatic schedule at whichever public entry
+    point sees data first, and a later add cannot flip it."""
+    torch, sw, cfg, facet_cfgs, _, sg_cfgs = _small_rows_problem()
+    if not cfg.core.supports_backward_band(torch.complex64):
+        pytest.skip("band schedule not available")
+    xA = sg_cfgs[0].size
+    data = [torch.randn((xA, xA), dtype=torch.complex64, device="cuda") for _ in sg_cfgs]
+    by1 = sorted(range(len(sg_cfgs)), key=lambda i: (sg_cfgs[i].off1, i))
+    wave = [i for i in by1 if sg_cfgs[i].off1 == sg_cfgs[by1[0]].off1]
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
+    parts = bwd.wave_contributions([sg_cfgs[i] for i in wave], [data[i] for i in wave])
+    assert bwd.wave_axis == 1  # resolved here, not at the first add_new_subgrid_task
+    bwd.accumulate_wave([sg_cfgs[i] for i in wave], parts)
+    rest = [i for i in by1 if i not in wave]
+    bwd.add_new_subgrid_tasks([sg_cfgs[i] for i in rest], [data[i] for i in rest])
+    assert bwd.wave_axis == 1
+    got = [t.cpu().numpy() for t in bwd.finish()]
+    ref = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs)
+    ref.add_new_subgrid_tasks([sg_cfgs[i] for i in by1], [data[i] for i in by1])
+    want = [t.cpu().numpy() for t in ref.finish()]
+    for a, b in zip(got, want):
+        assert relrms(a, b) < 3e-6
+    # complex128 data through the low-level entry keeps the reference schedule
+    b128 = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
+    b128.wave_contributions([sg_cfgs[0]], [data[0].to(torch.complex128)])
+    assert b128.wave_axis == 0

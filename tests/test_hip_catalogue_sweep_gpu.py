@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 SWEEP = {
     "1k[1]-n512-256": 1,       # all powers of two, smallest fused pair (m, xM) = (128, 256)
     "4k[1]-n2k-512": 1,        # (256, 512)
+    "2k[1]-n1k-512": 1,        # yN = 1024: the backward gather-sum transform must take the four-step (r3 bug: the
+                               # single-pass 32-column geometry has no gather-sum load and read the table as a row map)
     "16k[1]-n8k-1k": 1,        # (512, 1024), generic K1, plain band
     "32k[1]-n16k-1k": 1,       # two-workgroup K1 at 16384, split band
     "3k[1]-n1536-512": 1,      # yN = 3 * 512
