@@ -21,14 +21,14 @@ template <int LOGM, int LOGX>
 static int launch_one_f(const SumFinishFacetArgs& a, int nbatch, hipStream_t s) {
     using S = SFGeo<LOGM, LOGX>;
     dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
-    constexpr size_t lds = sum_finish_facets_lds<LOGM, LOGX>();
+    constexpr size_t lds = sum_finish_facets_kernel_lds<LOGM, LOGX>();
     hipLaunchKernelGGL((sum_finish_facets_kernel<LOGM, LOGX>), grid, dim3(S::NT), lds, s, a);
     return (int)hipGetLastError();
 }
 template <int LOGM, int LOGX>
 static int init_one_f() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&sum_finish_facets_kernel<LOGM, LOGX>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sum_finish_facets_lds<LOGM, LOGX>()));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sum_finish_facets_kernel_lds<LOGM, LOGX>()));
 }
 
 template <int LOGM, int LOGX>

@@ -86,6 +86,17 @@ template <int LOGM, int LOGX>
 constexpr size_t sum_finish_facets_lds() {
     return SFWide<LOGM, LOGX>::ON ? SFWide<LOGM, LOGX>::LDS_BYTES : SFGeo<LOGM, LOGX>::LDS_BYTES;
 }
+// sum_finish_facets_kernel, one wave per row (r4): the accumulator row lives in REGISTERS (see the kernel), so LDS only
+// holds ONE exchange buffer per row -- used by the m-point transforms first, by the xM-point transform last -- and Fn
+template <int LOGM, int LOGX>
+constexpr size_t sum_finish_facets_reg_lds() {
+    using S = SFGeo<LOGM, LOGX>;
+    return (S::LDS_X > S::LDS_M ? S::LDS_X : S::LDS_M) + ((size_t)4 << LOGM);
+}
+template <int LOGM, int LOGX>
+constexpr size_t sum_finish_facets_kernel_lds() {
+    return SFWide<LOGM, LOGX>::ON ? SFWide<LOGM, LOGX>::LDS_BYTES : sum_finish_facets_reg_lds<LOGM, LOGX>();
+}
 
 template <int LOGM, int LOGX>
 __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_rows_kernel(const SumFinishArgs A) {
@@ -197,27 +208,33 @@ struct SumFinishFacetArgs {
     int rgroup[kSumFinishMaxFacets];
 };
 
+// (register form, 1024-point rows: 4 waves per SIMD = 16 rows per CU, which the 8.7 KB of LDS per row now allow)
 template <int LOGM, int LOGX>
-__global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
+__global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GX = typename S::GX;
     using W = SFWide<LOGM, LOGX>;
     using GM = std::conditional_t<W::ON, typename W::GM, typename S::GM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cx<float>* ex_m = reinterpret_cast<cx<float>*>(smem);
-    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + (W::ON ? W::LDS_M : S::LDS_M));
+    // (wave-parallel form: accumulator row in LDS behind the m-point exchange buffers; register form: one exchange
+    // buffer per row shared by both transforms, then the Fn table)
+    cx<float>* acc = reinterpret_cast<cx<float>*>(smem + (W::ON ? W::LDS_M : 0));
     constexpr int M = GM::N, X = GX::N, PM = GM::P, PX = GX::P, TR = S::TR;
     const int t = threadIdx.x % TR, rb = threadIdx.x / TR;
     const int b = blockIdx.y;
     const int row0 = blockIdx.x * S::RB;
     const int row = row0 + rb;
     const bool live = row < A.nrows;
+    cx<float> y[PX];  // register form: the lane's part of the accumulator row, y[v] = row[t + v * TR]
 
-    static_for<0, PX>([&](auto vI) {
-        constexpr int v = decltype(vI)::value;
-        acc[lds_pos<GX>(rb, t + v * TR, false)] = cx<float>{0.f, 0.f};
-    });
-    row_sync<GX>(false);
+    if constexpr (W::ON) {
+        static_for<0, PX>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            acc[lds_pos<GX>(rb, t + v * TR, false)] = cx<float>{0.f, 0.f};
+        });
+        row_sync<GX>(false);
+    }
 
     if constexpr (W::ON) {
         static_assert(S::RB == 1, "one row per workgroup");
@@ -297,7 +314,23 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
     // batch before the current group is transformed -- measured r3 on the 4096-point rows of the N = 32768 workload,
     // whose 8 groups per row are 8 dependent load -> transform steps: 114.5 vs 111-113 ms for the subgrid side, no
     // gain; the 4-points-per-lane m-point transforms with their 9 workgroup barriers each are the cost there.)
-    constexpr int NB = SWF_SF_NB;
+    // r4: ACCUMULATOR IN REGISTERS.  Output e of the m-point transform of lane t is e = t (mod 64) (Stockham: every
+    // output of a lane is congruent to its lane index modulo the thread count), and its place in the padded row, taken
+    // at its plain inverse-transform index p = (kk - m/2 + s') mod xM, is congruent to e modulo m -- so it lands in one
+    // of lane t's OWN inputs y[v] = row[t + 64 v] of the xM-point transform, v = (e - t) / 64 + (m / 64) c with
+    // c = p / m in [0, xM / m).  The placement becomes xM / m multiply-adds per output with weights Fn[kk] * (c == c')
+    // instead of a read-modify-write of an LDS row: no accumulator row (13.3 -> 8.7 KB of LDS per row: 16 instead of
+    // 12 waves per CU), no zero fill, no final read-back, and Fn from a copy in LDS.
+    static_assert(S::LDS_X >= S::LDS_M, "one exchange buffer per row, sized by the longer transform");
+    constexpr int RATIO = X / M;
+    static_assert(PX == PM * RATIO, "accumulator slots");
+    cx<float>* ex_row = reinterpret_cast<cx<float>*>(smem) + (size_t)rb * GX::PITCH;  // this row's exchange buffer (rb = 0 addressing)
+    float* fn_l = reinterpret_cast<float*>(smem + (S::LDS_X > S::LDS_M ? S::LDS_X : S::LDS_M));
+    for (int i = threadIdx.x; i < M; i += S::NT) fn_l[i] = A.fn[i];
+    static_for<0, PX>([&](auto vI) { y[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
+    __syncthreads();
+    // (8 points per lane and 1024-point rows: two facets in flight keep the kernel at 128 VGPRs without spills)
+    constexpr int NB = (PM >= 8 && LOGX <= 10 && SWF_SF_NB > 2) ? 2 : SWF_SF_NB;
     for (int g = 0; g < A.ngroups; g++) {  // workgroup-uniform
         cx<float> xs[PM];
         static_for<0, PM>([&](auto vI) { xs[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
@@ -345,34 +378,64 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void sum_finish_facets_ker
         }
         if (!anyg) continue;
         const int sp = A.gsp1[g];
-        fft_phases<GM, float, 0>(xs, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+        fft_phases<GM, float, 0>(xs, t, 0, false, ex_row, A.tw_m, [&](int e, cx<float> v, auto sI) {
+            // slot = u * RAD + r of the last phase (radix RAD = 2^LR, NB = PM / RAD blocks): e = t + TR * (u + NB * r)
+            constexpr int LR = GM::LOGN % GM::LOGP == 0 ? GM::LOGP : GM::LOGN % GM::LOGP, RAD = 1 << LR, NBL = PM / RAD;
+            constexpr int slot = (decltype(sI)::value / RAD) + NBL * (decltype(sI)::value % RAD);
             const int ck = e ^ (M >> 1);
             const int kk = (ck - sp) & (M - 1);
-            const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);  // centred position in the padded subgrid
-            const float w = A.fn[kk];
-            cx<float>* p = acc + lds_pos<GX>(rb, dest ^ (X >> 1), false);  // stored at its plain iFFT index
-            cx<float> o = *p;
-            o.x += v.x * w;
-            o.y += v.y * w;
-            *p = o;
+            const int p = (kk - (M >> 1) + sp) & (X - 1);  // plain inverse-transform index of the placed element
+            const int c = p >> LOGM;
+            const float w = fn_l[kk];
+            static_for<0, RATIO>([&](auto cI) {
+                constexpr int cc = decltype(cI)::value;
+                const float wc = c == cc ? w : 0.f;
+                y[slot + PM * cc].x += v.x * wc;
+                y[slot + PM * cc].y += v.y * wc;
+            });
         });
-        row_sync<GX>(false);  // also protects ex_m reuse by the next group
+        row_sync<GX>(false);  // the exchange buffer is reused by the next group
     }
+    static_for<0, PX>([&](auto vI) { y[decltype(vI)::value].y = -y[decltype(vI)::value].y; });  // inverse = conj(FFT(conj(.)))
+    acc = ex_row - (size_t)rb * GX::PITCH;  // the xM-point transform exchanges through the same rows
 
     }  // !W::ON
 
-    cx<float> y[PX];
-    static_for<0, PX>([&](auto vI) {
-        constexpr int v = decltype(vI)::value;
-        cx<float> val = acc[lds_pos<GX>(rb, t + v * TR, false)];
-        val.y = -val.y;  // inverse transform = conj(FFT(conj(.)))
-        y[v] = val;
-    });
-    row_sync<GX>(false);
+    if constexpr (W::ON) {
+        static_for<0, PX>([&](auto vI) {
+            constexpr int v = decltype(vI)::value;
+            cx<float> val = acc[lds_pos<GX>(rb, t + v * TR, false)];
+            val.y = -val.y;  // inverse transform = conj(FFT(conj(.)))
+            y[v] = val;
+        });
+        row_sync<GX>(false);
+    }
     cx<float>* __restrict__ out = A.out + (long long)b * A.out_bs + (long long)(live ? row : 0) * A.out_rs;
     const float* __restrict__ mask = A.mask ? A.mask + (long long)b * A.mask_bs : nullptr;
     const int st_a = A.st_a[b];
     const float scale = 1.f / (float)X;
+    if constexpr (!W::ON) {
+        // r4: the mask values of the lane's PX outputs are requested together BEFORE the transform (output slot s of the
+        // last phase is element e = t + TR * (u + NB r)) instead of inside the store loop (fewer branches; measured r4,
+        // same box: 251.9 vs 253.7 us per wave for sum_finish + K5b, i.e. no difference)
+        constexpr int LRX = GX::LOGN % GX::LOGP == 0 ? GX::LOGP : GX::LOGN % GX::LOGP, RADX = 1 << LRX, NBX = PX / RADX;
+        float mw[PX];
+        static_for<0, PX>([&](auto sI) {
+            constexpr int sl = decltype(sI)::value;
+            constexpr int vi = (sl / RADX) + NBX * (sl % RADX);
+            const int d = (((t + TR * vi) ^ (X >> 1)) + st_a) & (X - 1);
+            const bool ok = d < A.xA && live;
+            mw[sl] = mask ? mask[ok ? d : 0] : 1.f;
+        });
+        fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v, auto sI) {
+            constexpr int sl = decltype(sI)::value;
+            const int ck = e ^ (X >> 1);
+            const int d = (ck + st_a) & (X - 1);
+            const float w = scale * mw[sl];
+            if (d < A.xA && live) out[d] = cx<float>{v.x * w, -v.y * w};
+        });
+        return;
+    }
     fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
         const int ck = e ^ (X >> 1);
         const int d = (ck + st_a) & (X - 1);
