@@ -112,6 +112,12 @@ int swiftly_hip_add_to_subgrid(swiftly_hip_t* h, int dtype, const void* in, int6
                                int64_t in_col_stride, void* out, int64_t out_row_stride, int64_t out_col_stride,
                                int64_t facet_off, void* stream);
 
+/* Swiftly.add_to_subgrid_2d(in[m, m], out[xM, xM], facet_off0, facet_off1) (core.py:752-778): both axes in one call;
+ * ACCUMULATES into out.  (Axis 0 into a stream-ordered [xM, m] intermediate, then axis 1 into out.) */
+int swiftly_hip_add_to_subgrid_2d(swiftly_hip_t* h, int dtype, const void* in, int64_t in_row_stride,
+                                  int64_t in_col_stride, void* out, int64_t out_row_stride, int64_t out_col_stride,
+                                  int64_t facet_off0, int64_t facet_off1, void* stream);
+
 /* Swiftly.finish_subgrid(in[rows, xM], out[rows, subgrid_size], subgrid_off)
  * (core.py:798-811; numpy form core.py:316-323), one axis per call.
  * `mask` (optional, device, real of matching precision, length subgrid_size)
@@ -130,6 +136,14 @@ int swiftly_hip_finish_subgrid(swiftly_hip_t* h, int dtype, const void* in, int6
 int swiftly_hip_prepare_subgrid(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t subgrid_size,
                                 int64_t in_row_stride, int64_t in_col_stride, void* out, int64_t out_row_stride,
                                 int64_t out_col_stride, int64_t subgrid_off, void* stream);
+
+/* Swiftly.prepare_subgrid_inplace(data[rows, xM], subgrid_off) (core.py:837-840): `data` already holds the subgrid
+ * zero-padded to xM (pad_mid: centred); in place it becomes fft(roll(data, subgrid_off)) along the axis whose element
+ * stride is col_stride.  ..._2d(data[xM, xM], off0, off1) (core.py:851-853) does both axes. */
+int swiftly_hip_prepare_subgrid_inplace(swiftly_hip_t* h, int dtype, void* data, int64_t rows, int64_t row_stride,
+                                        int64_t col_stride, int64_t subgrid_off, void* stream);
+int swiftly_hip_prepare_subgrid_inplace_2d(swiftly_hip_t* h, int dtype, void* data, int64_t row_stride, int64_t col_stride,
+                                           int64_t subgrid_off0, int64_t subgrid_off1, void* stream);
 
 /* Swiftly.extract_from_subgrid(in[rows, xM], out[rows, m], facet_off)
  * (core.py:873; numpy form core.py:390-405).  Overwrites out. */

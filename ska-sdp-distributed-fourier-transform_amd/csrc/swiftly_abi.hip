@@ -1227,6 +1227,46 @@ int swiftly_hip_prepare_subgrid(swiftly_hip_t* h, int dtype, const void* in, int
                                              subgrid_off, 1, 0, 0, nullptr, stream);
 }
 
+// Swiftly.prepare_subgrid_inplace(data[rows, xM], subgrid_off) (core.py:837-840): `data` holds the subgrid already
+// zero-padded to xM (pad_mid: centred); in place it becomes fft(roll(data, subgrid_off)) along the strided/contiguous
+// axis given by the two strides.  = prepare_subgrid with subgrid_size = xM_size and in == out: every kernel reads all
+// of a row (column tile) before it writes any of it, and the four-step passes go through their own scratch.
+int swiftly_hip_prepare_subgrid_inplace(swiftly_hip_t* h, int dtype, void* data, int64_t rows, int64_t row_stride,
+                                        int64_t col_stride, int64_t subgrid_off, void* stream) {
+    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    return swiftly_hip_prepare_subgrid(h, dtype, data, rows, h->xM, row_stride, col_stride, data, row_stride, col_stride,
+                                       subgrid_off, stream);
+}
+// Swiftly.prepare_subgrid_inplace_2d(data[xM, xM], off0, off1) (core.py:851-853): both axes, axis 1 first
+int swiftly_hip_prepare_subgrid_inplace_2d(swiftly_hip_t* h, int dtype, void* data, int64_t row_stride, int64_t col_stride,
+                                           int64_t subgrid_off0, int64_t subgrid_off1, void* stream) {
+    if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    int rc = swiftly_hip_prepare_subgrid_inplace(h, dtype, data, h->xM, row_stride, col_stride, subgrid_off1, stream);
+    if (rc) return rc;
+    return swiftly_hip_prepare_subgrid_inplace(h, dtype, data, h->xM, col_stride, row_stride, subgrid_off0, stream);
+}
+// Swiftly.add_to_subgrid_2d(in[m, m], out[xM, xM], facet_off0, facet_off1) (core.py:752-778; numpy form = two
+// add_to_subgrid calls, core.py:274-285): ACCUMULATES.  Axis 0 first, as api_helper.py:85-99 does it (the float32
+// rounding of the two orders differs: 5.6e-7 vs 9.0e-7 on the reference-generated golden contribution), into a
+// stream-ordered [xM, m] intermediate, then axis 1 straight into `out`.
+int swiftly_hip_add_to_subgrid_2d(swiftly_hip_t* h, int dtype, const void* in, int64_t in_row_stride,
+                                  int64_t in_col_stride, void* out, int64_t out_row_stride, int64_t out_col_stride,
+                                  int64_t facet_off0, int64_t facet_off1, void* stream) {
+    const int64_t rows = h ? h->m : 0, in_cs = in_col_stride, out_cs = out_col_stride;
+    CHECK_COMMON();
+    const int64_t m = h->m, xM = h->xM;
+    const size_t esz = dtype == SWIFTLY_C64 ? 8 : 16;
+    void* tmp = nullptr;
+    HIP_TRY(hipMallocAsync(&tmp, (size_t)m * (size_t)xM * esz, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(tmp, 0, (size_t)m * (size_t)xM * esz, (hipStream_t)stream));  // add_to_subgrid accumulates
+    // axis 0: the transform runs along the rows of `in` = its strided axis; the "rows" of the primitive are the m columns
+    int rc = swiftly_hip_add_to_subgrid(h, dtype, in, m, in_col_stride, in_row_stride, tmp, 1, m, facet_off0, stream);
+    if (!rc) rc = swiftly_hip_add_to_subgrid(h, dtype, tmp, xM, m, 1, out, out_row_stride, out_col_stride, facet_off1, stream);
+    hipError_t e = hipFreeAsync(tmp, (hipStream_t)stream);
+    if (!rc && e != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e));
+    return rc;
+}
+
 int swiftly_hip_extract_from_subgrid_batch(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_rs,
                                            int64_t in_cs, void* out, int64_t out_rs, int64_t out_cs,
                                            int64_t facet_off, int64_t nbatch, int64_t in_bs, int64_t out_bs,

@@ -56,6 +56,13 @@ def _declare(lib):
         fn = getattr(lib, "swiftly_hip_" + name)
         fn.restype = c_int
         fn.argtypes = args
+    # the 2-D single-call forms of the native shim (core.py:752-778, 837-855)
+    lib.swiftly_hip_add_to_subgrid_2d.restype = c_int
+    lib.swiftly_hip_add_to_subgrid_2d.argtypes = [vp, c_int, vp, i64, i64, vp, i64, i64, i64, i64, vp]
+    lib.swiftly_hip_prepare_subgrid_inplace.restype = c_int
+    lib.swiftly_hip_prepare_subgrid_inplace.argtypes = [vp, c_int, vp, i64, i64, i64, i64, vp]
+    lib.swiftly_hip_prepare_subgrid_inplace_2d.restype = c_int
+    lib.swiftly_hip_prepare_subgrid_inplace_2d.argtypes = [vp, c_int, vp, i64, i64, i64, i64, vp]
     pi64 = POINTER(i64)
     batch = [i64, i64, i64, pi64]  # nbatch, in_bs, out_bs, offs
     for name, args in [

@@ -896,12 +896,35 @@ class SwiftlyCoreHip:
         """Both axes of :py:meth:`add_to_subgrid` (core.py:752-778)."""
         if len(facet_contrib.shape) != 2:
             raise ValueError(f"Invalid number of dimensions in input array: {len(facet_contrib.shape)}")
+        torch = _torch()
         dev, was_numpy = self._as_device(facet_contrib)
+        m, xM = self.xM_yN_size, self.xM_size
+        if tuple(dev.shape) != (m, m):
+            raise ValueError(f"Input has shape {tuple(dev.shape)}, expected {(m, m)}!")
+        if isinstance(out, torch.Tensor) or out is None:
+            # ONE native call (swiftly_hip_add_to_subgrid_2d = Swiftly.add_to_subgrid_2d of the reference's shim)
+            if out is None:
+                res = torch.zeros((xM, xM), dtype=dev.dtype, device=self._device)
+            else:
+                if tuple(out.shape) != (xM, xM):
+                    raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(xM, xM)}!")
+                if out.device != self._device or out.dtype != dev.dtype:
+                    raise ValueError("out= tensor must be a complex tensor of the input's dtype on the core's device")
+                res = out
+            if any(st < 0 for st in dev.stride()) or any(st < 0 for st in res.stride()):
+                raise ValueError("negative strides are not supported")
+            _lib.check(
+                self._lib.swiftly_hip_add_to_subgrid_2d(
+                    self._handle, self._code(dev), ctypes.c_void_p(dev.data_ptr()), dev.stride(0), dev.stride(1),
+                    ctypes.c_void_p(res.data_ptr()), res.stride(0), res.stride(1), int(facet_off0), int(facet_off1),
+                    self._stream(),
+                )
+            )
+            if was_numpy and out is None:
+                return res.cpu().numpy()
+            return res
         tmp = self.add_to_subgrid(dev, facet_off0, axis=0)
-        res = self.add_to_subgrid(tmp, facet_off1, axis=1, out=out)
-        if was_numpy and out is None:
-            return res.cpu().numpy()
-        return res
+        return self.add_to_subgrid(tmp, facet_off1, axis=1, out=out)  # numpy out=: through the accumulate copy-back
 
     def finish_subgrid(self, summed_contribs, subgrid_off, subgrid_size, out=None, masks=None):
         """Inverse-transform the summed contributions along every axis and cut
@@ -967,6 +990,39 @@ class SwiftlyCoreHip:
         if was_numpy and out is None:
             return res.cpu().numpy()
         return res
+
+    def prepare_subgrid_inplace(self, padded, subgrid_off):
+        """``Swiftly.prepare_subgrid_inplace[_2d]`` of the reference's native shim (core.py:837-855): ``padded`` is a
+        device tensor ``[xM]``, ``[rows, xM]`` (one offset: last axis) or ``[xM, xM]`` with a list of two offsets that
+        already holds the subgrid zero-padded to ``xM_size`` (``pad_mid``); it is transformed in place."""
+        torch = _torch()
+        if not isinstance(padded, torch.Tensor) or padded.device != self._device or not padded.is_complex():
+            raise ValueError("prepare_subgrid_inplace needs a complex tensor on the core's device")
+        xM = self.xM_size
+        two = isinstance(subgrid_off, (list, tuple)) and len(subgrid_off) == 2
+        if any(st < 0 for st in padded.stride()):
+            raise ValueError("negative strides are not supported")
+        if two:
+            if tuple(padded.shape) != (xM, xM):
+                raise ValueError(f"Invalid shape {tuple(padded.shape)}!")
+            _lib.check(
+                self._lib.swiftly_hip_prepare_subgrid_inplace_2d(
+                    self._handle, self._code(padded), ctypes.c_void_p(padded.data_ptr()), padded.stride(0),
+                    padded.stride(1), int(subgrid_off[0]), int(subgrid_off[1]), self._stream(),
+                )
+            )
+            return padded
+        off = subgrid_off[0] if isinstance(subgrid_off, (list, tuple)) else subgrid_off
+        x2 = padded.unsqueeze(0) if padded.dim() == 1 else padded
+        if x2.dim() != 2 or x2.shape[1] != xM:
+            raise ValueError(f"Invalid shape {tuple(padded.shape)}!")
+        _lib.check(
+            self._lib.swiftly_hip_prepare_subgrid_inplace(
+                self._handle, self._code(padded), ctypes.c_void_p(x2.data_ptr()), x2.shape[0], x2.stride(0), x2.stride(1),
+                int(off), self._stream(),
+            )
+        )
+        return padded
 
     def extract_from_subgrid(self, FSi, facet_off, axis, out=None):
         """Cut the window of a prepared subgrid that lands on the facet at

@@ -44,7 +44,10 @@ def test_pickle_roundtrip():
     b = _chain(clone, facet, 8, 6, P["xA_size"])
     assert numpy.array_equal(a, b)
     # the state carries no device pointers
-    assert set(core.__getstate__()) == {"W", "N", "xM_size", "yN_size"}
+    assert set(core.__getstate__()) == {"W", "N", "xM_size", "yN_size", "column_precision"}
+    core.column_precision = 64  # the precision setting travels with the pickle
+    assert pickle.loads(pickle.dumps(core)).column_precision == 64
+    core.column_precision = 32
 
 
 def test_eight_threads_share_one_core():
@@ -221,4 +224,76 @@ def test_integration_binding_host_staging():
     run("prepare_subgrid", padded.T.copy(), padded.T, -4)      # axis 0
     want = ref.prepare_subgrid(sg, [-4, 6])
     assert numpy.abs(padded - want).max() <= 1e-12 * numpy.abs(want).max()
+
+    # the single-call 2-D entries of the shim (core.py:752-778, 837-855) through the raw ABI, complex128 and complex64
+    def staged(arr):
+        d = ctypes.c_void_p()
+        c = numpy.array(arr, order="C", copy=True)  # (fetch() overwrites it with the result)
+        _lib.check(lib.swiftly_hip_malloc(ctypes.byref(d), c.nbytes))
+        lib.swiftly_hip_memcpy_h2d(d, c.ctypes.data, c.nbytes, None)
+        return d, c
+
+    def fetch(d, like):
+        lib.swiftly_hip_memcpy_d2h(like.ctypes.data, d, like.nbytes, None)
+        _lib.check(lib.swiftly_hip_stream_synchronize(None))
+        lib.swiftly_hip_free(d)
+        return like
+
+    for cdt, code, tol in ((numpy.complex128, 1, 1e-12), (numpy.complex64, 0, 2e-6)):
+        p2 = numpy.zeros((xM, xM), dtype=cdt)
+        p2[lo : lo + xA, lo : lo + xA] = sg
+        d, c = staged(p2)
+        _lib.check(lib.swiftly_hip_prepare_subgrid_inplace_2d(h, code, d, xM, 1, -4, 6, None))
+        got = fetch(d, c)
+        assert numpy.abs(got - want).max() <= tol * numpy.abs(want).max()
+        # one axis, in place, on the first 9 rows (last axis) ...
+        d, c = staged(p2[lo : lo + 9])
+        _lib.check(lib.swiftly_hip_prepare_subgrid_inplace(h, code, d, 9, xM, 1, 6, None))
+        got = fetch(d, c)
+        w1 = numpy.stack([ref.prepare_subgrid(sg[r].astype(complex), 6) for r in range(9)])
+        assert numpy.abs(got - w1).max() <= tol * numpy.abs(w1).max()
+        # add_to_subgrid_2d accumulates into a pre-filled [xM, xM]
+        c2 = (rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))).astype(cdt)
+        a2 = (rng.standard_normal((xM, xM)) + 1j * rng.standard_normal((xM, xM))).astype(cdt)
+        w2 = a2.astype(complex) + ref.add_to_subgrid(ref.add_to_subgrid(c2.astype(complex), -12, axis=0), 20, axis=1)
+        d_in, _ = staged(c2)
+        d_out, co = staged(a2)
+        _lib.check(lib.swiftly_hip_add_to_subgrid_2d(h, code, d_in, m, 1, d_out, xM, 1, -12, 20, None))
+        got = fetch(d_out, co)
+        lib.swiftly_hip_free(d_in)
+        assert numpy.abs(got - w2).max() <= tol * numpy.abs(w2).max() * (1 if code else 10)
     lib.swiftly_hip_destroy(h)
+
+
+def test_python_mirror_of_the_2d_shim_calls():
+    """SwiftlyCoreHip.add_to_subgrid_2d (one native call) and prepare_subgrid_inplace against the oracle."""
+    import torch
+
+    from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+
+    W, N, xM, yN, xA = P["W"], P["N"], P["xM_size"], P["yN_size"], P["xA_size"]
+    core = SwiftlyCoreHip(W, N, xM, yN)
+    ref = orc.OracleCore(W, N, xM, yN)
+    m = ref.xM_yN_size
+    rng = numpy.random.default_rng(9)
+    c2 = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+    want = ref.add_to_subgrid(ref.add_to_subgrid(c2, 12, axis=0), -4, axis=1)
+    got = core.add_to_subgrid_2d(c2, 12, -4)
+    assert isinstance(got, numpy.ndarray) and numpy.abs(got - want).max() <= 1e-12 * numpy.abs(want).max()
+    acc = torch.from_numpy(want.copy()).cuda()
+    core.add_to_subgrid_2d(torch.from_numpy(c2).cuda(), 12, -4, out=acc)
+    assert numpy.abs(acc.cpu().numpy() - 2 * want).max() <= 1e-12 * numpy.abs(want).max()
+    with pytest.raises(ValueError):
+        core.add_to_subgrid_2d(c2[:-1], 12, -4)
+    sg = rng.standard_normal((xA, xA)) + 1j * rng.standard_normal((xA, xA))
+    padded = numpy.zeros((xM, xM), dtype=complex)
+    lo = xM // 2 - xA // 2
+    padded[lo : lo + xA, lo : lo + xA] = sg
+    t = torch.from_numpy(padded).cuda()
+    assert core.prepare_subgrid_inplace(t, [4, -6]) is t
+    want = ref.prepare_subgrid(sg, [4, -6])
+    assert numpy.abs(t.cpu().numpy() - want).max() <= 1e-12 * numpy.abs(want).max()
+    rows = torch.from_numpy(padded[lo : lo + 3].copy()).cuda()
+    core.prepare_subgrid_inplace(rows, 8)
+    w1 = numpy.stack([ref.prepare_subgrid(sg[r], 8) for r in range(3)])
+    assert numpy.abs(rows.cpu().numpy() - w1).max() <= 1e-12 * numpy.abs(w1).max()
