@@ -116,3 +116,70 @@ def test_sparse_facet_list_on_fused_path(wave_axis):
     facet_cfgs = [sw.FacetConfig(o0, o1, yB, (rng.random(yB) > 0.05).astype(float), None) for o0, o1 in offs]
     sg_cfgs = [sw.SubgridConfig(i0 * 928, i1 * 928, 928) for i0, i1 in ((0, 0), (0, 2), (3, 0), (3, 2), (70, 2))]
     _run(P, facet_cfgs, sg_cfgs, wave_axis, 2e-5)
+
+
+def _full_cover_wave(P, facet_cfgs, wave, check_idx, bwd_facets, tol_f, tol_b, seed=1200, column_precision=None):
+    """One WHOLE wave (all subgrids of the cover that share an ``off1``) through the default pipelines with the given
+    facets: forward against the separable oracle on the subgrids ``check_idx`` of the wave, backward (separable
+    subgrids of the whole wave) element by element on sampled rows of the facets ``bwd_facets``."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+
+    cfg = sw.SwiftlyConfig(backend="hip", column_precision=column_precision, **P)
+    yB = P["yB_size"]
+    vectors = [sep.facet_vectors(seed + j, yB, rank=2) for j in range(len(facet_cfgs))]
+    facets = [bench.separable_facet(torch, vectors[j], c) for j, c in enumerate(facet_cfgs)]
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=wave)
+    assert fwd.wave_axis == 1
+    got = fwd.get_subgrid_tasks(wave)
+    par = bench.verify_subgrids(P, facet_cfgs, vectors, wave, {i: got[i].cpu().numpy() for i in check_idx}, tol=tol_f)
+    print(f"N={P['N']} full-cover wave of {len(wave)} subgrids, {len(facet_cfgs)} facets: forward {par['rel_rmse_each']}")
+    assert par["ok"], par["rel_rmse_each"]
+    del fwd, got, facets
+    torch.cuda.empty_cache()
+    sg_vectors = [sep.subgrid_vectors(seed + 500 + i, c.size, rank=1) for i, c in enumerate(wave)]
+    subgrids = [bench.separable_facet(torch, sg_vectors[i], c) for i, c in enumerate(wave)]
+    bwd = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=wave)
+    bwd.add_new_subgrid_tasks(wave, subgrids)
+    assert bwd.wave_axis == 1
+    out = bwd.finish()
+    bpar = bench.verify_facets(P, [facet_cfgs[j] for j in bwd_facets], wave, sg_vectors, [out[j] for j in bwd_facets],
+                               rows_per_facet=6, tol=tol_b)
+    print(f"    backward rows of facets {bwd_facets}: {bpar['rel_rmse_each']}")
+    assert bpar["ok"], bpar["rel_rmse_each"]
+
+
+def test_config3_full_cover_wave_all_64_facets():
+    """BASELINE config 3 at FULL facet cover (r3 review: only 2 of the 64 facets were driver-checked): 8 x 8 facets ->
+    the 16 subgrids of one off1 column.  The subgrid side sums 64 facets in 8 off1 groups per padded row through the
+    wave-parallel sum_finish / split_prepare instances <10, 12> with their host-side colouring rounds; yN = 8192 runs
+    the generic K1, m = 1024 the single-pass column transform."""
+    import ska_sdp_exec_swiftly_amd as sw
+
+    P = dict(W=11.0, fov=1.0, N=32768, yB_size=4096, yN_size=8192, xA_size=2048, xM_size=4096)
+    facet_cfgs = sw.api.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
+    assert len(facet_cfgs) == 64
+    sgs = sw.api.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
+    wave = [c for c in sgs if c.off1 == 5 * 2048]
+    assert len(wave) == 16
+    _full_cover_wave(P, facet_cfgs, wave, check_idx=[0, 7, 15], bwd_facets=[0, 13, 36, 63], tol_f=2e-5, tol_b=4e-5)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_config5_full_wave_yN65536(bits):
+    """BASELINE config 5 (catalogue 128k[1]-n64k-1k, yN = 65536) on the two facets a rank of an 8-GPU node holds: one
+    whole wave (142 subgrids) forward against the oracle, and -- instead of the adjoint identity of r3 -- its backward
+    pass element by element against the separable backward oracle; in both column precisions."""
+    import ska_sdp_exec_swiftly_amd as sw
+
+    P = dict(W=10.875, fov=1.0, N=131072, yB_size=45056, yN_size=65536, xA_size=928, xM_size=1024)
+    cover = sw.api.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)
+    facet_cfgs = [c for c in cover if (c.off0, c.off1) in ((0, 45056), (90112, 0))]
+    sgs = sw.api.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
+    wave = [c for c in sgs if c.off1 == 3 * 928]
+    assert len(wave) == 142
+    # column_precision = 64: float64 arithmetic in the 256 x 256 passes of K2, in K3 and in their backward mirrors
+    tol_f, tol_b = (2e-5, 4e-5) if bits == 32 else (5e-6, 1e-5)
+    _full_cover_wave(P, facet_cfgs, wave, check_idx=[0, 70, 141], bwd_facets=[0, 1], tol_f=tol_f, tol_b=tol_b,
+                     column_precision=bits)
