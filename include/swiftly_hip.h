@@ -68,6 +68,10 @@ const char* swiftly_hip_last_error(void);
 int swiftly_hip_version(void);
 /* Number of visible HIP devices (0 when there is no GPU; never fails). */
 int swiftly_hip_device_count(void);
+/* Identity of the build: the first 16 hex digits of the SHA-256 of the kernel sources (the headers and .hip files
+ * of csrc, this header, the Makefile) the library was compiled from.  The per-kernel counter summaries under profiles/
+ * record it and bench.py compares it with the running build. */
+const char* swiftly_hip_build_id(void);
 
 /*
  * Replaces Swiftly(N, yN_size, xM_size, W) (core.py:508-510) and the parameter

@@ -1,6 +1,7 @@
 // C ABI of libswiftly_hip.so, part 3: device memory / stream helpers for callers without their own allocator,
 // CU-partitioned streams and diagnostics (include/swiftly_hip.h, last section).
 #include "swiftly_abi_internal.h"
+#include "build/build_id.h"
 
 // where does this workgroup run?  xcc_id << 16 | se_id << 8 | cu_id  (HW_REG_XCC_ID, HW_REG_HW_ID of gfx9);
 // the workgroup lingers for a few microseconds so that a census grid spreads over all CUs its stream may use
@@ -16,6 +17,8 @@ __global__ void cu_census_kernel(int* __restrict__ out) {
 
 
 extern "C" {
+
+const char* swiftly_hip_build_id(void) { return SWF_SRC_HASH; }
 
 int swiftly_hip_set_column_precision(swiftly_hip_t* h, int bits) {
     if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");

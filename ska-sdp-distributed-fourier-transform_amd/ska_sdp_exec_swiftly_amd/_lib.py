@@ -35,6 +35,8 @@ def _declare(lib):
     lib.swiftly_hip_destroy.argtypes = [vp]
     lib.swiftly_hip_contribution_size.restype = i64
     lib.swiftly_hip_contribution_size.argtypes = [vp]
+    lib.swiftly_hip_build_id.restype = ctypes.c_char_p
+    lib.swiftly_hip_build_id.argtypes = []
     lib.swiftly_hip_set_column_precision.restype = ctypes.c_int
     lib.swiftly_hip_set_column_precision.argtypes = [vp, ctypes.c_int]
     lib.swiftly_hip_get_column_precision.restype = ctypes.c_int
@@ -177,3 +179,21 @@ def check(rc):
     if rc == ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
     raise SwiftlyHipError(msg)
+
+
+def build_info():
+    """Identity of the running native build: ``src_hash`` compiled into the library (``swiftly_hip_build_id``: hash of
+    the kernel sources), ``so_sha256`` of the loaded file, and the git commit the objects were built at (stamped by
+    the Makefile beside them; ``None`` when absent)."""
+    import hashlib  # pylint: disable=import-outside-toplevel
+
+    lib = load()
+    with open(LIB_PATH, "rb") as fh:
+        sha = hashlib.sha256(fh.read()).hexdigest()
+    head = None
+    try:
+        with open(os.path.join(os.path.dirname(_HERE), "csrc", "build", "GIT_HEAD"), encoding="utf-8") as fh:
+            head = "".join(fh.read().split())
+    except OSError:
+        pass
+    return dict(src_hash=lib.swiftly_hip_build_id().decode(), so_sha256=sha[:16], git_head=head, library=os.path.basename(LIB_PATH))

@@ -149,6 +149,14 @@ def budget(P=PROBE, fo=PROBE_FO, so=PROBE_SO, seed=5, split=(32, 64)):
     return rows
 
 
+def chain_error(bits, P=PROBE, fo=PROBE_FO, so=PROBE_SO, seed=5, split=(32, 64)):
+    """end-to-end relative RMSE of the emulated chain with the given per-stage arithmetic"""
+    rng = numpy.random.default_rng(seed)
+    yB = P["yB"]
+    facet = _c64(rng.standard_normal((yB, yB)) + 1j * rng.standard_normal((yB, yB)))
+    return rel_rmse(forward_chain(P, facet, fo, so, bits, split), reference_chain(P, facet, fo, so))
+
+
 if __name__ == "__main__":
     for name, v in budget().items():
         print(f"{v:.3e}  {name}")

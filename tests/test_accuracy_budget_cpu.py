@@ -1,0 +1,31 @@
+"""
+The complex64 error budget of the forward dataflow, pinned on the CPU (tests/accuracy_model.py: the HIP pipeline's axis
+order and stored intermediates replayed with numpy / scipy on the probe configuration N = 8192, one dense facet, one
+subgrid, against the complex128 oracle chain).  These numbers are what DESIGN.md section 2 and the tolerances in
+bench.py rest on; r3's storage-floor figure (1.0e-5) came from a probe that trusted numpy's complex64 ifft to compute
+in double and was 4x too high.
+"""
+import accuracy_model as am
+
+
+def test_storage_floor_and_the_stages_that_set_the_float32_error():
+    rows = am.budget()
+    for name, v in rows.items():
+        print(f"{v:.3e}  {name}")
+    floor = rows["storage floor: float64 arithmetic, complex64 intermediates (no scratch)"]
+    floor_scratch = rows["storage floor incl. the complex64 four-step scratch of K2"]
+    all32 = rows["float32 arithmetic everywhere (r3 kernels)"]
+    assert 1.5e-6 < floor < 3e-6            # 2.3e-6
+    assert floor < floor_scratch < 4.5e-6   # 3.3e-6: the scratch is one more complex64 rounding at the amplified level
+    assert 1.0e-5 < all32 < 1.6e-5          # 1.3e-5: what the float32 kernels measure on this configuration (1.28e-5)
+    # the float32 ARITHMETIC of two stages sets the end-to-end error: K2 (yN-point transform along the strided axis) and
+    # K3 (the m-point transform behind it) work on data amplified by BOTH facet windows; every other stage is harmless
+    assert rows["float32 arithmetic in k2 only"] > 2.5 * floor_scratch
+    assert rows["float32 arithmetic in k3 only"] > 2.5 * floor_scratch
+    for st in ("k1", "sf", "k5"):
+        assert rows[f"float32 arithmetic in {st} only"] < 1.1 * floor_scratch
+    # float64 arithmetic in K2 alone is not enough, in K2 and K3 it is
+    assert rows["float64 arithmetic in k2 only (r4 kernels)"] > 2 * floor_scratch
+    both = am.chain_error(dict(k1=32, k2=64, k3=64, sf=32, k5=32))
+    print(f"{both:.3e}  float64 arithmetic in k2 and k3 (column_precision = 64)")
+    assert both < 1.15 * floor_scratch      # 3.5e-6

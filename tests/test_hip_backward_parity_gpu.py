@@ -12,8 +12,9 @@ kernels at the long transform lengths.
   finish_facet axis 0 -> mask0 -> add_to_facet axis 1 into the band) and ``swiftly_hip_finish_facet_band`` (the
   ``ST = 2`` long-row kernel) at yN = 32768 and 65536 against the oracle primitives.
 
-Tolerances (complex64, float32 arithmetic, W = 10.875 family): single long transform of
-un-amplified data 2e-6 relative RMSE; the whole backward pass 4e-5 per facet row set.
+Tolerances (complex64, W = 10.875 family): single long transform of un-amplified data 2e-6
+relative RMSE; the whole backward pass 3.5e-5 per facet row set with float32 arithmetic (measured 2.1e-5), 1e-5 with
+float64 arithmetic in the column passes (measured 5.1e-6).
 """
 import numpy
 import pytest
@@ -31,15 +32,18 @@ def relrms(a, b):
     return float(numpy.sqrt(numpy.mean(numpy.abs(a - b) ** 2) / numpy.mean(numpy.abs(b) ** 2)))
 
 
-@pytest.mark.parametrize("baxis", [1, 0])
-def test_backward_64k_sparse_rows_match_oracle(baxis):
+@pytest.mark.parametrize("baxis,bits", [(1, 32), (0, 32), (1, 64)], ids=["band-f32", "reference-order-f32", "band-f64"])
+def test_backward_64k_sparse_rows_match_oracle(baxis, bits):
+    """bits = 64: float64 arithmetic in the column passes of the band schedule (gather-sum four-step + the m-point
+    pass of extract_from_subgrid): 2.1e-5 -> 5.1e-6, bound 1e-5."""
     import torch
 
     import ska_sdp_exec_swiftly_amd as sw
 
     wl = bench.WORKLOADS["64k-sparse"]
     p = wl["params"]
-    cfg = sw.SwiftlyConfig(backend="hip", **p)
+    cfg = sw.SwiftlyConfig(backend="hip", column_precision=bits, **p)
+    tol = BACKWARD_TOL if bits == 32 else bench.HIGH_PRECISION_BACKWARD_PARITY_TOL
     facet_cfgs = sw.make_full_facet_cover(cfg)
     sg_cfgs = bench.select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
     assert (len(facet_cfgs), len(sg_cfgs)) == (9, 505)
@@ -62,10 +66,10 @@ def test_backward_64k_sparse_rows_match_oracle(baxis):
     out = bwd.finish()
     torch.cuda.synchronize()
     par = bench.verify_facets(p, facet_cfgs, sg_cfgs, vectors, out, rows_per_facet=16)
-    print(f"backward wave_axis={baxis}: relRMSE per facet {par['rel_rmse_each']} max|err|/rms {par['max_abs_over_rms']:.2e}")
+    print(f"backward wave_axis={baxis} float{bits}: relRMSE per facet {par['rel_rmse_each']} max|err|/rms {par['max_abs_over_rms']:.2e}")
     assert par["facets"] == 9 and par["rows_per_facet"] == 16
-    assert par["rel_rmse"] < BACKWARD_TOL, par
-    assert par["max_abs_over_rms"] < 20 * BACKWARD_TOL, par
+    assert par["rel_rmse"] < tol, par
+    assert par["max_abs_over_rms"] < 40 * tol, par
 
 
 LONG = [

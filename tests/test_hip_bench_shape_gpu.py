@@ -13,7 +13,8 @@ bench.py constructs it -- against
       tests/test_api.py:56-125.
 
 Tolerance (complex64, W = 10.875 family, max 1/pswf ~ 90): relative RMSE vs the
-complex128 oracle < 2e-5 per subgrid.
+complex128 oracle < 1.5e-5 per subgrid with float32 arithmetic (measured 1.0e-5),
+< 5e-6 with float64 arithmetic in the column passes (measured 2.8e-6); DESIGN.md section 2.
 """
 import numpy
 import pytest
@@ -69,8 +70,12 @@ def _axes(sw, cfg, torch):
     return axes
 
 
-def test_forward_64k_sparse_matches_oracle():
+@pytest.mark.parametrize("bits", [32, 64])
+def test_forward_64k_sparse_matches_oracle(bits):
+    """bits = 64: float64 arithmetic in K2 / K3 (column_precision): 1.0e-5 -> 2.8e-6 on the band pipeline, bound 5e-6."""
     torch, sw, p, cfg, facet_cfgs, sg_cfgs = _setup()
+    cfg.core.column_precision = bits
+    tol = TOL if bits == 32 else bench.HIGH_PRECISION_PARITY_TOL
     N, yB = p["N"], p["yB_size"]
     # dense separable facets (exactly bench.py's data) + point sources near the centre, the edges and
     # in the wrapped (negative-coordinate) facets, so every facet carries both kinds of content
@@ -84,6 +89,8 @@ def test_forward_64k_sparse_matches_oracle():
     picks = _picks(sg_cfgs, p, 6)
     assert len(picks) == 10
     for axis in _axes(sw, cfg, torch):
+        if bits == 64 and axis == 0:
+            continue  # the float64 column passes belong to the band pipeline
         fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=axis)
         got = {}
         for widx in _waves_with(sg_cfgs, picks, axis):
@@ -93,9 +100,9 @@ def test_forward_64k_sparse_matches_oracle():
                     got[i] = res[k].cpu().numpy()
         assert sorted(got) == sorted(picks)
         par = bench.verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, got, pixels)
-        print(f"wave_axis={axis}: relRMSE per subgrid {par['rel_rmse_each']} max|err|/rms {par['max_abs_over_rms']:.2e}")
-        assert par["rel_rmse"] < TOL, par
-        assert par["max_abs_over_rms"] < 20 * TOL, par
+        print(f"wave_axis={axis} float{bits}: relRMSE per subgrid {par['rel_rmse_each']} max|err|/rms {par['max_abs_over_rms']:.2e}")
+        assert par["rel_rmse"] < tol, par
+        assert par["max_abs_over_rms"] < 20 * tol, par
         del fwd, got
         torch.cuda.empty_cache()
 

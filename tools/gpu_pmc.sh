@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel HBM traffic of the forward pass (three rocprofv3 runs of the same command; counters in their own runs):
-#   tools/gpu_pmc.sh OUTDIR [workload]   ->  OUTDIR/pmc_kernels.json (copy to profiles/r3_pmc_kernels.json)
+#   tools/gpu_pmc.sh OUTDIR [workload]   ->  OUTDIR/pmc_kernels.json (copy to profiles/r4_pmc_kernels.json; carries the build identity: source hash, .so hash, git commit)
 out=$1; wl=${2:-64k-sparse}
 mkdir -p "$out"
 export TMPDIR=/tmp

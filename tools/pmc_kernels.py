@@ -8,7 +8,7 @@
   pmc_write.db    : rocprofv3 --kernel-trace --pmc WRITE_SIZE     -> bytes written per launch
 
 (FETCH_SIZE / WRITE_SIZE need separate passes on gfx950; FETCH_SIZE tallies 64 B per 128 B request and is doubled;
-MI355X_MICROARCH.md, section HBM.)  Writes profiles/r3_pmc_kernels.json, which bench.py reads for `roofline.traffic`,
+MI355X_MICROARCH.md, section HBM.)  Writes profiles/r4_pmc_kernels.json, which bench.py reads for `roofline.traffic`,
 `roofline.sustained` and the `kernels` table of the JSON line."""
 import collections
 import json
@@ -67,7 +67,7 @@ def per_kernel(path, counter=None):
 
 def main():
     kt, pf, pw = sys.argv[1:4]
-    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r3_pmc_kernels.json")
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r4_pmc_kernels.json")
     workload = sys.argv[5] if len(sys.argv) > 5 else "64k-sparse"
     t, f, w = per_kernel(kt), per_kernel(pf, "FETCH_SIZE"), per_kernel(pw, "WRITE_SIZE")
     table = {}
@@ -90,7 +90,13 @@ def main():
             rec = json.load(fh)
     except (OSError, ValueError):
         rec = {}
+    # which build this was collected on (r4): the source hash compiled into the library, the hash of the .so file and
+    # the git commit stamped by the Makefile; bench.py reports "stale" when the running library differs
+    sys.path.insert(0, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd"))
+    from ska_sdp_exec_swiftly_amd import _lib  # noqa: E402  pylint: disable=import-outside-toplevel
+
     rec[workload] = dict(
+        build=_lib.build_info(),
         kernels=table,
         note="rocprofv3 --kernel-trace (durations) and --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
              "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-backward` of this build; per-launch "
