@@ -36,16 +36,18 @@ static int launch_mode_f64(const ColPassArgs& a, const ColZ& cz, int outer, int 
     } else {
         using G = typename CGeoFor<LOGN, double>::type;
         if (!a.twd || (MODE == 0 && !a.twd_full)) return (int)hipErrorInvalidValue;
-        dim3 grid((unsigned)((a.ncols + G::COLS - 1) / G::COLS), (unsigned)outer, (unsigned)nbatch);
         if (a.gs) {
-            if constexpr (MODE != 1 && !G::HALF) {
-                hipLaunchKernelGGL((col_pass_kernel<G, MODE, true, true, double>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in,
+            using GG = typename CGeoFor<LOGN, double>::type_gs;
+            if constexpr (MODE != 1 && !GG::HALF) {
+                dim3 ggrid((unsigned)((a.ncols + GG::COLS - 1) / GG::COLS), (unsigned)outer, (unsigned)nbatch);
+                hipLaunchKernelGGL((col_pass_kernel<GG, MODE, true, true, double>), ggrid, dim3(GG::NT), GG::LDS_BYTES, s, a, a.in,
                                    a.out, a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.twd, a.twd_full, cz);
                 return (int)hipGetLastError();
             } else {
                 return (int)hipErrorInvalidConfiguration;
             }
         }
+        dim3 grid((unsigned)((a.ncols + G::COLS - 1) / G::COLS), (unsigned)outer, (unsigned)nbatch);
         if (MODE == 2 || a.scratch_nt)
             hipLaunchKernelGGL((col_pass_kernel<G, MODE, true, false, double>), grid, dim3(G::NT), G::LDS_BYTES, s, a, a.in,
                                a.out, a.ld_win, a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.twd, a.twd_full, cz);
@@ -68,10 +70,11 @@ static int init_mode_f64() {
             rc = (int)hipFuncSetAttribute(
                 reinterpret_cast<const void*>(&col_pass_kernel<G, (MODE == 2 ? 0 : MODE), false, false, double>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if constexpr (MODE != 1 && !G::HALF) {
+        using GG = typename CGeoFor<LOGN, double>::type_gs;
+        if constexpr (MODE != 1 && !GG::HALF) {
             if (!rc)
-                rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<G, MODE, true, true, double>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+                rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<GG, MODE, true, true, double>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GG::LDS_BYTES);
         }
         return rc;
     }

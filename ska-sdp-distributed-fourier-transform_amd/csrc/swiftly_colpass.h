@@ -170,7 +170,12 @@ constexpr int kColPassMaxLogF64 = 9;
 template <int LOGN>
 struct CGeoFor<LOGN, double> {
     static constexpr int LOGP = LOGN < 4 ? LOGN : 4;
-    using type = CGeo<LOGN, LOGP, true, (LOGN >= 9 ? 32 : 64), 8>;
+    // 32-column tiles for 128 points (256 threads and 32 KiB per workgroup: four workgroups per CU in different phases
+    // instead of two; measured r4 on the 64k pass: 757 -> 632 us per wave) and for 512 points (1024 threads); 256 points
+    // stay at 64 columns (1024 threads, 128 KiB: 608 us against 632 us with 32 columns)
+    using type = CGeo<LOGN, LOGP, true, ((LOGN == 7 || LOGN >= 9) ? 32 : 64), 8>;
+    // the gather-sum load (backward pass) exists for 64-column tiles only
+    using type_gs = CGeo<LOGN, LOGP, true, (LOGN >= 9 ? 32 : 64), 8>;
 };
 
 // value of `val` held by the lane that describes row slot v of THIS lane's half-wave (HALF) / of the wave
