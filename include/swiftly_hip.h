@@ -300,6 +300,15 @@ int64_t swiftly_hip_band_columns_for(const swiftly_hip_t* h, int64_t band_len);
 int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                    int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                    int64_t band_start, int64_t band_len, int fold_other_axis_window, void* stream);
+/* The same for a BLOCK OF ROWS [other_axis_row0, other_axis_row0 + rows) of a facet with other_axis_size rows (`in` points
+ * at the first row of the block): the folded window of the other axis is that facet's 1/pswf at those rows, so that the
+ * band rows of several blocks -- computed by different GPUs -- assemble to the band buffer of the whole facet
+ * (distributed.py: cooperative facets when the facet count does not divide by the number of ranks).
+ * other_axis_size = 0: no window of the other axis.  Split band layout only (yN_size 16384 .. 65536). */
+int swiftly_hip_prepare_facet_band_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
+                                        int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
+                                        int64_t band_start, int64_t band_len, int64_t other_axis_size,
+                                        int64_t other_axis_row0, void* stream);
 
 /* K2: for every facet f < nfacets: extract_from_facet(P_f, subgrid_off1, axis=1) (core.py:715) folded into the load
  * of prepare_facet(., facet_off0s[f], axis=0) WITHOUT its window (pre-applied by prepare_facet_band).

@@ -1323,7 +1323,23 @@ int swiftly_hip_finish_facet(swiftly_hip_t* h, int dtype, const void* in, int64_
 int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                    int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                    int64_t band_start, int64_t band_len, int fold_other_axis_window, void* stream) {
+    return swiftly_hip_prepare_facet_band_rows(h, dtype, in, rows, facet_size, in_row_stride, out, out_row_stride, facet_off,
+                                               band_start, band_len, fold_other_axis_window ? rows : 0, 0, stream);
+}
+
+// prepare_facet_band for the rows [other_axis_row0, other_axis_row0 + rows) of a facet whose other axis has
+// other_axis_size pixels: the folded window of the other axis is that facet's, not the one of a `rows`-pixel facet
+// (cooperative facets of the multi-GPU pass: every rank transforms a block of rows of the same facet);
+// other_axis_size = 0: no window of the other axis.
+int swiftly_hip_prepare_facet_band_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
+                                        int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
+                                        int64_t band_start, int64_t band_len, int64_t other_axis_size,
+                                        int64_t other_axis_row0, void* stream) {
+    const int fold_other_axis_window = other_axis_size > 0;
     if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    if (fold_other_axis_window && (other_axis_row0 < 0 || other_axis_row0 + rows > other_axis_size))
+        return fail(SWIFTLY_ERR_PARAM, "rows [%lld, +%lld) are not inside a facet of %lld rows", (long long)other_axis_row0,
+                    (long long)rows, (long long)other_axis_size);
     DeviceGuard device_guard_(h->device);
     if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: complex64 only");
     CHECK_FACET_SIZE();
@@ -1334,13 +1350,15 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     if (rows < 0 || rows > 0x7fffffff) return fail(SWIFTLY_ERR_PARAM, "bad row count");
     if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN)
         return fail(SWIFTLY_ERR_PARAM, "band [%lld, +%lld) is not a cyclic range of [0, %d)", (long long)band_start, (long long)band_len, yN);
-    if (fold_other_axis_window && (rows <= 0 || rows >= h->yN))
-        return fail(SWIFTLY_ERR_PARAM, "other-axis facet size %lld must be in [1, yN_size - 1]", (long long)rows);
+    if (fold_other_axis_window && (other_axis_size <= 0 || other_axis_size >= h->yN))
+        return fail(SWIFTLY_ERR_PARAM, "other-axis facet size %lld must be in [1, yN_size - 1]", (long long)other_axis_size);
     if (rows == 0) return 0;
     if (!band_is_split(h)) {
         // short rows: the generic contiguous-axis prepare_facet, whole padded axis, plain column order
         if (band_start != 0 || band_len != yN)
             return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band: yN_size %d keeps the whole padded axis (band must be (0, yN_size))", yN);
+        if (fold_other_axis_window && (other_axis_row0 != 0 || other_axis_size != rows))
+            return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_band_rows: row blocks need the split band layout (yN_size 16384 .. 65536)");
         return do_prepare_facet<float>(h, in, rows, facet_size, in_row_stride, 1, out, out_row_stride, 1, facet_off, INT64_MIN,
                                        nullptr, nullptr, fold_other_axis_window, 0, (hipStream_t)stream);
     }
@@ -1355,7 +1373,7 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
     r.st_len = yN; r.st_mod = yN;
     r.scale = (float)(1.0 / yN);
     r.conj_ld = r.conj_st = 1;
-    r.row_win = fold_other_axis_window ? h->invp_f + (yN / 2 - (int)(rows / 2)) : nullptr;
+    r.row_win = fold_other_axis_window ? h->invp_f + (yN / 2 - (int)(other_axis_size / 2) + (int)other_axis_row0) : nullptr;
     r.band_start = (int)band_start; r.band_len = (int)band_len; r.band_half = (int)band_half_columns(band_len);
     const cx<float>* twh = twiddles<float>(h, h->log_yN - 1);
     const cx<float>* twf = twiddles<float>(h, h->log_yN);

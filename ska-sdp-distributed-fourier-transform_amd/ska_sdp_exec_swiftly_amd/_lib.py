@@ -92,6 +92,8 @@ def _declare(lib):
     lib.swiftly_hip_band_columns_for.argtypes = [vp, i64]
     lib.swiftly_hip_prepare_facet_band.restype = c_int
     lib.swiftly_hip_prepare_facet_band.argtypes = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, c_int, vp]
+    lib.swiftly_hip_prepare_facet_band_rows.restype = c_int
+    lib.swiftly_hip_prepare_facet_band_rows.argtypes = [vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]
     lib.swiftly_hip_prepare_facet_columns.restype = c_int
     lib.swiftly_hip_prepare_facet_columns.argtypes = [vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, i64, vp, vp]
     lib.swiftly_hip_transform_contributions.restype = c_int

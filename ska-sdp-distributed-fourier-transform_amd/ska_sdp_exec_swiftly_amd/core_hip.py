@@ -567,10 +567,12 @@ class SwiftlyCoreHip:
         """physical columns of a band buffer"""
         return int(self._lib.swiftly_hip_band_columns_for(self._handle, int(band[1])))
 
-    def prepare_facet_band(self, facet, facet_off, band, out=None, fold_other_axis_window=True):
+    def prepare_facet_band(self, facet, facet_off, band, out=None, fold_other_axis_window=True, rows_of=None):
         """K1 (contiguous axis first): ``prepare_facet(facet, facet_off, axis=1)`` for every row of a row-major
         device facet, keeping only the band of output columns (parity-split layout, see include/swiftly_hip.h),
-        times the 1/PSWF window of axis 0 when ``fold_other_axis_window``."""
+        times the 1/PSWF window of axis 0 when ``fold_other_axis_window``.  ``rows_of=(size, row0)``: ``facet`` is
+        the block of rows ``[row0, row0 + facet.shape[0])`` of a facet with ``size`` rows -- the axis-0 window is that
+        facet's (``swiftly_hip_prepare_facet_band_rows``)."""
         torch = _torch()
         if facet.dim() != 2 or facet.stride(1) != 1:
             raise ValueError("prepare_facet_band needs a row-major 2-D device tensor")
@@ -579,6 +581,16 @@ class SwiftlyCoreHip:
             out = torch.empty((facet.shape[0], ncols), dtype=facet.dtype, device=self._device)
         elif tuple(out.shape) != (facet.shape[0], ncols) or out.stride(1) != 1:
             raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(facet.shape[0], ncols)}!")
+        if rows_of is not None:
+            _lib.check(
+                self._lib.swiftly_hip_prepare_facet_band_rows(
+                    self._handle, self._code(facet), ctypes.c_void_p(facet.data_ptr()), int(facet.shape[0]),
+                    int(facet.shape[1]), facet.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(0), int(facet_off),
+                    int(band[0]), int(band[1]), int(rows_of[0]) if fold_other_axis_window else 0, int(rows_of[1]),
+                    self._stream(),
+                )
+            )
+            return out
         _lib.check(
             self._lib.swiftly_hip_prepare_facet_band(
                 self._handle, self._code(facet), ctypes.c_void_p(facet.data_ptr()), int(facet.shape[0]),

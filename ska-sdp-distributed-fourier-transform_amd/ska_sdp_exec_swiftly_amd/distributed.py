@@ -49,11 +49,28 @@ class FacetSharding:
     with the FEWEST facets: when the facet count does not divide by the world
     size (the catalogue's 3x3 facets on 8 GPUs) the ranks that carry an extra
     facet already have the longest facet-side critical path, so they take no
-    subgrid-side work (``balance=False``: every rank takes subgrids)."""
+    subgrid-side work (``balance=False``: every rank takes subgrids).
 
-    def __init__(self, n_facets, rank, world, balance=True):
+    **Cooperative facets** (r4; ``wave_keys`` = the wave keys of the plan in band order): the ``F mod world`` facets
+    that do not fill a round are not handed to single ranks (which bounds the 3x3 cover at 4.9x on 8 GPUs) but worked
+    on by ALL ranks -- the reference balances at (facet, column) task granularity too (api.py:300-324):
+
+    * K1 (the full-facet transform along the contiguous axis) is row-independent: rank ``r`` transforms the rows
+      ``coop_rows(size, r)`` of every cooperative facet;
+    * the per-wave facet-side work (K2, K3) of a cooperative facet belongs to ONE rank per wave, ``key_owner[key]``,
+      contiguous ranges of waves per rank -- so each rank needs all rows but only the band columns of its waves: one
+      all-to-all per pass moves the band rows (row blocks out, column ranges in);
+    * the blocks of wave ``key`` therefore come from ``items_of(r, key)`` = the whole facets of ``r`` plus the
+      cooperative facets it owns for that wave, and arrive in the order ``arrival(key)``."""
+
+    def __init__(self, n_facets, rank, world, balance=True, wave_keys=None):
         self.n_facets, self.rank, self.world = n_facets, rank, world
-        self.facets_of = [[j for j in range(n_facets) if j % world == r] for r in range(world)]
+        n_whole = n_facets
+        self.coop = []
+        if wave_keys is not None and world > 1 and n_facets % world:
+            n_whole = (n_facets // world) * world
+            self.coop = list(range(n_whole, n_facets))
+        self.facets_of = [[j for j in range(n_whole) if j % world == r] for r in range(world)]
         self.local_facets = self.facets_of[rank]
         counts = [len(f) for f in self.facets_of]
         if balance and min(counts) < max(counts):
@@ -63,6 +80,15 @@ class FacetSharding:
         # facet order after concatenating received blocks in source-rank order (= owner-major order)
         self.arrival_order = [j for r in range(world) for j in self.facets_of[r]]
         self.to_global = numpy.argsort(self.arrival_order)  # arrival position of global facet j
+        self.wave_keys, self.key_owner, self.keys_of = None, {}, [[] for _ in range(world)]
+        if self.coop:
+            self.wave_keys = [int(k) for k in wave_keys]
+            K = len(self.wave_keys)
+            bounds = [(i * K) // world for i in range(world + 1)]
+            for r in range(world):
+                self.keys_of[r] = self.wave_keys[bounds[r] : bounds[r + 1]]
+                for k in self.keys_of[r]:
+                    self.key_owner[k] = r
 
     def subgrids_of(self, n_subgrids, rank=None):
         """indices (within the wave) of the subgrids of ``rank``"""
@@ -70,6 +96,24 @@ class FacetSharding:
         if rank not in self.subgrid_ranks:
             return []
         return list(range(self.subgrid_ranks.index(rank), n_subgrids, len(self.subgrid_ranks)))
+
+    def coop_rows(self, size, rank=None):
+        """``(row0, rows)`` of a cooperative facet with ``size`` rows that ``rank`` transforms in K1 (blocks of whole
+        multiples of 8 rows, consecutive in rank order)"""
+        rank = self.rank if rank is None else rank
+        cut = [min(size, ((i * size) // self.world + 7) // 8 * 8) for i in range(self.world)] + [size]
+        return cut[rank], cut[rank + 1] - cut[rank]
+
+    def items_of(self, rank, key=None):
+        """global facet indices whose blocks ``rank`` produces for wave ``key``"""
+        own = list(self.facets_of[rank])
+        if self.coop and key is not None and self.key_owner.get(int(key)) == rank:
+            own += self.coop
+        return own
+
+    def arrival(self, key=None):
+        """facet order of the blocks of wave ``key`` after concatenating the received chunks in source-rank order"""
+        return [j for r in range(self.world) for j in self.items_of(r, key)]
 
 
 class _Pending:
@@ -112,21 +156,22 @@ def _all_to_all(send, in_counts, out_counts, group=None, async_op=True):
     return _Pending(work if async_op else None, recv, send)
 
 
-def forward_layout(sharding, n_subgrids, blk):
-    """Element counts of the forward exchange: (per-destination subgrid index lists, in_counts, out_counts)."""
-    F_local = len(sharding.local_facets)
+def forward_layout(sharding, n_subgrids, blk, key=None):
+    """Element counts of the forward exchange: (per-destination subgrid index lists, in_counts, out_counts); ``key``
+    = the wave key when facets are worked on cooperatively (the senders' item counts depend on the wave)."""
+    F_local = len(sharding.items_of(sharding.rank, key))
     mine = sharding.subgrids_of(n_subgrids)
     dests = [sharding.subgrids_of(n_subgrids, r) for r in range(sharding.world)]
     in_counts = [F_local * len(d) * blk for d in dests]
-    out_counts = [len(sharding.facets_of[r]) * len(mine) * blk for r in range(sharding.world)]
+    out_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
     return dests, in_counts, out_counts
 
 
-def backward_layout(sharding, n_subgrids, blk):
+def backward_layout(sharding, n_subgrids, blk, key=None):
     """Element counts of the backward exchange (subgrid holder -> facet owner)."""
     mine = sharding.subgrids_of(n_subgrids)
-    F_local = len(sharding.local_facets)
-    in_counts = [len(sharding.facets_of[r]) * len(mine) * blk for r in range(sharding.world)]
+    F_local = len(sharding.items_of(sharding.rank, key))
+    in_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
     out_counts = [F_local * len(sharding.subgrids_of(n_subgrids, r)) * blk for r in range(sharding.world)]
     return in_counts, out_counts
 
@@ -190,6 +235,38 @@ def _dist_info(group):
     return 0, 1
 
 
+def _plan_wave_keys(core, plan):
+    """Wave keys (subgrid ``off1``) of a plan in BAND order -- sorted by the position of their column window in the
+    band of the whole plan -- so that contiguous key ranges are contiguous column ranges; ``(keys, band)``."""
+    band = core.band_for_offsets([sg.off1 for sg in plan])
+    yN, m, N = core.yN_size, core.xM_yN_size, core.N
+    keys = sorted({int(sg.off1) for sg in plan}, key=lambda k: (yN // 2 - m // 2 + k * yN // N - band[0]) % yN)
+    return keys, band
+
+
+class _CoopBands:
+    """Column bookkeeping of the cooperative facets of one rank set: the band of the whole plan, the sub-band of every
+    rank's wave range and where it sits inside the parity-split layout of the whole band (swiftly_rowpass.h): a band that
+    starts an even number of columns ``delta`` after the whole band has its even / odd runs at columns ``delta / 2``
+    of the whole band's even / odd runs."""
+
+    def __init__(self, core, sharding, band):
+        self.band = band
+        self.half = core.band_columns(band) // 2
+        self.sub = []  # per rank: (band of its waves or None, half columns, delta / 2, columns copied per run)
+        for r in range(sharding.world):
+            keys = sharding.keys_of[r]
+            if not keys:
+                self.sub.append((None, 0, 0, 0))
+                continue
+            b = core.band_for_offsets(keys)
+            delta = (b[0] - band[0]) % core.yN_size
+            if b == (0, core.yN_size) or delta % 2 or delta + b[1] > band[1]:
+                raise ValueError("internal: the band of a wave range is not a sub-band of the plan's band")
+            h = core.band_columns(b) // 2
+            self.sub.append((b, h, delta // 2, min(h, self.half - delta // 2)))
+
+
 class DistributedForward:
     """Facet-sharded ``SwiftlyForward`` (HIP).  Every rank constructs it with
     the FULL list of facet configs but only the data of its own facets
@@ -201,10 +278,16 @@ class DistributedForward:
     subgrids of the wave directly into the send buffer, the all-to-all moves the
     blocks to the subgrids' owners, and the owners run ``sum_finish_facets`` +
     the axis-0 finish.  ``dtype``: complex dtype of the pass (all ranks must
-    agree; a rank without facets cannot infer it)."""
+    agree; a rank without facets cannot infer it).
+
+    **Facet counts that do not divide by the world size** (r4, band pipeline with a plan): the leftover facets are
+    worked on cooperatively (:class:`FacetSharding`) -- every rank needs the rows ``sharding.coop_rows(size)`` of each
+    of them in ``facet_data[j]`` (the whole facet is accepted too), :py:meth:`prepare_all_facets` runs K1 on them and the
+    band-row exchange, and each wave's K2 / K3 of a cooperative facet runs on the rank that owns the wave.
+    ``cooperative=False`` keeps whole-facet ownership (facet ``j`` on rank ``j % world``)."""
 
     def __init__(self, swiftly_config, facet_configs, facet_data, lru_forward=1, group=None, subgrid_configs=None,
-                 wave_axis=None, dtype=None, rank_world=None):
+                 wave_axis=None, dtype=None, rank_world=None, cooperative=True):
         from .api import SwiftlyForward, preferred_wave_axis  # pylint: disable=import-outside-toplevel
 
         torch = _torch()
@@ -212,26 +295,14 @@ class DistributedForward:
         # rank_world=(rank, world) overrides the process group: "virtual ranks" of one process, used with
         # pack_wave / unpack_wave and a caller-provided exchange (tests of the multi-rank layouts on one GPU)
         self.rank, self.world = rank_world if rank_world is not None else _dist_info(group)
+        self._virtual = rank_world is not None
         self.config = swiftly_config
         self.core = swiftly_config.core
         self.facet_configs = list(facet_configs)
-        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world)
-        local = self.sharding.local_facets
         self.dtype = dtype if dtype is not None else torch.complex64
         if wave_axis is None:
             wave_axis = preferred_wave_axis(swiftly_config, self.dtype, n_facets=len(self.facet_configs))
-        self.local = SwiftlyForward(
-            swiftly_config,
-            [(self.facet_configs[j], facet_data[j]) for j in local],
-            lru_forward=lru_forward,
-            subgrid_configs=subgrid_configs,
-            wave_axis=wave_axis,
-        )
-        if local and self.local.dtype != self.dtype:
-            raise ValueError(f"local facets are {self.local.dtype}, the pass was declared {self.dtype}")
-        self.local.dtype = self.dtype
         self.wave_axis = wave_axis
-        self.arrival_cfgs = [self.facet_configs[j] for j in self.sharding.arrival_order]
         # the receiving side sums over ALL facets of the cover in one kernel (<= MAX_FUSED_FACETS of them)
         self.fused = (
             self.dtype == torch.complex64
@@ -242,11 +313,106 @@ class DistributedForward:
                 f"wave_axis=1 needs the fused subgrid side (complex64, <= {self.core.MAX_FUSED_FACETS} facets in total); "
                 "use wave_axis=0 (preferred_wave_axis(config, dtype, n_facets=...) says which)"
             )
+        keys = None
+        self._plan = list(subgrid_configs) if subgrid_configs is not None else None
+        if (cooperative and self.wave_axis == 1 and self._plan and self.world > 1 and len(self.facet_configs) % self.world
+                and self.core.band_for_offsets([self._plan[0].off1]) != (0, self.core.yN_size)
+                and len({c.size for c in self.facet_configs}) == 1):
+            keys, band = _plan_wave_keys(self.core, self._plan)
+            if band == (0, self.core.yN_size):
+                keys = None  # the plan needs the whole padded axis: no sub-bands to hand out
+        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys)
+        local = self.sharding.local_facets
+        self.local = None
+        if local or not self.sharding.coop:
+            self.local = SwiftlyForward(
+                swiftly_config,
+                [(self.facet_configs[j], facet_data[j]) for j in local],
+                lru_forward=lru_forward,
+                subgrid_configs=subgrid_configs,
+                wave_axis=wave_axis,
+            )
+            if local and self.local.dtype != self.dtype:
+                raise ValueError(f"local facets are {self.local.dtype}, the pass was declared {self.dtype}")
+            self.local.dtype = self.dtype
+        self.arrival_cfgs = [self.facet_configs[j] for j in self.sharding.arrival_order]
+        # cooperative facets: one single-facet SwiftlyForward per facet over the waves this rank owns; its band buffer
+        # is assembled by the band-row exchange of prepare_all_facets instead of its own K1
+        self._coop, self._coop_data, self._coop_bands, self._coop_ready, self._coop_seen = {}, {}, None, False, set()
+        if self.sharding.coop:
+            self._coop_bands = _CoopBands(self.core, self.sharding, band)
+            mine = set(self.sharding.keys_of[self.rank])
+            my_plan = [sg for sg in self._plan if int(sg.off1) in mine]
+            for j in self.sharding.coop:
+                cfg = self.facet_configs[j]
+                self._coop_data[j] = facet_data[j]
+                if my_plan:
+                    ghost = torch.zeros(1, dtype=self.dtype, device=self.core.device).expand(cfg.size, cfg.size)
+                    fwd = SwiftlyForward(swiftly_config, [(cfg, ghost)], lru_forward=lru_forward, subgrid_configs=my_plan,
+                                         wave_axis=1)
+                    fwd.dtype = self.dtype
+                    self._coop[j] = fwd
+
+    # -- cooperative facets: K1 on this rank's rows + the band-row exchange ----------------------------------------
+    def pack_coop(self, j):
+        """K1 of this rank's rows of cooperative facet ``j`` over the band of the whole plan, cut into the column
+        ranges of the ranks' wave ranges: ``(send, in_counts, out_counts)`` -- chunk ``d`` = ``[my rows, band columns
+        of rank d]``, received chunk ``s`` = ``[rows of rank s, my band columns]``."""
+        torch = _torch()
+        core, cb, sh = self.core, self._coop_bands, self.sharding
+        cfg = self.facet_configs[j]
+        yB = cfg.size
+        row0, rows = sh.coop_rows(yB)
+        data = self._coop_data[j]
+        if data is None or tuple(data.shape) not in ((yB, yB), (rows, yB)):
+            raise ValueError(f"rank {self.rank} needs the rows [{row0}, {row0 + rows}) of cooperative facet {j} "
+                             f"(shape ({rows}, {yB})) or the whole facet in facet_data[{j}]")
+        if not isinstance(data, torch.Tensor):
+            data = torch.as_tensor(data)
+        block = data[row0 : row0 + rows] if data.shape[0] == yB and rows != yB else data
+        block = block.to(device=core.device, dtype=self.dtype)
+        in_counts = [rows * 2 * cb.sub[d][1] for d in range(self.world)]
+        out_counts = [sh.coop_rows(yB, s)[1] * 2 * cb.sub[self.rank][1] for s in range(self.world)]
+        send = torch.empty(sum(in_counts), dtype=self.dtype, device=core.device)
+        if rows:
+            part = core.prepare_facet_band(block, cfg.off1, cb.band, rows_of=(yB, row0))  # [rows, 2 * half]
+            pos = 0
+            for d in range(self.world):
+                _, h, d2, w = cb.sub[d]
+                if h:
+                    chunk = send[pos : pos + rows * 2 * h].view(rows, 2 * h)
+                    chunk[:, :w].copy_(part[:, d2 : d2 + w])
+                    chunk[:, h : h + w].copy_(part[:, cb.half + d2 : cb.half + d2 + w])
+                pos += rows * 2 * h
+        return send, in_counts, out_counts
+
+    def unpack_coop(self, j, recv):
+        """hand the assembled band buffer ``[facet rows, my band columns]`` (received chunks in rank order = row
+        order) to the cooperative facet's forward object"""
+        self._coop_seen.add(j)
+        self._coop_ready = self._coop_seen >= set(self.sharding.coop)
+        if j not in self._coop:
+            return
+        b, h, _, _ = self._coop_bands.sub[self.rank]
+        fwd = self._coop[j]
+        yB = self.facet_configs[j].size
+        fwd.BF_Fs_persist = recv.view(1, yB, 2 * h)
+        fwd._band = b  # pylint: disable=protected-access
 
     def prepare_all_facets(self):
-        """K1 for the local facets"""
-        if self.sharding.local_facets:
+        """K1 for the local facets; cooperative facets: K1 on this rank's rows and the exchange of the band rows"""
+        if self.local is not None and self.sharding.local_facets:
             self.local.prepare_all_facets()
+        if self.sharding.coop and not self._coop_ready and not self._virtual:
+            # (virtual ranks of one process: the caller moves the buffers of pack_coop / unpack_coop itself)
+            for j in self.sharding.coop:
+                send, in_counts, out_counts = self.pack_coop(j)
+                self.unpack_coop(j, exchange_blocks(send, in_counts, out_counts, self.group).wait())
+
+    def _arrival_cfgs(self, key):
+        if not self.sharding.coop:
+            return self.arrival_cfgs
+        return [self.facet_configs[j] for j in self.sharding.arrival(key)]
 
     def pack_wave(self, sgs):
         """Compute this rank's blocks for the subgrids ``sgs`` (one wave: same wave key and size) straight into
@@ -254,10 +420,12 @@ class DistributedForward:
         torch = _torch()
         core = self.core
         m = core.xM_yN_size
-        dests, in_counts, out_counts = forward_layout(self.sharding, len(sgs), m * m)
-        F_local = len(self.sharding.local_facets)
+        key = int(sgs[0].off1) if self.sharding.coop else None
+        dests, in_counts, out_counts = forward_layout(self.sharding, len(sgs), m * m, key)
+        F_whole = len(self.sharding.local_facets)
+        items = self.sharding.items_of(self.rank, key)
         send = torch.empty(sum(in_counts), dtype=self.dtype, device=core.device)
-        if self.fused and self.wave_axis == 1 and F_local:
+        if self.fused and self.wave_axis == 1 and items:
             # one native call for the whole wave: block (f, i) of subgrid i = dests[d][k] goes to
             # chunk_base[d] + f * len(dests[d]) * m^2 + k * m^2
             offs, fstr = [0] * len(sgs), [0] * len(sgs)
@@ -267,12 +435,18 @@ class DistributedForward:
                     offs[i] = base + k * m * m
                     fstr[i] = len(d) * m * m
                 base += cnt
-            self.local.wave_blocks_into(sgs, send, (offs, fstr))
+            if F_whole:
+                self.local.wave_blocks_into(sgs, send, (offs, fstr))
+            for n, j in enumerate(items[F_whole:]):  # cooperative facets this rank owns for this wave: items F_whole + n
+                if not self._coop_ready:
+                    raise RuntimeError("prepare_all_facets() (the band-row exchange) must run before the first wave")
+                shifted = [o + (F_whole + n) * f for o, f in zip(offs, fstr)]
+                self._coop[j].wave_blocks_into(sgs, send, (shifted, fstr))
             return send, in_counts, out_counts
         pos = 0
         for d, cnt in zip(dests, in_counts):
             if cnt:
-                block = send[pos : pos + cnt].view(F_local, len(d), m, m)
+                block = send[pos : pos + cnt].view(F_whole, len(d), m, m)
                 self.local.wave_blocks([sgs[i] for i in d], block, transformed=self.fused)
             pos += cnt
         return send, in_counts, out_counts
@@ -286,8 +460,9 @@ class DistributedForward:
         if not mine:
             return mine, None
         m = self.core.xM_yN_size
-        blocks = recv.view(len(self.facet_configs), len(mine), m, m)  # facets in arrival order
-        res = finish_from_blocks(self.core, blocks, self.arrival_cfgs, [sgs[i] for i in mine], transformed=self.fused)
+        cfgs = self._arrival_cfgs(int(sgs[0].off1))
+        blocks = recv.view(len(cfgs), len(mine), m, m)  # facets in arrival order
+        res = finish_from_blocks(self.core, blocks, cfgs, [sgs[i] for i in mine], transformed=self.fused)
         return mine, res
 
     def start_wave(self, sgs):
@@ -320,14 +495,22 @@ class DistributedBackward:
 
     At most ``MAX_IN_FLIGHT`` waves may be started and not yet finished: the send buffer of the fused route is
     one of two alternating workspaces, so :py:meth:`start_wave` makes the compute stream wait for the exchange
-    that last read the slot it is about to overwrite."""
+    that last read the slot it is about to overwrite.
+
+    **Cooperative facets** (r4; band schedule with a plan, facet count not a multiple of the world size; mirror of
+    :class:`DistributedForward`): the contributions of wave ``key`` to a leftover facet go to ``key_owner[key]``, which
+    accumulates them into a band accumulator over the columns of ITS waves; :py:meth:`finish` zero-fills the untouched
+    columns, moves row blocks to the ranks that own them (one all-to-all: column ranges out, row blocks in, overlapping
+    columns of neighbouring ranges added) and runs the contiguous-axis ``finish_facet`` on this rank's rows.  The pieces
+    are in ``coop_pieces`` = ``[(facet index, row0, tensor [rows, size])]`` after :py:meth:`finish`."""
 
     MAX_IN_FLIGHT = 2
 
     # pylint: disable=too-many-arguments
     def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None, rank_world=None, wave_axis=0,
-                 subgrid_configs=None, dtype=None):
+                 subgrid_configs=None, dtype=None, cooperative=True):
         from .api import SwiftlyBackward  # pylint: disable=import-outside-toplevel
+        from .core_hip import band_range  # pylint: disable=import-outside-toplevel
 
         torch = _torch()
         self.dtype = dtype if dtype is not None else torch.complex64
@@ -337,20 +520,54 @@ class DistributedBackward:
         self.group = group
         self.wave_axis = int(wave_axis)
         self.rank, self.world = rank_world if rank_world is not None else _dist_info(group)
+        self._virtual = rank_world is not None
         self.config = swiftly_config
-        self.core = swiftly_config.core
+        self.core = core = swiftly_config.core
         self.facet_configs = list(facet_configs)
-        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world)
+        plan = list(subgrid_configs) if subgrid_configs is not None else None
+        keys = None
+        if (cooperative and self.wave_axis == 1 and plan and self.world > 1 and len(self.facet_configs) % self.world
+                and self.dtype == torch.complex64 and core.band_for_offsets([plan[0].off1]) != (0, core.yN_size)
+                and len({c.size for c in self.facet_configs}) == 1):
+            keys, band = _plan_wave_keys(core, plan)  # the same wave ranges as DistributedForward
+            if band == (0, core.yN_size):
+                keys = None
+        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys)
+        sh = self.sharding
         # facet owner side: accumulators of the local facets
-        self.local = SwiftlyBackward(
-            swiftly_config, [self.facet_configs[j] for j in self.sharding.local_facets], lru_backward=lru_backward,
-            wave_axis=self.wave_axis, subgrid_configs=subgrid_configs,
-        )
-        # subgrid holder side: contributions to ALL facets, owner-major order
+        self.local = None
+        if sh.local_facets or not sh.coop:
+            self.local = SwiftlyBackward(
+                swiftly_config, [self.facet_configs[j] for j in sh.local_facets], lru_backward=lru_backward,
+                wave_axis=self.wave_axis, subgrid_configs=subgrid_configs,
+            )
+            self.local.dtype = self.dtype
+        # subgrid holder side: contributions to ALL facets, owner-major order (cooperative facets last)
+        self._base_order = sh.arrival_order + sh.coop
         self.splitter = SwiftlyBackward(
-            swiftly_config, [self.facet_configs[j] for j in self.sharding.arrival_order], lru_backward=1
+            swiftly_config, [self.facet_configs[j] for j in self._base_order], lru_backward=1
         )
-        self.local.dtype = self.splitter.dtype = self.dtype
+        self.splitter.dtype = self.dtype
+        self._coop, self.coop_pieces = {}, []
+        self._coop_band = None
+        if sh.coop:
+            N, yN, m = core.N, core.yN_size, core.xM_yN_size
+            self._coop_band = band_range(N, yN, m, [sg.off1 for sg in plan])  # plain column order (backward layout)
+            self._coop_sub = []  # per rank: (first column inside the whole band, columns)
+            for r in range(self.world):
+                if sh.keys_of[r]:
+                    b = band_range(N, yN, m, sh.keys_of[r])
+                    self._coop_sub.append(((b[0] - self._coop_band[0]) % yN, b[1]))
+                else:
+                    self._coop_sub.append((0, 0))
+            mine = set(sh.keys_of[self.rank])
+            my_plan = [sg for sg in plan if int(sg.off1) in mine]
+            if my_plan:
+                for j in sh.coop:
+                    cb = SwiftlyBackward(swiftly_config, [self.facet_configs[j]], lru_backward=lru_backward, wave_axis=1,
+                                         subgrid_configs=my_plan)
+                    cb.dtype = self.dtype
+                    self._coop[j] = cb
 
     def pack_wave(self, sgs, subgrids_mine):
         """``sgs``: all subgrid configs of the wave (same size and same ``off0`` -- ``off1`` with ``wave_axis=1``,
@@ -363,14 +580,22 @@ class DistributedBackward:
         core = self.core
         m = core.xM_yN_size
         S = len(sgs)
-        mine = self.sharding.subgrids_of(S)
+        sh = self.sharding
+        mine = sh.subgrids_of(S)
         if len(subgrids_mine) != len(mine):
             raise ValueError(f"rank {self.rank} holds {len(mine)} subgrids of this wave, got {len(subgrids_mine)}")
-        in_counts, out_counts = backward_layout(self.sharding, S, m * m)
+        key = int(sgs[0].off1) if sh.coop else None
+        in_counts, out_counts = backward_layout(sh, S, m * m, key)
         if mine:
-            send = self.splitter.wave_contributions([sgs[i] for i in mine], subgrids_mine).reshape(-1)
-            if send.dtype != self.dtype:
-                raise ValueError(f"subgrids are {send.dtype}, the pass was declared {self.dtype}")
+            parts = self.splitter.wave_contributions([sgs[i] for i in mine], subgrids_mine)
+            if parts.dtype != self.dtype:
+                raise ValueError(f"subgrids are {parts.dtype}, the pass was declared {self.dtype}")
+            order = sh.arrival(key)
+            if order != self._base_order:
+                # the cooperative facets' blocks go to the rank that owns this wave: one gather of the [m, m] blocks
+                perm = torch.as_tensor([self._base_order.index(j) for j in order], device=parts.device)
+                parts = parts.index_select(0, perm)
+            send = parts.reshape(-1)
         else:
             send = torch.empty(0, dtype=self.dtype, device=core.device)
         return send, in_counts, out_counts
@@ -378,20 +603,28 @@ class DistributedBackward:
     def unpack_wave(self, sgs, recv):
         """Accumulate the received contributions (one chunk ``[my facet][subgrid of source][m, m]`` per source
         rank) into this rank's facets."""
-        F_local = len(self.sharding.local_facets)
+        sh = self.sharding
+        key = int(sgs[0].off1) if sh.coop else None
+        items = sh.items_of(self.rank, key)
+        F_local = len(items)
         if not F_local:
             return
+        F_whole = len(sh.local_facets)
         m = self.core.xM_yN_size
         S = len(sgs)
         chunks = []
         pos = 0
         for r in range(self.world):
-            idx = self.sharding.subgrids_of(S, r)
+            idx = sh.subgrids_of(S, r)
             cnt = F_local * len(idx) * m * m
             if cnt:
                 chunks.append(([sgs[i] for i in idx], recv[pos : pos + cnt].view(F_local, len(idx), m, m)))
             pos += cnt
-        self.local.accumulate_chunks(sgs[0].off1 if self.wave_axis == 1 else sgs[0].off0, chunks)
+        wave_key = sgs[0].off1 if self.wave_axis == 1 else sgs[0].off0
+        if F_whole:
+            self.local.accumulate_chunks(wave_key, [(c, t[:F_whole]) for c, t in chunks])
+        for n, j in enumerate(items[F_whole:]):
+            self._coop[j].accumulate_chunks(wave_key, [(c, t[F_whole + n : F_whole + n + 1]) for c, t in chunks])
 
     def start_wave(self, sgs, subgrids_mine):
         """:py:meth:`pack_wave` + start of the mirror all-to-all; returns a handle for :py:meth:`finish_wave`."""
@@ -414,6 +647,58 @@ class DistributedBackward:
         """start_wave + finish_wave"""
         self.finish_wave(self.start_wave(sgs, subgrids_mine))
 
+    # -- cooperative facets: column ranges out, row blocks in, contiguous-axis finish on this rank's rows -------------
+    def pack_coop_finish(self, j):
+        """``(send, in_counts, out_counts)`` of the finishing exchange of cooperative facet ``j``: this rank's band
+        accumulator ``[facet rows, my columns]`` (untouched columns zero-filled) IS the send buffer -- the row blocks
+        of the ranks are consecutive -- and rank ``s`` sends ``[my rows, columns of s]``."""
+        torch = _torch()
+        core, sh = self.core, self.sharding
+        yB = self.facet_configs[j].size
+        ncol = self._coop_sub[self.rank][1]
+        cb = self._coop.get(j)
+        if ncol == 0:
+            acc = torch.empty(0, dtype=self.dtype, device=core.device)
+        elif cb is None or cb._bands is None:  # pylint: disable=protected-access
+            acc = torch.zeros((yB, ncol), dtype=self.dtype, device=core.device)
+        else:
+            core.band_zero_untouched(cb._bands, cb._touched)  # pylint: disable=protected-access
+            acc = cb._bands[0]  # pylint: disable=protected-access
+            if tuple(acc.shape) != (yB, ncol):
+                raise ValueError("internal: cooperative accumulator does not match the wave range's band")
+        in_counts = [sh.coop_rows(yB, d)[1] * ncol for d in range(self.world)]
+        rows = sh.coop_rows(yB)[1]
+        out_counts = [rows * self._coop_sub[s][1] for s in range(self.world)]
+        return acc.reshape(-1), in_counts, out_counts
+
+    def unpack_coop_finish(self, j, recv):
+        """assemble ``[my rows, band]`` from the received column ranges (overlaps of neighbouring ranges ADD) and finish
+        the rows along the contiguous axis: ``(facet index, row0, tensor [rows, size])``"""
+        torch = _torch()
+        core, sh = self.core, self.sharding
+        cfg = self.facet_configs[j]
+        row0, rows = sh.coop_rows(cfg.size)
+        if rows == 0:
+            return (j, row0, torch.empty((0, cfg.size), dtype=self.dtype, device=core.device))
+        buf = torch.zeros((rows, self._coop_band[1]), dtype=self.dtype, device=core.device)
+        pos = 0
+        for s in range(self.world):
+            c0, n = self._coop_sub[s]
+            if n:
+                buf[:, c0 : c0 + n] += recv[pos : pos + rows * n].view(rows, n)
+            pos += rows * n
+        out = core.finish_facet_band(buf, self._coop_band, cfg.off1, cfg.size, mask=cfg.mask1)
+        return (j, row0, out)
+
     def finish(self):
-        """Finished facets of this rank: ``(global facet indices, list of tensors)``."""
-        return self.sharding.local_facets, (self.local.finish() if self.sharding.local_facets else [])
+        """Finished facets of this rank: ``(global facet indices, list of tensors)``; the rows of cooperative facets
+        this rank finished are in ``coop_pieces`` (virtual ranks: the caller moves the buffers of pack_coop_finish /
+        unpack_coop_finish itself)."""
+        sh = self.sharding
+        if sh.coop and not self._virtual:
+            self.coop_pieces = []
+            for j in sh.coop:
+                send, in_counts, out_counts = self.pack_coop_finish(j)
+                recv = exchange_blocks(send, in_counts, out_counts, self.group).wait()
+                self.coop_pieces.append(self.unpack_coop_finish(j, recv))
+        return sh.local_facets, (self.local.finish() if sh.local_facets else [])

@@ -101,9 +101,72 @@ def main():
     for j, o in zip(idx, out):
         assert o.dtype == torch.complex128
         assert float((o - ref[j]).abs().max()) <= 1e-10 * float(ref[j].abs().max()), (rank, "c128", j)
+    cooperative_section(rank, world)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}/{world}: ok", flush=True)
+
+
+def cooperative_section(rank, world):
+    """Cooperative facets (r4) through the real process group: a facet count that does not divide by the world size at
+    yN = 32768 (split band layout), band pipelines with a plan -- K1 on row blocks, the band-row exchange, per-wave
+    ownership of the leftover facet, the finishing exchange of the backward pass -- against the single-process classes."""
+    import torch
+    import torch.distributed as dist
+
+    import ska_sdp_exec_swiftly_amd as sw
+    from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
+
+    yB, xA = 352, 928
+    P = dict(W=10.875, fov=1.0, N=65536, yB_size=yB, yN_size=32768, xA_size=xA, xM_size=1024)
+    cfg = sw.SwiftlyConfig(backend="hip", **P)
+    if not cfg.core.supports_band_pipeline(torch.complex64):
+        return
+    fstep = cfg.facet_off_step
+    offs = [(0, 0), (0, 50 * fstep), (-70 * fstep, 0), (40 * fstep, -30 * fstep)][: (3 if world == 2 else 4)]
+    facet_cfgs = [sw.FacetConfig(o0, o1, yB) for o0, o1 in offs]
+    assert len(facet_cfgs) % world
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    facets = [torch.randn((yB, yB), dtype=torch.complex64, generator=gen).cuda() for _ in facet_cfgs]
+    sg_cfgs = [sw.SubgridConfig(i0 * xA, i1 * xA, xA) for i0 in (0, 2, 69) for i1 in (0, 3, 4, 70)]
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off1, []).append(c)
+    dfw = DistributedForward(cfg, facet_cfgs, facets, subgrid_configs=sg_cfgs, wave_axis=1, dtype=torch.complex64)
+    sh = dfw.sharding
+    assert sh.coop == list(range((len(facet_cfgs) // world) * world, len(facet_cfgs)))
+    dfw.prepare_all_facets()
+    ref = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
+    full = {}
+    pending = None
+    for wave in list(waves.values()) + [None]:
+        handle = dfw.start_wave(wave) if wave is not None else None
+        if pending is not None:
+            mine, res = dfw.finish_wave(pending)
+            want = ref.get_wave(pending[0])
+            for k, i in enumerate(mine or []):
+                assert float((res[k] - want[i]).abs().max()) <= 2e-5 * float(want.abs().max()), (rank, "coop fwd", i)
+            for i, c in enumerate(pending[0]):
+                full[(c.off0, c.off1)] = want[i]
+        pending = handle
+    dbw = DistributedBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs, dtype=torch.complex64)
+    rb = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs)
+    for wave in waves.values():
+        mine = dbw.sharding.subgrids_of(len(wave))
+        dbw.add_wave(wave, [full[(wave[i].off0, wave[i].off1)] for i in mine])
+        rb.add_new_subgrid_tasks(wave, [full[(c.off0, c.off1)] for c in wave])
+    idx, out = dbw.finish()
+    want = rb.finish()
+    for j, o in zip(idx, out):
+        rms = float(want[j].abs().pow(2).mean().sqrt())
+        assert float((o - want[j]).abs().pow(2).mean().sqrt()) <= 3e-6 * rms, (rank, "coop bwd whole", j)
+    assert sorted(p[0] for p in dbw.coop_pieces) == sh.coop
+    for j, row0, piece in dbw.coop_pieces:
+        w = want[j][row0 : row0 + piece.shape[0]]
+        assert piece.shape[0] == sh.coop_rows(yB)[1]
+        rms = float(want[j].abs().pow(2).mean().sqrt())
+        assert float((piece - w).abs().pow(2).mean().sqrt()) <= 3e-6 * rms, (rank, "coop bwd piece", j)
+    dist.barrier()
 
 
 if __name__ == "__main__":

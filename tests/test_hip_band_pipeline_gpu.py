@@ -390,3 +390,103 @@ def test_backward_axis_is_fixed_by_the_first_entry_point():
     b128 = sw.SwiftlyBackward(cfg, facet_cfgs, subgrid_configs=sg_cfgs)
     b128.wave_contributions([sg_cfgs[0]], [data[0].to(torch.complex128)])
     assert b128.wave_axis == 0
+
+
+def _virtual_all_to_all(sends, in_counts):
+    """In-process stand-in for all_to_all_single: rank r receives, from every source s in order, the chunk s sent
+    to r (``sends[s]`` flat buffers, ``in_counts[s][r]`` elements)."""
+    import torch
+
+    world = len(sends)
+    starts = [numpy.concatenate([[0], numpy.cumsum(c)]) for c in in_counts]
+    return [
+        torch.cat([sends[s][int(starts[s][r]) : int(starts[s][r + 1])] for s in range(world)]) for r in range(world)
+    ]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_cooperative_facets_virtual_ranks(world):
+    """Facet counts that do not divide by the world size (r4): 3 facets on 2 ranks (one whole facet each + facet 2
+    worked on by both) and on 8 ranks (all three cooperative).  Virtual ranks in one process, the three exchanges
+    (band rows, forward blocks per wave, backward blocks per wave, finishing rows) replaced by in-process shuffles of
+    the flat buffers; results against the single-process classes: the same kernels on the same numbers -- only the
+    order of the facet sums (arrival order) and of the column overlaps differs."""
+    import torch
+
+    from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
+
+    torch_, sw, cfg, facet_cfgs, facets, sg_cfgs = _small_rows_problem()
+    if not cfg.core.supports_band_pipeline(torch.complex64) or not cfg.core.supports_backward_band(torch.complex64):
+        pytest.skip("band pipelines not available")
+    ref = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
+    fwds = [DistributedForward(cfg, facet_cfgs, facets, subgrid_configs=sg_cfgs, wave_axis=1, dtype=torch.complex64,
+                               rank_world=(r, world)) for r in range(world)]
+    sh = fwds[0].sharding
+    assert sh.coop == ([2] if world == 2 else [0, 1, 2])
+    assert sorted(k for r in range(world) for k in sh.keys_of[r]) == sorted({c.off1 for c in sg_cfgs})
+    yB = facet_cfgs[0].size
+    assert sum(sh.coop_rows(yB, r)[1] for r in range(world)) == yB
+    for f in fwds:
+        f.prepare_all_facets()
+    for j in sh.coop:
+        packed = [f.pack_coop(j) for f in fwds]
+        recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+        for r, f in enumerate(fwds):
+            assert recvs[r].numel() == sum(packed[r][2])
+            f.unpack_coop(j, recvs[r])
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off1, []).append(c)
+    full = {}
+    for key, wave in waves.items():
+        want = ref.get_wave(wave)
+        packed = [f.pack_wave(wave) for f in fwds]
+        # the cooperative facets' blocks come from the rank that owns the wave
+        owner = sh.key_owner[int(key)]
+        assert [len(sh.items_of(r, key)) for r in range(world)] == [
+            len(sh.facets_of[r]) + (len(sh.coop) if r == owner else 0) for r in range(world)]
+        recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+        got = {}
+        for r, f in enumerate(fwds):
+            assert recvs[r].numel() == sum(packed[r][2])
+            mine, res = f.unpack_wave(wave, recvs[r])
+            for k, i in enumerate(mine):
+                got[i] = res[k]
+        assert sorted(got) == list(range(len(wave)))
+        scale = float(want.abs().max())
+        for i, c in enumerate(wave):
+            assert float((got[i] - want[i]).abs().max()) <= 2e-5 * scale, (key, i)
+            full[(c.off0, c.off1)] = want[i]
+    # backward, band schedule, the same wave ranges
+    rb = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs)
+    bwds = [DistributedBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs, dtype=torch.complex64,
+                                rank_world=(r, world)) for r in range(world)]
+    assert bwds[0].sharding.coop == sh.coop
+    for key, wave in waves.items():
+        data = [full[(c.off0, c.off1)] for c in wave]
+        rb.add_new_subgrid_tasks(wave, data)
+        packed = [b.pack_wave(wave, [data[i] for i in b.sharding.subgrids_of(len(wave))]) for b in bwds]
+        recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+        for r, b in enumerate(bwds):
+            assert recvs[r].numel() == sum(packed[r][2])
+            b.unpack_wave(wave, recvs[r])
+    want = rb.finish()
+    done = {}
+    for b in bwds:
+        idx, out = b.finish()
+        for j, o in zip(idx, out):
+            done[j] = o
+    for j in sh.coop:
+        packed = [b.pack_coop_finish(j) for b in bwds]
+        recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+        rows = []
+        for r, b in enumerate(bwds):
+            assert recvs[r].numel() == sum(packed[r][2])
+            jj, row0, piece = b.unpack_coop_finish(j, recvs[r])
+            assert jj == j and row0 == sh.coop_rows(yB, r)[0]
+            rows.append(piece)
+        done[j] = torch.cat(rows)
+    assert sorted(done) == list(range(len(facet_cfgs)))
+    for j, w in enumerate(want):
+        assert done[j].shape == w.shape
+        assert float((done[j] - w).abs().pow(2).mean().sqrt()) <= 3e-6 * float(w.abs().pow(2).mean().sqrt()), j
