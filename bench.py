@@ -586,7 +586,10 @@ def main():
     local = [j for j in range(F) if j % world == rank]
     vectors = [sep.facet_vectors(1234 + j, p["yB_size"], rank=2) for j in range(F)]
     facet_data = [None] * F
-    for j in local:
+    # facets that do not fill a round of ranks are worked on by all ranks (distributed.FacetSharding, band pipeline):
+    # every rank then needs its rows of them -- the synthetic facet is simply built everywhere
+    shared = list(range((F // world) * world, F)) if world > 1 and wave_axis == 1 else []
+    for j in sorted(set(local) | set(shared)):
         facet_data[j] = separable_facet(torch, vectors[j], facet_cfgs[j])
 
     picks = sep.pick_subgrids(sg_cfgs, 6) if not args.no_verify else []
@@ -943,7 +946,8 @@ def main():
             contributions=F * S, params=p,
             wave_axis=wave_axis,
             facet_data="separable rank-2 dense random (1/8 grid), seed 1234+j, times cover masks",
-            parallelism=f"facets sharded over {world} rank(s), contribution all-to-all" if world > 1 else "1 GPU",
+            parallelism=(f"facets sharded over {world} rank(s) (facets beyond a full round worked on cooperatively: K1 by "
+                         f"row blocks, K2/K3 by wave ranges), contribution all-to-all per wave") if world > 1 else "1 GPU",
         ),
         hbm_algorithmic_gbs=round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
         hbm_algorithmic_frac_of_peak=round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4),

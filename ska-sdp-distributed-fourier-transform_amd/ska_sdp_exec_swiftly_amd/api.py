@@ -920,7 +920,9 @@ class SwiftlyForward:
 
     def _check_planned(self, sgs):
         if self._plan is not None:
-            allowed = self.__dict__.setdefault("_plan_set", {(int(sg.off0), int(sg.off1)) for sg in self._plan})
+            allowed = self.__dict__.get("_plan_set")
+            if allowed is None:  # (built once: a set comprehension as a setdefault argument would run on every call)
+                allowed = self.__dict__["_plan_set"] = {(int(sg.off0), int(sg.off1)) for sg in self._plan}
             if any((int(sg.off0), int(sg.off1)) not in allowed for sg in sgs):
                 raise ValueError("subgrid was not in the subgrid_configs plan")
 

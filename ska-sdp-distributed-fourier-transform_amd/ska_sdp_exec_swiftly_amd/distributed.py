@@ -548,6 +548,7 @@ class DistributedBackward:
             swiftly_config, [self.facet_configs[j] for j in self._base_order], lru_backward=1
         )
         self.splitter.dtype = self.dtype
+        self._splitters = {tuple(self._base_order): self.splitter}
         self._coop, self.coop_pieces = {}, []
         self._coop_band = None
         if sh.coop:
@@ -587,14 +588,19 @@ class DistributedBackward:
         key = int(sgs[0].off1) if sh.coop else None
         in_counts, out_counts = backward_layout(sh, S, m * m, key)
         if mine:
-            parts = self.splitter.wave_contributions([sgs[i] for i in mine], subgrids_mine)
+            # the contributions come out in the facet order of the splitter = the arrival order of this wave: with
+            # cooperative facets that order depends on the rank that owns the wave, so there is one splitter per owner
+            order = tuple(sh.arrival(key))
+            splitter = self._splitters.get(order)
+            if splitter is None:
+                from .api import SwiftlyBackward  # pylint: disable=import-outside-toplevel
+
+                splitter = self._splitters[order] = SwiftlyBackward(
+                    self.config, [self.facet_configs[j] for j in order], lru_backward=1)
+                splitter.dtype = self.dtype
+            parts = splitter.wave_contributions([sgs[i] for i in mine], subgrids_mine)
             if parts.dtype != self.dtype:
                 raise ValueError(f"subgrids are {parts.dtype}, the pass was declared {self.dtype}")
-            order = sh.arrival(key)
-            if order != self._base_order:
-                # the cooperative facets' blocks go to the rank that owns this wave: one gather of the [m, m] blocks
-                perm = torch.as_tensor([self._base_order.index(j) for j in order], device=parts.device)
-                parts = parts.index_select(0, perm)
             send = parts.reshape(-1)
         else:
             send = torch.empty(0, dtype=self.dtype, device=core.device)

@@ -35,6 +35,9 @@ def one_pass():
     dfw = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64, rank_world=(rank, world))
     t0 = time.perf_counter()
     dfw.prepare_all_facets()
+    for j in dfw.sharding.coop:  # cooperative facets: K1 on this rank's rows + (dummy) band-row exchange
+        send, inc, outc = dfw.pack_coop(j)
+        dfw.unpack_coop(j, torch.empty(sum(outc), dtype=torch.complex64, device="cuda"))
     t1 = time.perf_counter()
     tp = tu = 0.0
     for wave in waves:
@@ -57,3 +60,13 @@ torch.cuda.synchronize()
 for _ in range(3):
     k1, tp, tu, host, total = one_pass()
     print(f"{name} world {world} rank {rank}: host enqueue {host:.2f} ms (K1 {k1:.2f}, pack {tp:.2f}, unpack {tu:.2f}) of {total:.2f} ms total, {len(waves)} waves")
+
+if os.environ.get("VR_PROFILE") == "1":
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    one_pass()
+    pr.disable()
+    pstats.Stats(pr).strip_dirs().sort_stats("tottime").print_stats(28)

@@ -50,7 +50,8 @@ def main():
             scale = len(waves) / max_waves
             waves = waves[:max_waves]
         data = [one] * len(fcs)  # timing only: every facet holds the same numbers
-        ranks = sorted({0, 1, world - 1} & set(range(world)))  # rank 0 carries the extra facet when F % world != 0
+        # every rank when facets are worked on cooperatively (the wave ranges differ by one wave), else the extremes
+        ranks = list(range(world)) if len(fcs) % world else sorted({0, 1, world - 1} & set(range(world)))
         ent = dict(facets=len(fcs), wave_axis=axis, waves_timed=len(waves), wave_scale=scale, ranks={})
         for rank in ranks:
             sent = [0]
@@ -60,6 +61,10 @@ def main():
                                          rank_world=(rank, world))
                 dfw.prepare_all_facets()
                 sent[0] = 0
+                for j in dfw.sharding.coop:  # cooperative facets: K1 on this rank's rows + (dummy) band-row exchange
+                    send, inc, outc = dfw.pack_coop(j)
+                    sent[0] += 8 * (sum(inc) - inc[rank])
+                    dfw.unpack_coop(j, torch.empty(sum(outc), dtype=torch.complex64, device="cuda"))
                 for wave in waves:
                     send, inc, outc = dfw.pack_wave(wave)
                     sent[0] += 8 * (sum(inc) - inc[rank])
@@ -75,7 +80,11 @@ def main():
                     if world > 1:
                         recv.zero_()
                     dbw.unpack_wave(wave, recv)
-                return dbw.finish()
+                out = dbw.finish()
+                for j in dbw.sharding.coop:  # finishing exchange of the cooperative facets (dummy receive buffer)
+                    send, inc, outc = dbw.pack_coop_finish(j)
+                    dbw.unpack_coop_finish(j, torch.zeros(sum(outc), dtype=torch.complex64, device="cuda"))
+                return out
 
             def timed(fn, reps=2):
                 fn()
