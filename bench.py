@@ -511,6 +511,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="64k-sparse", choices=sorted(WORKLOADS))  # default: BASELINE.json's metric config
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="group", choices=["group", "wave"],
+                    help="multi-GPU: 'group' (default) = every wave's subgrids are finished by ONE rank and the waves are "
+                         "exchanged in groups of n_gpus waves with distinct owners (one balanced all-to-all per group); "
+                         "'wave' = the subgrids of every wave dealt out round-robin, one all-to-all per wave")
     ap.add_argument("--column-precision", type=int, default=32, choices=[32, 64],
                     help="arithmetic of the column passes K2 / K3 (complex64 data): 32 = float32 (default, the timed "
                          "configuration of every round), 64 = float64 butterflies (3.7x smaller error, 1.5x the time)")
@@ -622,12 +626,39 @@ def main():
 
     else:
 
+        grouped = args.exchange == "group" and wave_axis == 1 and world > 1
+        index_of = {(c.off0, c.off1): i for i, c in enumerate(sg_cfgs)}
+
         def one_pass(timer=None, keep=None):  # pylint: disable=unused-argument
             dfw = DistributedForward(
                 cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs, wave_axis=wave_axis,
-                dtype=torch.complex64,
+                dtype=torch.complex64, whole_waves=grouped,
             )
             dfw.prepare_all_facets()
+            if grouped:
+                # whole waves per rank, one all-to-all per group of `world` waves; the exchange of group g runs while
+                # the facet side of group g+1 is computed
+                by_key = {dfw.wave_key(w): w for w in waves}
+                n = 0
+                pending = None
+
+                def finish_group(h):
+                    sgs, res = dfw.finish_group(h)
+                    if sgs is None:
+                        return 0
+                    if keep is not None:
+                        for k, c in enumerate(sgs):
+                            if index_of[(c.off0, c.off1)] in picks:
+                                keep[index_of[(c.off0, c.off1)]] = res[k].cpu().numpy()
+                    return len(sgs)
+
+                for group in dfw.sharding.wave_groups:
+                    handle = dfw.start_group([by_key[k] for k in group])
+                    if pending is not None:
+                        n += finish_group(pending)
+                    pending = handle
+                n += finish_group(pending)
+                return n
             # software pipeline: the all-to-all of wave w runs while wave w+1's column/extract kernels do
             n = 0
             pending = None
@@ -878,10 +909,26 @@ def main():
                     del fwd
                     return bwd.finish()
                 dfw = DistributedForward(cfg, facet_cfgs, facet_data, lru_forward=1, subgrid_configs=sg_cfgs,
-                                         wave_axis=wave_axis, dtype=torch.complex64)
-                dbw = DistributedBackward(cfg, facet_cfgs, wave_axis=baxis, subgrid_configs=sg_cfgs, dtype=torch.complex64)
+                                         wave_axis=wave_axis, dtype=torch.complex64, whole_waves=grouped)
+                dbw = DistributedBackward(cfg, facet_cfgs, wave_axis=baxis, subgrid_configs=sg_cfgs, dtype=torch.complex64,
+                                          whole_waves=grouped)
                 dfw.prepare_all_facets()
                 pend_f = pend_b = None
+                if grouped:
+                    by_key = {dfw.wave_key(w): w for w in waves}
+                    for group in dfw.sharding.wave_groups + [None]:
+                        gw = [by_key[k] for k in group] if group is not None else None
+                        hf = (gw, dfw.start_group(gw)) if gw is not None else None
+                        if pend_f is not None:
+                            sgs, res = dfw.finish_group(pend_f[1])
+                            hb = dbw.start_group(pend_f[0], [res[k] for k in range(len(sgs))] if sgs is not None else [])
+                            if pend_b is not None:
+                                dbw.finish_group(pend_b)
+                            pend_b = hb
+                        pend_f = hf
+                    dbw.finish_group(pend_b)
+                    del dfw
+                    return dbw.finish()[1]
                 for wave in waves + [None]:
                     hf = (wave, dfw.start_wave(wave)) if wave is not None else None
                     if pend_f is not None:
@@ -947,7 +994,9 @@ def main():
             wave_axis=wave_axis,
             facet_data="separable rank-2 dense random (1/8 grid), seed 1234+j, times cover masks",
             parallelism=(f"facets sharded over {world} rank(s) (facets beyond a full round worked on cooperatively: K1 by "
-                         f"row blocks, K2/K3 by wave ranges), contribution all-to-all per wave") if world > 1 else "1 GPU",
+                         f"row blocks, K2/K3 by wave ranges), contribution all-to-all per "
+                         + ("group of waves with distinct owners" if args.exchange == "group" and wave_axis == 1 else "wave"))
+            if world > 1 else "1 GPU",
         ),
         hbm_algorithmic_gbs=round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
         hbm_algorithmic_frac_of_peak=round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4),

@@ -63,8 +63,28 @@ class FacetSharding:
     * the blocks of wave ``key`` therefore come from ``items_of(r, key)`` = the whole facets of ``r`` plus the
       cooperative facets it owns for that wave, and arrive in the order ``arrival(key)``."""
 
-    def __init__(self, n_facets, rank, world, balance=True, wave_keys=None):
+    def __init__(self, n_facets, rank, world, balance=True, wave_keys=None, wave_sizes=None):
         self.n_facets, self.rank, self.world = n_facets, rank, world
+        # wave_sizes = {wave key: subgrids in the wave}: WHOLE waves are owned by single ranks (largest waves first,
+        # always to the rank with the fewest subgrids so far) instead of every wave being dealt out subgrid by subgrid.
+        # At 8 ranks a rank then finishes ~3 whole waves of ~20 subgrids instead of 25 x 2-3 subgrids: the subgrid-side
+        # kernels run at their single-GPU efficiency (measured r4, 64k workload: 45 -> 24 us per wave and rank).  The
+        # exchange of a wave becomes a gather to its owner; over consecutive waves the owners rotate.
+        #   A gather per wave would leave six of a GPU's seven xGMI links idle, so the waves are exchanged in GROUPS of
+        # `world` waves with distinct owners (``wave_groups``): one balanced all-to-all per group
+        # (DistributedForward.start_group / finish_group).
+        self.wave_rank, self.wave_groups = None, None
+        if wave_sizes is not None and world > 1:
+            load = [0] * world
+            self.wave_rank, self.wave_groups = {}, []
+            by_size = sorted(wave_sizes.items(), key=lambda kv: (-kv[1], kv[0]))
+            for g0 in range(0, len(by_size), world):
+                group = by_size[g0 : g0 + world]  # waves of similar size; the largest goes to the least loaded rank
+                ranks = sorted(range(world), key=lambda q: (load[q], q))
+                for (k, n), r in zip(group, ranks):
+                    self.wave_rank[int(k)] = r
+                    load[r] += n
+                self.wave_groups.append([int(k) for k, _ in group])
         n_whole = n_facets
         self.coop = []
         if wave_keys is not None and world > 1 and n_facets % world:
@@ -90,9 +110,14 @@ class FacetSharding:
                 for k in self.keys_of[r]:
                     self.key_owner[k] = r
 
-    def subgrids_of(self, n_subgrids, rank=None):
-        """indices (within the wave) of the subgrids of ``rank``"""
+    def subgrids_of(self, n_subgrids, rank=None, key=None):
+        """indices (within the wave) of the subgrids of ``rank``; ``key`` = the wave key (needed when whole waves are
+        owned by single ranks)"""
         rank = self.rank if rank is None else rank
+        if self.wave_rank is not None:
+            if key is None:
+                raise ValueError("whole-wave subgrid ownership: subgrids_of needs the wave key")
+            return list(range(n_subgrids)) if self.wave_rank[int(key)] == rank else []
         if rank not in self.subgrid_ranks:
             return []
         return list(range(self.subgrid_ranks.index(rank), n_subgrids, len(self.subgrid_ranks)))
@@ -160,8 +185,8 @@ def forward_layout(sharding, n_subgrids, blk, key=None):
     """Element counts of the forward exchange: (per-destination subgrid index lists, in_counts, out_counts); ``key``
     = the wave key when facets are worked on cooperatively (the senders' item counts depend on the wave)."""
     F_local = len(sharding.items_of(sharding.rank, key))
-    mine = sharding.subgrids_of(n_subgrids)
-    dests = [sharding.subgrids_of(n_subgrids, r) for r in range(sharding.world)]
+    mine = sharding.subgrids_of(n_subgrids, key=key)
+    dests = [sharding.subgrids_of(n_subgrids, r, key) for r in range(sharding.world)]
     in_counts = [F_local * len(d) * blk for d in dests]
     out_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
     return dests, in_counts, out_counts
@@ -169,10 +194,10 @@ def forward_layout(sharding, n_subgrids, blk, key=None):
 
 def backward_layout(sharding, n_subgrids, blk, key=None):
     """Element counts of the backward exchange (subgrid holder -> facet owner)."""
-    mine = sharding.subgrids_of(n_subgrids)
+    mine = sharding.subgrids_of(n_subgrids, key=key)
     F_local = len(sharding.items_of(sharding.rank, key))
     in_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
-    out_counts = [F_local * len(sharding.subgrids_of(n_subgrids, r)) * blk for r in range(sharding.world)]
+    out_counts = [F_local * len(sharding.subgrids_of(n_subgrids, r, key)) * blk for r in range(sharding.world)]
     return in_counts, out_counts
 
 
@@ -235,6 +260,17 @@ def _dist_info(group):
     return 0, 1
 
 
+def _wave_sizes(plan, wave_axis):
+    """{wave key: number of subgrids} of a plan (whole-wave subgrid ownership needs a plan)"""
+    if not plan:
+        raise ValueError("whole_waves=True needs the plan of subgrids (subgrid_configs)")
+    sizes = {}
+    for sg in plan:
+        k = int(sg.off1 if wave_axis == 1 else sg.off0)
+        sizes[k] = sizes.get(k, 0) + 1
+    return sizes
+
+
 def _plan_wave_keys(core, plan):
     """Wave keys (subgrid ``off1``) of a plan in BAND order -- sorted by the position of their column window in the
     band of the whole plan -- so that contiguous key ranges are contiguous column ranges; ``(keys, band)``."""
@@ -287,7 +323,7 @@ class DistributedForward:
     ``cooperative=False`` keeps whole-facet ownership (facet ``j`` on rank ``j % world``)."""
 
     def __init__(self, swiftly_config, facet_configs, facet_data, lru_forward=1, group=None, subgrid_configs=None,
-                 wave_axis=None, dtype=None, rank_world=None, cooperative=True):
+                 wave_axis=None, dtype=None, rank_world=None, cooperative=True, whole_waves=False):
         from .api import SwiftlyForward, preferred_wave_axis  # pylint: disable=import-outside-toplevel
 
         torch = _torch()
@@ -321,7 +357,8 @@ class DistributedForward:
             keys, band = _plan_wave_keys(self.core, self._plan)
             if band == (0, self.core.yN_size):
                 keys = None  # the plan needs the whole padded axis: no sub-bands to hand out
-        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys)
+        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys,
+                                      wave_sizes=_wave_sizes(self._plan, self.wave_axis) if whole_waves else None)
         local = self.sharding.local_facets
         self.local = None
         if local or not self.sharding.coop:
@@ -409,22 +446,33 @@ class DistributedForward:
                 send, in_counts, out_counts = self.pack_coop(j)
                 self.unpack_coop(j, exchange_blocks(send, in_counts, out_counts, self.group).wait())
 
+    def wave_key(self, sgs):
+        """key of the wave ``sgs`` (``off1``, or ``off0`` in the reference schedule)"""
+        return int(sgs[0].off1 if self.wave_axis == 1 else sgs[0].off0)
+
+    def subgrids_of(self, sgs, rank=None):
+        """indices within the wave ``sgs`` of the subgrids ``rank`` (default: this rank) finishes"""
+        return self.sharding.subgrids_of(len(sgs), rank, self.wave_key(sgs))
+
     def _arrival_cfgs(self, key):
         if not self.sharding.coop:
             return self.arrival_cfgs
         return [self.facet_configs[j] for j in self.sharding.arrival(key)]
 
-    def pack_wave(self, sgs):
+    def pack_wave(self, sgs, into=None):
         """Compute this rank's blocks for the subgrids ``sgs`` (one wave: same wave key and size) straight into
-        the send buffer ``[dest][local facet][subgrid of dest][m, m]``; returns ``(send, in_counts, out_counts)``."""
+        the send buffer ``[dest][local facet][subgrid of dest][m, m]``; returns ``(send, in_counts, out_counts)``.
+        ``into``: flat buffer of the right size to fill instead of a fresh one (a slice of a group's send buffer)."""
         torch = _torch()
         core = self.core
         m = core.xM_yN_size
-        key = int(sgs[0].off1) if self.sharding.coop else None
+        key = self.wave_key(sgs)
         dests, in_counts, out_counts = forward_layout(self.sharding, len(sgs), m * m, key)
         F_whole = len(self.sharding.local_facets)
         items = self.sharding.items_of(self.rank, key)
-        send = torch.empty(sum(in_counts), dtype=self.dtype, device=core.device)
+        if into is not None and into.numel() != sum(in_counts):
+            raise ValueError("destination buffer does not match the wave's send size")
+        send = into if into is not None else torch.empty(sum(in_counts), dtype=self.dtype, device=core.device)
         if self.fused and self.wave_axis == 1 and items:
             # one native call for the whole wave: block (f, i) of subgrid i = dests[d][k] goes to
             # chunk_base[d] + f * len(dests[d]) * m^2 + k * m^2
@@ -456,11 +504,12 @@ class DistributedForward:
         source][my subgrid][m, m]``: returns ``(indices within sgs, tensor [S_local, xA, xA] or None)``."""
         from .api import finish_from_blocks  # pylint: disable=import-outside-toplevel
 
-        mine = self.sharding.subgrids_of(len(sgs))
+        key = self.wave_key(sgs)
+        mine = self.sharding.subgrids_of(len(sgs), key=key)
         if not mine:
             return mine, None
         m = self.core.xM_yN_size
-        cfgs = self._arrival_cfgs(int(sgs[0].off1))
+        cfgs = self._arrival_cfgs(key)
         blocks = recv.view(len(cfgs), len(mine), m, m)  # facets in arrival order
         res = finish_from_blocks(self.core, blocks, cfgs, [sgs[i] for i in mine], transformed=self.fused)
         return mine, res
@@ -471,6 +520,54 @@ class DistributedForward:
         kernels (compute stream)."""
         send, in_counts, out_counts = self.pack_wave(sgs)
         return sgs, exchange_blocks(send, in_counts, out_counts, self.group)
+
+    # -- whole-wave ownership: one balanced all-to-all per GROUP of waves with distinct owners --------------------
+    def pack_group(self, waves):
+        """``waves``: the waves (lists of subgrid configs) of one ``sharding.wave_groups`` entry, in any order.  Every
+        wave goes to its owner as ONE chunk ``[my items][its subgrids][m, m]``: ``(send, in_counts, out_counts)`` of a
+        single all-to-all that moves the whole group -- each rank sends to and receives from every other rank."""
+        torch = _torch()
+        sh = self.sharding
+        if sh.wave_rank is None:
+            raise ValueError("pack_group needs whole-wave subgrid ownership (whole_waves=True)")
+        m2 = self.core.xM_yN_size ** 2
+        owner = {}
+        for sgs in waves:
+            r = sh.wave_rank[self.wave_key(sgs)]
+            if r in owner:
+                raise ValueError("two waves of a group have the same owner")
+            owner[r] = sgs
+        in_counts = [len(sh.items_of(self.rank, self.wave_key(owner[d]))) * len(owner[d]) * m2 if d in owner else 0
+                     for d in range(self.world)]
+        mine = owner.get(self.rank)
+        out_counts = [len(sh.items_of(s, self.wave_key(mine))) * len(mine) * m2 if mine is not None else 0
+                      for s in range(self.world)]
+        send = torch.empty(sum(in_counts), dtype=self.dtype, device=self.core.device)
+        pos = 0
+        for d in range(self.world):
+            if in_counts[d]:
+                sub_send, sub_in, _ = self.pack_wave(owner[d], into=send[pos : pos + in_counts[d]])
+                assert sub_send.numel() == in_counts[d] and sub_in[d] == in_counts[d]
+            pos += in_counts[d]
+        return send, in_counts, out_counts
+
+    def unpack_group(self, waves, recv):
+        """finish the wave of the group this rank owns: ``(its subgrid configs or None, tensor [S, xA, xA] or None)``"""
+        for sgs in waves:
+            if self.sharding.wave_rank[self.wave_key(sgs)] == self.rank:
+                _, res = self.unpack_wave(sgs, recv)
+                return sgs, res
+        return None, None
+
+    def start_group(self, waves):
+        """:py:meth:`pack_group` + start of the group's all-to-all; handle for :py:meth:`finish_group`"""
+        send, in_counts, out_counts = self.pack_group(waves)
+        return waves, exchange_blocks(send, in_counts, out_counts, self.group)
+
+    def finish_group(self, handle):
+        """wait for the exchange of a started group and :py:meth:`unpack_group`"""
+        waves, pending = handle
+        return self.unpack_group(waves, pending.wait())
 
     def finish_wave(self, handle):
         """Wait for the exchange of a started wave and :py:meth:`unpack_wave`."""
@@ -508,7 +605,7 @@ class DistributedBackward:
 
     # pylint: disable=too-many-arguments
     def __init__(self, swiftly_config, facet_configs, lru_backward=1, group=None, rank_world=None, wave_axis=0,
-                 subgrid_configs=None, dtype=None, cooperative=True):
+                 subgrid_configs=None, dtype=None, cooperative=True, whole_waves=False):
         from .api import SwiftlyBackward  # pylint: disable=import-outside-toplevel
         from .core_hip import band_range  # pylint: disable=import-outside-toplevel
 
@@ -532,7 +629,8 @@ class DistributedBackward:
             keys, band = _plan_wave_keys(core, plan)  # the same wave ranges as DistributedForward
             if band == (0, core.yN_size):
                 keys = None
-        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys)
+        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys,
+                                      wave_sizes=_wave_sizes(plan, self.wave_axis) if whole_waves else None)
         sh = self.sharding
         # facet owner side: accumulators of the local facets
         self.local = None
@@ -570,6 +668,14 @@ class DistributedBackward:
                     cb.dtype = self.dtype
                     self._coop[j] = cb
 
+    def wave_key(self, sgs):
+        """key of the wave ``sgs`` (``off1`` in the band schedule, else ``off0``)"""
+        return int(sgs[0].off1 if self.wave_axis == 1 else sgs[0].off0)
+
+    def subgrids_of(self, sgs, rank=None):
+        """indices within the wave ``sgs`` of the subgrids ``rank`` (default: this rank) holds"""
+        return self.sharding.subgrids_of(len(sgs), rank, self.wave_key(sgs))
+
     def pack_wave(self, sgs, subgrids_mine):
         """``sgs``: all subgrid configs of the wave (same size and same ``off0`` -- ``off1`` with ``wave_axis=1``,
         where the facet owners take the strided-axis transform per wave and the contiguous one at the end --
@@ -582,10 +688,10 @@ class DistributedBackward:
         m = core.xM_yN_size
         S = len(sgs)
         sh = self.sharding
-        mine = sh.subgrids_of(S)
+        key = self.wave_key(sgs)
+        mine = sh.subgrids_of(S, key=key)
         if len(subgrids_mine) != len(mine):
             raise ValueError(f"rank {self.rank} holds {len(mine)} subgrids of this wave, got {len(subgrids_mine)}")
-        key = int(sgs[0].off1) if sh.coop else None
         in_counts, out_counts = backward_layout(sh, S, m * m, key)
         if mine:
             # the contributions come out in the facet order of the splitter = the arrival order of this wave: with
@@ -606,11 +712,11 @@ class DistributedBackward:
             send = torch.empty(0, dtype=self.dtype, device=core.device)
         return send, in_counts, out_counts
 
-    def unpack_wave(self, sgs, recv):
+    def unpack_wave(self, sgs, recv, only_source=None):
         """Accumulate the received contributions (one chunk ``[my facet][subgrid of source][m, m]`` per source
-        rank) into this rank's facets."""
+        rank) into this rank's facets.  ``only_source``: ``recv`` holds the chunk of that source only (group exchange)."""
         sh = self.sharding
-        key = int(sgs[0].off1) if sh.coop else None
+        key = self.wave_key(sgs)
         items = sh.items_of(self.rank, key)
         F_local = len(items)
         if not F_local:
@@ -621,7 +727,9 @@ class DistributedBackward:
         chunks = []
         pos = 0
         for r in range(self.world):
-            idx = sh.subgrids_of(S, r)
+            if only_source is not None and r != only_source:
+                continue
+            idx = sh.subgrids_of(S, r, key)
             cnt = F_local * len(idx) * m * m
             if cnt:
                 chunks.append(([sgs[i] for i in idx], recv[pos : pos + cnt].view(F_local, len(idx), m, m)))
@@ -652,6 +760,63 @@ class DistributedBackward:
     def add_wave(self, sgs, subgrids_mine):
         """start_wave + finish_wave"""
         self.finish_wave(self.start_wave(sgs, subgrids_mine))
+
+    # -- whole-wave ownership: one balanced all-to-all per GROUP of waves with distinct holders ---------------------
+    def pack_group(self, waves, subgrids_mine):
+        """``waves``: the waves of one ``sharding.wave_groups`` entry; ``subgrids_mine``: data of ALL subgrids of the wave
+        of the group this rank holds (``[]`` if none).  ``(send, in_counts, out_counts)`` of the group's all-to-all:
+        this rank sends its wave's contributions to every facet owner and receives, from the holder of every other wave
+        of the group, that wave's contributions to its own facets."""
+        sh = self.sharding
+        if sh.wave_rank is None:
+            raise ValueError("pack_group needs whole-wave subgrid ownership (whole_waves=True)")
+        m2 = self.core.xM_yN_size ** 2
+        holder = {sh.wave_rank[self.wave_key(sgs)]: sgs for sgs in waves}
+        if len(holder) != len(waves):
+            raise ValueError("two waves of a group have the same holder")
+        mine = holder.get(self.rank)
+        if mine is not None:
+            send, in_counts, _ = self.pack_wave(mine, subgrids_mine)
+        else:
+            if len(subgrids_mine):
+                raise ValueError(f"rank {self.rank} holds no wave of this group")
+            send = _torch().empty(0, dtype=self.dtype, device=self.core.device)
+            in_counts = [0] * self.world
+        out_counts = [len(sh.items_of(self.rank, self.wave_key(holder[s]))) * len(holder[s]) * m2 if s in holder else 0
+                      for s in range(self.world)]
+        return send, in_counts, out_counts
+
+    def unpack_group(self, waves, recv):
+        """accumulate the received contributions of every wave of the group (one chunk per holder) into this rank's facets"""
+        sh = self.sharding
+        m = self.core.xM_yN_size
+        holder = {sh.wave_rank[self.wave_key(sgs)]: sgs for sgs in waves}
+        pos = 0
+        for s in range(self.world):
+            sgs = holder.get(s)
+            if sgs is None:
+                continue
+            cnt = len(sh.items_of(self.rank, self.wave_key(sgs))) * len(sgs) * m * m
+            if cnt:
+                # the chunk of source s is exactly what unpack_wave expects for a wave whose only holder is s
+                self.unpack_wave(sgs, recv[pos : pos + cnt], only_source=s)
+            pos += cnt
+
+    def start_group(self, waves, subgrids_mine):
+        """:py:meth:`pack_group` + start of the group's all-to-all; handle for :py:meth:`finish_group`"""
+        while len(self._started) >= self.MAX_IN_FLIGHT:
+            self._started.pop(0).wait()
+        send, in_counts, out_counts = self.pack_group(waves, subgrids_mine)
+        pending = exchange_blocks(send, in_counts, out_counts, self.group)
+        self._started.append(pending)
+        return waves, pending
+
+    def finish_group(self, handle):
+        """wait for the exchange of a started group and :py:meth:`unpack_group`"""
+        waves, pending = handle
+        recv = pending.wait()
+        self._started = [q for q in self._started if q is not pending]
+        self.unpack_group(waves, recv)
 
     # -- cooperative facets: column ranges out, row blocks in, contiguous-axis finish on this rank's rows -------------
     def pack_coop_finish(self, j):

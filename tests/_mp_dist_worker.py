@@ -167,6 +167,38 @@ def cooperative_section(rank, world):
         rms = float(want[j].abs().pow(2).mean().sqrt())
         assert float((piece - w).abs().pow(2).mean().sqrt()) <= 3e-6 * rms, (rank, "coop bwd piece", j)
     dist.barrier()
+    # whole-wave ownership with one all-to-all per group of waves (bench.py's default multi-GPU schedule), streaming
+    # forward -> backward like the round-trip leg of bench.py
+    dfw = DistributedForward(cfg, facet_cfgs, facets, subgrid_configs=sg_cfgs, wave_axis=1, dtype=torch.complex64,
+                             whole_waves=True)
+    dbw = DistributedBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs, dtype=torch.complex64, whole_waves=True)
+    dfw.prepare_all_facets()
+    by_key = {int(k): w for k, w in waves.items()}
+    pend_f = pend_b = None
+    for group in dfw.sharding.wave_groups + [None]:
+        gw = [by_key[k] for k in group] if group is not None else None
+        hf = (gw, dfw.start_group(gw)) if gw is not None else None
+        if pend_f is not None:
+            sgs, res = dfw.finish_group(pend_f[1])
+            if sgs is not None:
+                for k, c in enumerate(sgs):
+                    w = full[(c.off0, c.off1)]
+                    assert float((res[k] - w).abs().max()) <= 2e-5 * float(w.abs().max()), (rank, "group fwd", c.off0, c.off1)
+            hb = dbw.start_group(pend_f[0], [full[(c.off0, c.off1)] for c in sgs] if sgs is not None else [])
+            if pend_b is not None:
+                dbw.finish_group(pend_b)
+            pend_b = hb
+        pend_f = hf
+    dbw.finish_group(pend_b)
+    idx, out = dbw.finish()
+    for j, o in zip(idx, out):
+        rms = float(want[j].abs().pow(2).mean().sqrt())
+        assert float((o - want[j]).abs().pow(2).mean().sqrt()) <= 3e-6 * rms, (rank, "group bwd whole", j)
+    for j, row0, piece in dbw.coop_pieces:
+        w = want[j][row0 : row0 + piece.shape[0]]
+        rms = float(want[j].abs().pow(2).mean().sqrt())
+        assert float((piece - w).abs().pow(2).mean().sqrt()) <= 3e-6 * rms, (rank, "group bwd piece", j)
+    dist.barrier()
 
 
 if __name__ == "__main__":

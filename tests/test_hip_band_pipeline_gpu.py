@@ -404,13 +404,14 @@ def _virtual_all_to_all(sends, in_counts):
     ]
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_cooperative_facets_virtual_ranks(world):
+@pytest.mark.parametrize("world,whole_waves", [(2, False), (8, False), (2, True), (8, True)])
+def test_cooperative_facets_virtual_ranks(world, whole_waves):
     """Facet counts that do not divide by the world size (r4): 3 facets on 2 ranks (one whole facet each + facet 2
     worked on by both) and on 8 ranks (all three cooperative).  Virtual ranks in one process, the three exchanges
     (band rows, forward blocks per wave, backward blocks per wave, finishing rows) replaced by in-process shuffles of
     the flat buffers; results against the single-process classes: the same kernels on the same numbers -- only the
-    order of the facet sums (arrival order) and of the column overlaps differs."""
+    order of the facet sums (arrival order) and of the column overlaps differs.  ``whole_waves``: every wave's subgrids
+    are finished / held by ONE rank (the exchange of a wave is a gather to its owner) instead of dealt out round-robin."""
     import torch
 
     from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward
@@ -420,8 +421,11 @@ def test_cooperative_facets_virtual_ranks(world):
         pytest.skip("band pipelines not available")
     ref = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
     fwds = [DistributedForward(cfg, facet_cfgs, facets, subgrid_configs=sg_cfgs, wave_axis=1, dtype=torch.complex64,
-                               rank_world=(r, world)) for r in range(world)]
+                               rank_world=(r, world), whole_waves=whole_waves) for r in range(world)]
     sh = fwds[0].sharding
+    if whole_waves:  # 4 waves of 3 subgrids: every wave on one rank, the ranks' loads differ by at most one wave
+        owners = [sh.wave_rank[int(c.off1)] for c in sg_cfgs]
+        assert len(set(owners)) == min(world, 4) and all(len(f.subgrids_of([c])) in (0, 1) for f in fwds for c in sg_cfgs)
     assert sh.coop == ([2] if world == 2 else [0, 1, 2])
     assert sorted(k for r in range(world) for k in sh.keys_of[r]) == sorted({c.off1 for c in sg_cfgs})
     yB = facet_cfgs[0].size
@@ -438,7 +442,26 @@ def test_cooperative_facets_virtual_ranks(world):
     for c in sg_cfgs:
         waves.setdefault(c.off1, []).append(c)
     full = {}
-    for key, wave in waves.items():
+    if whole_waves:
+        # one all-to-all per GROUP of waves with distinct owners: every rank sends to / receives from every rank
+        assert sorted(k for g in sh.wave_groups for k in g) == sorted(waves) and all(len(g) <= world for g in sh.wave_groups)
+        for group in sh.wave_groups:
+            gw = [waves[k] for k in group]
+            packed = [f.pack_group(gw) for f in fwds]
+            recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+            seen = 0
+            for r, f in enumerate(fwds):
+                assert recvs[r].numel() == sum(packed[r][2])
+                sgs, res = f.unpack_group(gw, recvs[r])
+                if sgs is None:
+                    continue
+                seen += 1
+                want = ref.get_wave(sgs)
+                for i, c in enumerate(sgs):
+                    assert float((res[i] - want[i]).abs().max()) <= 2e-5 * float(want.abs().max()), (c.off0, c.off1)
+                    full[(c.off0, c.off1)] = want[i]
+            assert seen == len(gw)
+    for key, wave in ({} if whole_waves else waves).items():
         want = ref.get_wave(wave)
         packed = [f.pack_wave(wave) for f in fwds]
         # the cooperative facets' blocks come from the rank that owns the wave
@@ -460,12 +483,25 @@ def test_cooperative_facets_virtual_ranks(world):
     # backward, band schedule, the same wave ranges
     rb = sw.SwiftlyBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs)
     bwds = [DistributedBackward(cfg, facet_cfgs, wave_axis=1, subgrid_configs=sg_cfgs, dtype=torch.complex64,
-                                rank_world=(r, world)) for r in range(world)]
+                                rank_world=(r, world), whole_waves=whole_waves) for r in range(world)]
     assert bwds[0].sharding.coop == sh.coop
-    for key, wave in waves.items():
+    if whole_waves:
+        for group in bwds[0].sharding.wave_groups:
+            gw = [waves[k] for k in group]
+            for wave in gw:
+                rb.add_new_subgrid_tasks(wave, [full[(c.off0, c.off1)] for c in wave])
+            packed = []
+            for b in bwds:
+                held = [w for w in gw if b.sharding.wave_rank[b.wave_key(w)] == b.rank]
+                packed.append(b.pack_group(gw, [full[(c.off0, c.off1)] for c in held[0]] if held else []))
+            recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
+            for r, b in enumerate(bwds):
+                assert recvs[r].numel() == sum(packed[r][2])
+                b.unpack_group(gw, recvs[r])
+    for key, wave in ({} if whole_waves else waves).items():
         data = [full[(c.off0, c.off1)] for c in wave]
         rb.add_new_subgrid_tasks(wave, data)
-        packed = [b.pack_wave(wave, [data[i] for i in b.sharding.subgrids_of(len(wave))]) for b in bwds]
+        packed = [b.pack_wave(wave, [data[i] for i in b.subgrids_of(wave)]) for b in bwds]
         recvs = _virtual_all_to_all([p[0] for p in packed], [p[1] for p in packed])
         for r, b in enumerate(bwds):
             assert recvs[r].numel() == sum(packed[r][2])

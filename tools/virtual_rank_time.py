@@ -22,6 +22,9 @@ from oracle import separable as sep  # noqa: E402  (data recipe only)
 from ska_sdp_exec_swiftly_amd.distributed import DistributedBackward, DistributedForward  # noqa: E402
 
 
+WHOLE = os.environ.get("VR_WHOLE_WAVES") == "1"  # every wave's subgrids on one rank (DistributedForward(whole_waves=True))
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "64k-sparse"
     out_path = sys.argv[2] if len(sys.argv) > 2 else None
@@ -32,7 +35,7 @@ def main():
     sgs = bench.select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
     m = cfg.core.xM_yN_size
     xA = p["xA_size"]
-    res = dict(workload=wl["name"], worlds={})
+    res = dict(workload=wl["name"], subgrid_ownership="whole waves" if WHOLE else "round-robin within a wave", worlds={})
     one = bench.separable_facet(torch, sep.facet_vectors(1234, p["yB_size"]), all_fcs[0])
     for world in (1, 2, 4, 8):
         cap = wl.get("max_facets_per_rank")
@@ -58,7 +61,7 @@ def main():
 
             def forward_pass():
                 dfw = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64,
-                                         rank_world=(rank, world))
+                                         rank_world=(rank, world), whole_waves=WHOLE)
                 dfw.prepare_all_facets()
                 sent[0] = 0
                 for j in dfw.sharding.coop:  # cooperative facets: K1 on this rank's rows + (dummy) band-row exchange
@@ -73,7 +76,8 @@ def main():
 
             def backward_pass(subs):
                 dbw = DistributedBackward(cfg, fcs, wave_axis=1 if cfg.core.supports_backward_band(torch.complex64) else 0,
-                                          subgrid_configs=sgs, dtype=torch.complex64, rank_world=(rank, world))
+                                          subgrid_configs=sgs, dtype=torch.complex64, rank_world=(rank, world),
+                                          whole_waves=WHOLE)
                 for wave, mine, got in subs:
                     send, inc, outc = dbw.pack_wave(wave, [got[k] for k in range(len(mine))] if got is not None else [])
                     recv = send if world == 1 else torch.empty(sum(outc), dtype=torch.complex64, device="cuda")
@@ -98,7 +102,7 @@ def main():
             t_f = timed(forward_pass) * scale
             # subgrid data for the backward leg: random subgrids of the right shape for the ones this rank holds
             dfw0 = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64,
-                                      rank_world=(rank, world))
+                                      rank_world=(rank, world), whole_waves=WHOLE)
             subs = []
             bkey = (lambda c: c.off1) if cfg.core.supports_backward_band(torch.complex64) else (lambda c: c.off0)
             bw = {}
@@ -106,7 +110,7 @@ def main():
                 bw.setdefault(bkey(c), []).append(c)
             bwl = list(bw.values())[: len(waves)]
             for wave in bwl:
-                mine = dfw0.sharding.subgrids_of(len(wave))
+                mine = dfw0.subgrids_of(wave)
                 got = torch.randn((len(mine), xA, xA), dtype=torch.complex64, device="cuda") if mine else None
                 subs.append((wave, mine, got))
             del dfw0
