@@ -19,6 +19,14 @@ for w in 8k 12k 24k 32k-8x8 64k-sparse-4x4 128k 128k-8x8; do
   timeout 500 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > "$out/bench_$w.json" 2> "$out/bench_$w.err"
 done
 for w in 8k 24k 32k-8x8 128k; do tools/gpu_trace.sh "$out" $w > /dev/null 2>&1; done
+# r4: the float64-arithmetic column passes as the timed configuration, its kernel trace, virtual ranks in both subgrid
+# ownership modes, the K1 timeline, a functional 2-rank run of the multi-GPU bench path on this one GPU (gloo, host-staged)
+timeout 500 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --column-precision 64 > "$out/bench_64k_sparse_f64.json" 2> "$out/bench_64k_sparse_f64.err"
+BENCH_ARGS="--column-precision 64" tools/gpu_trace_only.sh "$out/trace_f64" A=1 > /dev/null 2>&1; cp "$out/trace_f64/kernel_stats.txt" "$out/kernel_stats_64k_sparse_f64.txt"; rm -rf "$out/trace_f64"
+timeout 600 python tools/virtual_rank_time.py 64k-sparse "$out/virtual_ranks_64k-sparse.json" > "$out/virtual_ranks.log" 2>&1
+VR_WHOLE_WAVES=1 timeout 600 python tools/virtual_rank_time.py 64k-sparse "$out/virtual_ranks_64k-sparse_whole_waves.json" > "$out/virtual_ranks_whole.log" 2>&1
+SWIFTLY_HIP_LIB="$here/variants/trace.so" timeout 200 python tools/k1_trace.py > "$out/k1_trace.txt" 2>&1
+SWIFTLY_BENCH_BACKEND=gloo SWIFTLY_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus 2 --steps 1 --warmup 0 --no-cpu-baseline --no-backward 2>/dev/null | grep '^{' > "$out/bench_2rank_functional_gloo.json"
 python - "$out" <<'PY'
 import glob, json, sys
 for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):

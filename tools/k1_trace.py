@@ -50,8 +50,6 @@ print(f"lifetime cycles: mean {life.mean():.0f} median {numpy.median(life):.0f} 
 for i, nm in enumerate(names):
     d = t[:, pts[i + 1]] - t[:, pts[i]]
     print(f"  {nm:24s} mean {d.mean():8.0f}  median {numpy.median(d):8.0f}  p10 {numpy.percentile(d, 10):8.0f}  p90 {numpy.percentile(d, 90):8.0f}  ({100 * d.mean() / life.mean():.1f} %)")
-span = t[:, 8].max() - t0
-print(f"kernel span {span} cycles; sum of lifetimes / (CUs * span) = {life.sum() / (len(numpy.unique(cuid)) * span):.2f} resident workgroups per CU")
 # per-CU: what is the sibling doing while a workgroup loads?  fraction of each phase overlapped by another
 # resident workgroup's compute phases (2..7)
 sel = numpy.unique(cuid)[:8]
@@ -61,4 +59,4 @@ for c in sel[:2]:
     print("CU", c, "first 8 workgroups (start, load end, compute end, end) relative cycles:")
     for b in order[:8]:
         print("   blk", b, (t[b, [0, 1, 7, 8]] - t0).tolist())
-numpy.save(os.path.join(ROOT, "gpurun_out", "r4b", "k1_trace.npy"), buf[:nblk])
+
