@@ -101,11 +101,11 @@ static int data_segment_run(const RowPassArgs& a, int n, int seglen, int* first)
     return run == count ? run : nseg;  // two runs cannot happen for one cyclic range; be safe
 }
 
-template <class G, bool PAIR, bool WIN, int ST, int NSEG>
+template <class G, bool PAIR, bool WIN, int ST, int NSEG, int CJ = -1>
 static void launch_band_inst(const RowPassArgs& a, unsigned blocks, const cx<float>* tw14, const cx<float>* tw_full,
                              hipStream_t s) {
-    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, NSEG>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a, a.in,
-                       a.out, a.ld_win, tw14, tw_full);
+    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, NSEG, CJ>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a,
+                       a.in, a.out, a.ld_win, tw14, tw_full);
 }
 // tuning knob SWIFTLY_ROW_SEGSKIP=0: always the all-segments kernel
 static bool segskip_enabled() {
@@ -125,24 +125,27 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
         constexpr int SEGLEN = PAIR ? 2 * G::T : G::T, NSEGTOT = 2 * G::N / SEGLEN;
         int first = 0;
         const int run = segskip_enabled() ? data_segment_run(a, 2 * G::N, SEGLEN, &first) : NSEGTOT;
-#define SWF_TRY_SEG(WIN, ST, NS)                                       \
+#define SWF_TRY_SEG(WIN, ST, NS, CJ)                                   \
     if (run <= NS) {                                                   \
         a.seg_rot = first;                                             \
-        launch_band_inst<G, PAIR, WIN, ST, NS>(a, blocks, tw14, tw_full, s); \
+        launch_band_inst<G, PAIR, WIN, ST, NS, CJ>(a, blocks, tw14, tw_full, s); \
         return (int)hipGetLastError();                                 \
     }
+        // these instances also have the conjugations compiled in (CJ): prepare_facet is an inverse transform (both
+        // set), finish_facet a forward one (neither)
+        const bool inv = a.conj_ld && a.conj_st, fwd = !a.conj_ld && !a.conj_st;
         if constexpr (PAIR) {
-            if (a.band_len > 0 && a.ld_win) {
-                SWF_TRY_SEG(true, 1, 16)
-                SWF_TRY_SEG(true, 1, 22)
-                SWF_TRY_SEG(true, 1, 24)
-            } else if (a.band_len < 0) {
-                SWF_TRY_SEG(false, 2, 13)
-                SWF_TRY_SEG(false, 2, 16)
+            if (a.band_len > 0 && a.ld_win && inv) {
+                SWF_TRY_SEG(true, 1, 16, 1)
+                SWF_TRY_SEG(true, 1, 22, 1)
+                SWF_TRY_SEG(true, 1, 24, 1)
+            } else if (a.band_len < 0 && fwd) {
+                SWF_TRY_SEG(false, 2, 13, 0)
+                SWF_TRY_SEG(false, 2, 16, 0)
             }
         } else {
-            if (a.band_len > 0 && a.ld_win) {
-                SWF_TRY_SEG(true, 1, 44)
+            if (a.band_len > 0 && a.ld_win && inv) {
+                SWF_TRY_SEG(true, 1, 44, 1)
             }
         }
 #undef SWF_TRY_SEG
@@ -196,9 +199,9 @@ static int init_band() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
-template <class G, bool WIN, int ST, int NSEG = 0, bool PAIR = true>
+template <class G, bool WIN, int ST, int NSEG = 0, bool PAIR = true, int CJ = -1>
 static int init_band_pair() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, PAIR, NSEG>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, PAIR, NSEG, CJ>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 template <class G>
@@ -233,12 +236,12 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 1>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 16>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 22>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 24>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16>();
-        if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 16, true, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 22, true, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 24, true, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13, true, 0>();
+        if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16, true, 0>();
+        if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false, 1>();
         if (!rcb) rcb = init_band_geo<BandGeo4>();
         if (!rcb) rcb = init_band_geo<BandGeo64k>();
         if (!rcb) rcb = init_band_geo<BandGeo16k>();

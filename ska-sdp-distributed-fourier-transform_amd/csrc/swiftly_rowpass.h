@@ -346,7 +346,18 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // instead: 1.80 ms; neither kept.  tools/k1_trace.py + -DSWF_TRACE=1: a workgroup lives 46 k cycles -- loads 20 %,
 // window products / first stage / inter-half twiddle 18 %, the three butterfly phases 35 %, the two exchanges 25 %
 // -- with two workgroups per CU, i.e. the SIMDs issue about 55 % of the time.)
-template <class G, bool HAS_WIN, int ST, bool PAIR = false, int NSEG = 0>
+// CJ (r4b): -1 = conjugation on load / store from the runtime flags (multiplications by +-1); 1 / 0 = the launcher
+// guarantees conj_ld = conj_st = 1 / 0 and the sign changes ride on the neg_hi modifier of the packed window and scale
+// products (bit-identical results, 32 + 64 multiplications per lane fewer).
+// Band store with ONE block per lane in the last phase (r4b): the lane's outputs are e = t + r T, i.e. cyclic band
+// distance d_r = (2 t + h + N/2 - band_start + 2 T r) mod N.  Across a wave d_r spans 128 consecutive values, so for all
+// but at most two r the whole wave is inside or outside the band: that decision is made on the SCALAR unit, outputs the
+// wave does not keep (65 % on the 64k workload) cost two scalar instructions instead of the rotation phase product,
+// the scale and five address / compare operations, and kept outputs are stored at  SGPR base + lane * 8.
+#ifndef SWF_ROW_UNIFORM_ST
+#define SWF_ROW_UNIFORM_ST 1
+#endif
+template <class G, bool HAS_WIN, int ST, bool PAIR = false, int NSEG = 0, int CJ = -1>
 __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                  cx<float>* __restrict__ gout,
                                                                  const float* __restrict__ ld_win,
@@ -424,8 +435,25 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
                     const f32x4 val = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off8, 0, 0));
                     if constexpr (HAS_WIN) {
                         const f32x2 w = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(off8 >> 1), 0, 0));
-                        a[q][0] = cx<float>{val.x * w.x, val.y * w.x};
-                        a[q][1] = cx<float>{val.z * w.y, val.w * w.y};
+                        if constexpr (CJ >= 0) {  // one packed product per point; CJ = 1: (x w, -y w)
+                            const f32x2 p0 = {val.x, val.y}, p1 = {val.z, val.w};
+                            f32x2 r0, r1;
+                            if constexpr (CJ == 1) {
+                                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r0) : "v"(p0), "v"(w));
+                                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_hi:[1,0]" : "=v"(r1) : "v"(p1), "v"(w));
+                            } else {
+                                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r0) : "v"(p0), "v"(w));
+                                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r1) : "v"(p1), "v"(w));
+                            }
+                            a[q][0] = pkc(r0);
+                            a[q][1] = pkc(r1);
+                        } else {
+                            a[q][0] = cx<float>{val.x * w.x, val.y * w.x};
+                            a[q][1] = cx<float>{val.z * w.y, val.w * w.y};
+                        }
+                    } else if constexpr (CJ == 1) {
+                        a[q][0] = cx<float>{val.x, -val.y};
+                        a[q][1] = cx<float>{val.z, -val.w};
                     } else {
                         a[q][0] = cx<float>{val.x, val.y};
                         a[q][1] = cx<float>{val.z, val.w};
@@ -434,7 +462,14 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
             });
             static_for<0, 2>([&](auto uI) {
                 constexpr int u = decltype(uI)::value;
-                if constexpr (r + R1 < NS)
+                if constexpr (CJ >= 0) {  // the conjugation already happened in the window product
+                    if constexpr (r + R1 < NS)
+                        x[u + 2 * r] = pkc(__builtin_elementwise_fma(pkv(a[1][u]), f32x2{sgn, sgn}, pkv(a[0][u])));
+                    else if constexpr (r < NS)
+                        x[u + 2 * r] = a[0][u];
+                    else
+                        x[u + 2 * r] = cx<float>{0.f, 0.f};
+                } else if constexpr (r + R1 < NS)
                     x[u + 2 * r] = cx<float>{a[0][u].x + sgn * a[1][u].x, (a[0][u].y + sgn * a[1][u].y) * sg_ld};
                 else if constexpr (r < NS)
                     x[u + 2 * r] = cx<float>{a[0][u].x, a[0][u].y * sg_ld};
@@ -552,6 +587,8 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         constexpr int LR = (PAIR || G::LOGN % G::LOGP == 0) ? G::LOGP : G::LOGN % G::LOGP, LNS = G::LOGN - LR;
         constexpr int CH = (1 << LR) < 16 ? (1 << LR) : 16;
         float wv[CH];
+        // (r4b: the wave-uniform in-range test of the band store below was tried here too -- window loads and stores
+        // inside scalar branches: 1.81 -> 1.92 ms per facet, the branches split the batches of 16 window loads; not kept)
         run_phases([&](int e, cx<float> v, auto sI) {
             constexpr int s = decltype(sI)::value;
             if constexpr (s % CH == 0) {
@@ -575,6 +612,43 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
                 *reinterpret_cast<f32x2*>(outb + ((unsigned)d << 3)) = val;
             }
         });
+        return;
+    }
+    constexpr bool ONEBLK = PAIR || (G::LOGN % G::LOGP == 0);  // last phase: one block per lane, outputs e = t + r T
+    if constexpr (BAND && ONEBLK && CJ >= 0 && SWF_ROW_UNIFORM_ST) {
+        constexpr int LNS = G::LOGN - G::LOGP;
+        static_assert(T == (1 << LNS), "e = t + (r << LNS)");
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int dw = ((wave << 7) + (N >> 1) - A.band_start + h) & (N - 1);  // d of lane 0, output r = 0
+        const int lane2 = (t & 63) << 1;
+        const unsigned lane8 = (unsigned)(t & 63) << 3;
+        const f32x2 sc = {scale, scale};
+        char* __restrict__ ob = outb + region;
+        run_phases([&](int, cx<float> v, auto sI) {
+            constexpr int r = decltype(sI)::value;
+            const int base = (dw + (r << (LNS + 1))) & (N - 1);  // wave-uniform
+            const bool all_in = base + 126 < A.band_len;
+            const bool none_in = base >= A.band_len && base + 126 < N;
+            if (none_in) return;
+            if constexpr (SEGSKIP) v = cmul(v, rphi);
+            f32x2 val;
+            const f32x2 vv = pkv(v);
+            if constexpr (CJ == 1)
+                asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(val) : "v"(vv), "v"(sc));
+            else
+                val = vv * sc;
+            if (all_in) {
+                *reinterpret_cast<f32x2*>(ob + ((unsigned)(base >> 1) << 3) + lane8) = val;
+            } else {
+                const int d = (base + lane2) & (N - 1);
+                if (d < A.band_len) *reinterpret_cast<f32x2*>(ob + ((unsigned)(d >> 1) << 3)) = val;
+            }
+        });
+#if SWF_TRACE
+        SWF_TRACE_POINT(7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SWF_TRACE_POINT(8);
+#endif
         return;
     }
     run_phases([&](int e, cx<float> v) {

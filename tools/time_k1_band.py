@@ -29,3 +29,16 @@ for off in (0, 22528, -22528):
         e1.record()
         torch.cuda.synchronize()
     print(os.environ.get("SWIFTLY_HIP_LIB", "default"), os.environ.get("SWIFTLY_ROW_SEGSKIP", ""), f"off {off}: K1 {e0.elapsed_time(e1) / n:.4f} ms per facet")
+
+# the backward mirror: finish_facet along the contiguous axis of a band accumulator
+acc = torch.randn((p["yB_size"], int(band[1])), device="cuda", dtype=torch.complex64)
+for off in (0, 22528):
+    fin = core.finish_facet_band(acc, band, off, p["yB_size"])
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            core.finish_facet_band(acc, band, off, p["yB_size"], out=fin)
+        e1.record()
+        torch.cuda.synchronize()
+    print(os.environ.get("SWIFTLY_HIP_LIB", "default"), f"off {off}: finish_facet_band {e0.elapsed_time(e1) / n:.4f} ms per facet")
