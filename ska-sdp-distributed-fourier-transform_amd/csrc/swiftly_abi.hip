@@ -281,6 +281,13 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
 void swiftly_hip_destroy(swiftly_hip_t* h) {
     if (!h) return;
     DeviceGuard guard(h->device);
+    for (hipStream_t st : h->chunk_st)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (hipEvent_t ev : h->chunk_ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -474,6 +481,92 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         scratch = ws;
     }
     int rc = 0;
+    // Layout of the intermediate (r4): row y2 * n1 + k1 -- a pass-A workgroup (one y2) WRITES n1 consecutive rows and a
+    // pass-B workgroup (one k1) reads a comb -- instead of row k1 * n2 + y2 (comb written, consecutive rows read).  HBM
+    // writes are the expensive direction on this chip (tools/mall_pipe.hip: ~4.2 TB/s against ~7.6 TB/s for reads, and a
+    // comb costs 7 % on the write side and nothing on the read side): pass A 425 -> 395 us per wave as a pure copy.
+    // SWIFTLY_SCRATCH_LAYOUT=0 restores the r1-r3 layout.
+    static const bool y2_major = !(getenv("SWIFTLY_SCRATCH_LAYOUT") && atoi(getenv("SWIFTLY_SCRATCH_LAYOUT")) == 0);
+    const int a_i_rows = y2_major ? 1 : n2, a_o_rows = y2_major ? n1 : 1;  // pass A: row of (e = k1, o = y2)
+    const int b_i_rows = y2_major ? n1 : 1, b_o_rows = y2_major ? 1 : n2;  // pass B: row of (i = y2, o = k1)
+    // Chunked, two-stream form (r4; K2 = the gathered forward transform of several facets): the batch items are worked
+    // on in chunks of `zc` items x `Wc` columns whose two passes run back to back, chunks alternating between two
+    // internal streams, each stream re-using ONE chunk-sized slot of the scratch.  The intermediate of a chunk (n * Wc *
+    // zc * 8 bytes, 67 MB for a 32768-point transform of 256 columns) is written and re-read while it sits in the 256 MiB
+    // Infinity Cache, and because a slot is overwritten by the stream's next chunk its dirty lines never have to reach
+    // HBM; pass A of one chunk (HBM reads) runs next to pass B of the other (cache reads).  SWIFTLY_K2_CHUNK="cols[,items]"
+    // (0 = off).
+    static const char* chunk_env = getenv("SWIFTLY_K2_CHUNK");
+    static const int chunk_cols = chunk_env ? atoi(chunk_env) : 0;
+    static const int chunk_items = (chunk_env && strchr(chunk_env, ',')) ? std::max(1, atoi(strchr(chunk_env, ',') + 1)) : 1;
+    if (chunk_cols >= 64 && gathered && !(cz.flags & kZColScatter) && !c.gs && qmul == 0 && slab == (long long)W &&
+        (nb > chunk_items || W > chunk_cols) && !own) {
+        const int Wc = std::min<int>((chunk_cols / 64) * 64, W), zc = std::min(chunk_items, nb);
+        const size_t slot_elems = (size_t)n * (size_t)Wc * (size_t)zc;
+        if (2 * slot_elems * sizeof(cx<float>) <= ws_bytes) {
+            {
+                std::lock_guard<std::mutex> lock(h->chunk_mu);
+                for (hipStream_t& s2 : h->chunk_st)
+                    if (!s2) {
+                        he = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+                        if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(he));
+                    }
+            }
+            // (events are per call: two host threads may drive the same handle on different streams)
+            hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+            for (hipEvent_t& e : ev) {
+                he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipEventCreateWithFlags: %s", hipGetErrorString(he));
+            }
+            (void)hipEventRecord(ev[0], st);
+            for (hipStream_t s2 : h->chunk_st) (void)hipStreamWaitEvent(s2, ev[0], 0);
+            int i = 0;
+            for (int z0 = 0; z0 < nb && !rc; z0 += zc) {
+                const int nz = std::min(zc, nb - z0);
+                for (int c0 = 0; c0 < W && !rc; c0 += Wc, i++) {
+                    const int wc = std::min(Wc, W - c0);
+                    hipStream_t s2 = h->chunk_st[i & 1];
+                    // item z of the launch sits at slot + (z - z0) * n * Wc: the kernels add z * bs, so shift the base back
+                    cx<float>* slot = (cx<float>*)scratch + (size_t)(i & 1) * slot_elems - (long long)z0 * (long long)(n * Wc);
+                    ColPassArgs A = c;
+                    A.scratch_nt = 0;
+                    A.ncols = wc; A.col0 = c0; A.z0 = z0;
+                    A.out = slot; A.out_pitch = (unsigned)Wc; A.out_bs = (long long)(n * Wc);
+                    A.out_bdiv = 0; A.out_bs_hi = 0;
+                    A.ld_mul = n2;
+                    A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
+                    A.tw = tw1; A.tw_full = twf;
+                    A.f64 = f64 ? 1 : 0; A.twd = twd1; A.twd_full = twdf;
+                    A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
+                    A.col_win = nullptr; A.st_rowmap = nullptr; A.st_win = nullptr; A.st_win2 = nullptr;
+                    rc = launch_col_checked(l1, 0, A, cz, n2, nz, s2);
+                    if (rc) break;
+                    ColPassArgs B = c;
+                    B.scratch_nt = 0;
+                    ColZ zb = cz;
+                    zb.flags &= ~(kZColGather | kZLoadB | kZLoadAF);  // the scratch is read plainly
+                    B.ncols = wc; B.col0 = 0; B.z0 = z0;
+                    B.in = slot; B.in_pitch = (unsigned)Wc; B.in_bs = (long long)(n * Wc);
+                    B.in_bdiv = 0; B.in_bs_hi = 0;
+                    B.in_i_rows = b_i_rows; B.in_o_rows = b_o_rows;
+                    B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr; B.gs = 0;
+                    B.out = c.out + c0;
+                    B.st_mul = n1;
+                    B.tw = tw2; B.tw_full = twf;
+                    B.f64 = f64 ? 1 : 0; B.twd = twd2; B.twd_full = twdf;
+                    B.conj_ld = 0;
+                    if (B.col_win) B.col_win += c0;
+                    rc = launch_col_checked(l2, 1, B, zb, n1, nz, s2);
+                }
+            }
+            for (int k = 0; k < 2; k++) {
+                (void)hipEventRecord(ev[1 + k], h->chunk_st[k]);
+                (void)hipStreamWaitEvent(st, ev[1 + k], 0);
+            }
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+            return rc;
+        }
+    }
     // scratch accesses: a small intermediate is left cacheable so that pass B finds it in the 256 MiB Infinity
     // Cache (measured: the 160 MB of a K5b wave, K3-5 12.5 -> 11.6 ms per pass); a large one is streamed
     // non-temporally (measured: K2, 1.2 GB per wave, 18.5 ms vs 19.6 ms cacheable).  SWIFTLY_SCRATCH_NT forces.
@@ -489,7 +582,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)Ws; A.out_bs = (long long)(n * Ws);
         A.out_bdiv = 0; A.out_bs_hi = 0;
         A.ld_mul = n2;
-        A.out_i_rows = n2; A.out_o_rows = 1;
+        A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
         A.tw = tw1; A.tw_full = twf;
         A.f64 = f64 ? 1 : 0; A.twd = twd1; A.twd_full = twdf;
         if (qmul > 0) {
@@ -509,7 +602,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         B.ncols = wc;
         B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)Ws; B.in_bs = (long long)(n * Ws);
         B.in_bdiv = 0; B.in_bs_hi = 0;
-        B.in_i_rows = 1; B.in_o_rows = n2;
+        B.in_i_rows = b_i_rows; B.in_o_rows = b_o_rows;
         B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr; B.gs = 0;
         B.out = c.out + c0;
         B.st_mul = n1;

@@ -65,6 +65,11 @@ struct ColPassArgs {
     // flag is 0 has not been written yet and is stored plainly (no read-modify-write, no zero fill needed)
     const unsigned char* touched;
     int ncols;                      // columns (= rows of the primitive)
+    // Sub-launches of one logical launch (r4: the chunked, two-stream four-step of col_transform): the batch items of this
+    // launch are z0 + blockIdx.z (the four-step scratch pointer is pre-shifted by the host so that item z0 sits at its
+    // start), and the column gather sees column col0 + (tile column) -- the launch covers columns [col0, col0 + ncols) of
+    // the logical one, with the un-gathered side's pointer pre-shifted by col0
+    int z0, col0;
     int full_logn;                  // log2 of the full (power-of-two) transform length of a decomposed transform
     // Sub-transform j of a length n = Q * 2^full_logn transform behind the radix-Q pass of swiftly_mixed.h (0 = off):
     // the input is the plain scratch of that pass (ld_plain: logical row = plain index, no map), the store map refers to
@@ -239,7 +244,7 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
     int scol = col;
     if (cz.flags & (kZColGather | kZColScatter)) {  // uniform
         // (cg_mod = m is a power of two; cg_full = yN any even length: b_base < cg_full, i < cg_mod <= cg_full)
-        const int i = (col + cz.b_rot[zb]) & (A.cg_mod - 1);
+        const int i = (col + A.col0 + cz.b_rot[zb]) & (A.cg_mod - 1);
         scol = cz.b_base[zb] + i;
         if (scol >= A.cg_full) scol -= A.cg_full;
         if (A.cg_band_len > 0) {
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(G::NT, G::MINW) void col_pass_kernel(const ColPassA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     col_pass_body<G, MODE, SNT, GS, ColZ, RC>(A, gin, gout, ld_win, ld_win2, st_win, st_win2, st_rowmap, tw, tw_full, cz,
                                     __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, blockIdx.x,
-                                    blockIdx.y, blockIdx.z, smem);
+                                    blockIdx.y, blockIdx.z + A.z0, smem);
 }
 
 constexpr int kColPassMinLog = 2;
