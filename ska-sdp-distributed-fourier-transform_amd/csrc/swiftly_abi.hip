@@ -491,14 +491,23 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     const int b_i_rows = y2_major ? n1 : 1, b_o_rows = y2_major ? 1 : n2;  // pass B: row of (i = y2, o = k1)
     // Chunked, two-stream form (r4; K2 = the gathered forward transform of several facets): the batch items are worked
     // on in chunks of `zc` items x `Wc` columns whose two passes run back to back, chunks alternating between two
-    // internal streams, each stream re-using ONE chunk-sized slot of the scratch.  The intermediate of a chunk (n * Wc *
-    // zc * 8 bytes, 67 MB for a 32768-point transform of 256 columns) is written and re-read while it sits in the 256 MiB
-    // Infinity Cache, and because a slot is overwritten by the stream's next chunk its dirty lines never have to reach
-    // HBM; pass A of one chunk (HBM reads) runs next to pass B of the other (cache reads).  SWIFTLY_K2_CHUNK="cols[,items]"
-    // (0 = off).
+    // internal streams, each stream re-using ONE chunk-sized slot of the scratch: pass A of one chunk (HBM reads, scratch
+    // writes) runs next to pass B of the other (scratch reads that can still hit the 256 MiB Infinity Cache).  Measured on
+    // the 64k workload (interleaved repeats on one box, gpurun_out/s3k, s3l): 40.7 -> 39.7 ms per pass with chunks of
+    // 2 facets x 256 columns (134 MB); 1 x 512: 40.0; 1 x 256, 4 x 128, 2 x 128, 3 x 256, 2 x 512: no gain or worse.  The
+    // gain is the overlap of the two kinds of pass, not cache residency: pure-copy stand-ins of the two passes bound it at
+    // 8 % of K2 (tools/mall_pipe.hip) -- the cache does not absorb the scratch WRITES.
+    // SWIFTLY_K2_CHUNK = "cols[,items]" | 0 (off) | unset: chunks of ~128 MB when the whole intermediate exceeds 256 MB.
     static const char* chunk_env = getenv("SWIFTLY_K2_CHUNK");
-    static const int chunk_cols = chunk_env ? atoi(chunk_env) : 0;
-    static const int chunk_items = (chunk_env && strchr(chunk_env, ',')) ? std::max(1, atoi(strchr(chunk_env, ',') + 1)) : 1;
+    int chunk_cols = chunk_env ? atoi(chunk_env) : -1;
+    int chunk_items = (chunk_env && strchr(chunk_env, ',')) ? std::max(1, atoi(strchr(chunk_env, ',') + 1)) : 1;
+    if (chunk_cols < 0) {  // automatic
+        chunk_cols = 0;
+        if (scratch_bytes > (size_t(256) << 20) && W >= 256) {
+            chunk_cols = 256;
+            chunk_items = (int)std::max<uint64_t>(1, (uint64_t(128) << 20) / (n * 256 * sizeof(cx<float>)));
+        }
+    }
     if (chunk_cols >= 64 && gathered && !(cz.flags & kZColScatter) && !c.gs && qmul == 0 && slab == (long long)W &&
         (nb > chunk_items || W > chunk_cols) && !own) {
         const int Wc = std::min<int>((chunk_cols / 64) * 64, W), zc = std::min(chunk_items, nb);

@@ -294,6 +294,46 @@ def test_forward_default_axis_with_plan_serves_any_order():
     assert relrms(got[5], so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))) < 2e-5
 
 
+@pytest.mark.parametrize("order", ["ascending", "descending", "shuffled"])
+def test_forward_planned_wave_prefetch_is_bit_identical(order):
+    """The planned-wave prefetch of SwiftlyForward (K2 of the predicted next wave on the core's side stream while the
+    subgrid side of the current one runs) does not change a single bit, whatever order the waves are asked for in --
+    a wrong prediction only leaves a prefetched buffer unused -- and the oracle agrees with what it serves."""
+    torch, sw, cfg, facet_cfgs, facets, sg_cfgs = _small_rows_problem(seed=77)
+    if not cfg.core.supports_band_pipeline(torch.complex64):
+        pytest.skip("band pipeline not available")
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off1, []).append(c)
+    keys = sorted(waves)
+    if order == "descending":
+        keys = keys[::-1]
+    elif order == "shuffled":
+        keys = [keys[i] for i in (2, 0, 3, 1)]
+
+    def run(prefetch):
+        old = sw.api._PREFETCH
+        sw.api._PREFETCH = prefetch
+        try:
+            fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
+            out = {k: fwd.get_wave(waves[k]).cpu().numpy() for k in keys}
+            used = fwd.__dict__.get("_prefetched", "never") != "never"
+        finally:
+            sw.api._PREFETCH = old
+        torch.cuda.synchronize()
+        return out, used
+
+    plain, used0 = run(False)
+    ahead, used1 = run(True)
+    assert not used0 and used1  # the second run really went through the prefetch
+    for k in keys:
+        assert numpy.array_equal(plain[k], ahead[k]), (order, k)
+    so = sep.SeparableOracle(core64()[1], [orc.CoverItem(c.off0, c.off1, c.size) for c in facet_cfgs],
+                             [sep.facet_vectors(77 + j, 352, rank=2) for j in range(3)])
+    c = waves[keys[1]][1]
+    assert relrms(ahead[keys[1]][1], so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))) < 2e-5
+
+
 @pytest.mark.parametrize("lru_backward", [1, 2])
 def test_backward_default_axis_with_plan_stages_single_adds(lru_backward):
     """SwiftlyBackward(subgrid_configs=plan) without wave_axis picks the band schedule for complex64 subgrids;
