@@ -5,6 +5,10 @@ out=$1; wl=${2:-64k-sparse}
 mkdir -p "$out"
 export TMPDIR=/tmp
 here=$(pwd)
+# (r4 session 3) every kernel ALONE on the chip: the planned-wave prefetch and the two-stream K2 chunks are switched off for
+# the collection, so that a launch is one kernel of one wave and its duration is not shared with a concurrent kernel; the
+# production pass overlaps them (bench.py's ms_per_step) -- byte counts per kernel do not depend on the schedule
+export SWIFTLY_PREFETCH=0 SWIFTLY_K2_CHUNK=0
 cmd="python $here/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-backward"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$here/$out/kt" -o kt -- $cmd > "$here/$out/kt.log" 2>&1 )
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$here/$out/pf" -o pf -- $cmd > "$here/$out/pf.log" 2>&1 )
