@@ -136,9 +136,18 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
         const bool inv = a.conj_ld && a.conj_st, fwd = !a.conj_ld && !a.conj_st;
         if constexpr (PAIR) {
             if (a.band_len > 0 && a.ld_win && inv) {
-                SWF_TRY_SEG(true, 1, 16, 1)
-                SWF_TRY_SEG(true, 1, 22, 1)
-                SWF_TRY_SEG(true, 1, 24, 1)
+                // forward K1: geometry with the twiddle preload (RGeoPre)
+                using GP = RGeoPre<G::LOGN, G::LOGP, G::SPLIT>;
+#define SWF_TRY_SEG_PRE(NS)                                                                    \
+    if (run <= NS) {                                                                           \
+        a.seg_rot = first;                                                                     \
+        launch_band_inst<GP, PAIR, true, 1, NS, 1>(a, blocks, tw14, tw_full, s);               \
+        return (int)hipGetLastError();                                                         \
+    }
+                SWF_TRY_SEG_PRE(16)
+                SWF_TRY_SEG_PRE(22)
+                SWF_TRY_SEG_PRE(24)
+#undef SWF_TRY_SEG_PRE
             } else if (a.band_len < 0 && fwd) {
                 SWF_TRY_SEG(false, 2, 13, 0)
                 SWF_TRY_SEG(false, 2, 16, 0)
@@ -236,9 +245,10 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 1>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 16, true, 1>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 22, true, 1>();
-        if (!rcb) rcb = init_band_pair<BandGeo5, true, 1, 24, true, 1>();
+        using BandGeo5Pre = RGeoPre<14, 5, true>;
+        if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 16, true, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 22, true, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 24, true, 1>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false, 1>();

@@ -336,7 +336,8 @@ struct lean_tw_of<G, std::enable_if_t<G::LEAN_TW>> {
 };
 
 template <typename R, int LOGR, int NB, int U, int PTOT, int N, bool LEAN = false>
-__device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx) {
+__device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx,
+                                               const cx<R>* pre = nullptr) {
     constexpr int RAD = 1 << LOGR;
     if constexpr (SWF_TW_TWO_FACTOR && LOGR >= 2) {
         constexpr int LQ = (LOGR + 1) / 2, Q = 1 << LQ, NH = RAD / Q;
@@ -377,7 +378,7 @@ __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __
         cx<R> wp[LOGR];
         static_for<0, LOGR>([&](auto bI) {
             constexpr int b = decltype(bI)::value;
-            wp[b] = tw[(kidx << b) & (N - 1)];
+            wp[b] = pre ? pre[b] : tw[(kidx << b) & (N - 1)];
         });
         static_for<1, RAD>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
@@ -406,7 +407,8 @@ __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __
 
 // One Stockham phase, compute part: twiddle + in-register DFTs.
 template <class G, typename R, int LOGNS, int LOGR>
-__device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<R>* __restrict__ tw) {
+__device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<R>* __restrict__ tw,
+                                              const cx<R>* pre = nullptr) {
     constexpr int RAD = 1 << LOGR, NB = G::P / RAD;
     static_for<0, NB>([&](auto uI) {
         constexpr int u = decltype(uI)::value;
@@ -414,11 +416,26 @@ __device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<
             int j = t + u * G::T;
             int k = j & ((1 << LOGNS) - 1);
             // angle = -2 pi k r / (Ns * RAD)  ->  table index k * N/(Ns*RAD) * r
-            twiddle_inputs<R, LOGR, NB, u, G::P, G::N, lean_tw_of<G>::value>(x, tw, k << (G::LOGN - LOGNS - LOGR));
+            twiddle_inputs<R, LOGR, NB, u, G::P, G::N, lean_tw_of<G>::value>(x, tw, k << (G::LOGN - LOGNS - LOGR),
+                                                                             NB == 1 ? pre : nullptr);
         }
         fft_reg<R, LOGR, NB, u, G::P>(x);
     });
 }
+// SWF_TW_PRELOAD (default 1; geometries with `static constexpr bool PRELOAD_TW = true`, r4c: RGeoPre = the forward K1): the LOGR table values the next phase's
+// inter-phase twiddles are built from are requested BEFORE the exchange that precedes the phase, so that their latency
+// (an L2 hit: the table is shared by every workgroup) hides under the exchange instead of following its last barrier
+#ifndef SWF_TW_PRELOAD
+#define SWF_TW_PRELOAD 1
+#endif
+template <class G, class = void>
+struct preload_tw_of {
+    static constexpr bool value = false;
+};
+template <class G>
+struct preload_tw_of<G, std::enable_if_t<G::PRELOAD_TW>> {
+    static constexpr bool value = SWF_TW_PRELOAD != 0;
+};
 
 // One Stockham phase, scatter part: f(e, value) for every output element of
 // this thread, e = natural-order index within the phase's output array.
@@ -535,15 +552,27 @@ __device__ __forceinline__ void phase_exchange_impl(cx<R> (&x)[G::P], int t, int
 // order); the last phase hands (natural-order output index, value) to `fin`.
 template <class G, typename R, int LOGNS, class F>
 __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds,
-                                           const cx<R>* __restrict__ tw, F&& fin) {
+                                           const cx<R>* __restrict__ tw, F&& fin, const cx<R>* pre = nullptr) {
     constexpr int REM = G::LOGN - LOGNS;
     constexpr int LOGR = REM < G::LOGP ? REM : G::LOGP;
-    phase_compute<G, R, LOGNS, LOGR>(x, t, tw);
+    phase_compute<G, R, LOGNS, LOGR>(x, t, tw, pre);
     if constexpr (LOGNS + LOGR == G::LOGN) {
         phase_scatter<G, R, LOGNS, LOGR>(x, t, fin);
     } else {
-        phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
-        fft_phases<G, R, LOGNS + LOGR>(x, t, rb, rowfast, lds, tw, fin);
+        constexpr int NLOGNS = LOGNS + LOGR, NREM = G::LOGN - NLOGNS, NLOGR = NREM < G::LOGP ? NREM : G::LOGP;
+        if constexpr (preload_tw_of<G>::value && G::P == (1 << NLOGR) && NLOGR >= 5) {
+            cx<R> nxt[NLOGR];
+            const int kidx = (t & ((1 << NLOGNS) - 1)) << (G::LOGN - NLOGNS - NLOGR);
+            static_for<0, NLOGR>([&](auto bI) {
+                constexpr int b = decltype(bI)::value;
+                nxt[b] = tw[(kidx << b) & (G::N - 1)];
+            });
+            phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
+            fft_phases<G, R, NLOGNS>(x, t, rb, rowfast, lds, tw, fin, nxt);
+        } else {
+            phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
+            fft_phases<G, R, NLOGNS>(x, t, rb, rowfast, lds, tw, fin);
+        }
     }
 }
 
@@ -554,8 +583,19 @@ __device__ __forceinline__ void fft_phases_pair(cx<R> (&x)[G::P], int t, void* l
     constexpr int LOGR1 = G::LOGN % G::LOGP;
     static_assert(LOGR1 > 0 && LOGR1 < G::LOGP, "needs a short first phase");
     phase_compute<G, R, 0, LOGR1>(x, t, tw);
-    phase_exchange<G, R, 0, LOGR1, true>(x, t, 0, false, lds);
-    fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin);
+    if constexpr (preload_tw_of<G>::value && G::LOGP >= 5 && G::LOGN - LOGR1 >= G::LOGP) {
+        cx<R> nxt[G::LOGP];
+        const int kidx = (t & ((1 << LOGR1) - 1)) << (G::LOGN - LOGR1 - G::LOGP);
+        static_for<0, G::LOGP>([&](auto bI) {
+            constexpr int b = decltype(bI)::value;
+            nxt[b] = tw[(kidx << b) & (G::N - 1)];
+        });
+        phase_exchange<G, R, 0, LOGR1, true>(x, t, 0, false, lds);
+        fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin, nxt);
+    } else {
+        phase_exchange<G, R, 0, LOGR1, true>(x, t, 0, false, lds);
+        fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin);
+    }
 }
 
 }  // namespace swf

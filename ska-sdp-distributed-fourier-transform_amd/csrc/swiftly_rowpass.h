@@ -80,6 +80,14 @@ struct RGeo {
     static constexpr size_t LDS_BYTES = (size_t)PITCH * ELEM;
 };
 
+// the same geometry with the inter-phase twiddle values requested before the exchange that precedes their phase
+// (swiftly_fft.h, preload_tw_of): r4c, the forward K1 instances -- 1.690 -> 1.625 ms per facet (same box); the backward
+// finish instances sit at 128 VGPRs and do not gain (1.80 -> 1.82 ms), so they keep the plain geometry
+template <int LOGN_, int LOGP_, bool SPLIT_, bool PAD_ = true>
+struct RGeoPre : RGeo<LOGN_, LOGP_, SPLIT_, PAD_> {
+    static constexpr bool PRELOAD_TW = true;
+};
+
 __device__ const float kRowOne = 1.f;
 
 // non-temporal accesses in the long-row kernel: loads measured much slower (the input row is read by two
@@ -425,6 +433,10 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
         const unsigned base8 = (unsigned)((2 * t + A.ld_a + (N >> 1) + rot) & (N - 1)) << 3;
+        // (r4c) the inter-half twiddle of the odd half is requested FIRST: it used to follow the last data load and its
+        // L2 latency was fully exposed (load, s_waitcnt vmcnt(0))
+        f32x4 wt_first = {1.f, 0.f, 1.f, 0.f};
+        if constexpr (preload_tw_of<G>::value) wt_first = *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
         static_for<0, R1>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
             cx<float> a[2][2];  // [q][u]
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         SWF_TRACE_POINT(1);
 #endif
         if (h) {  // uniform: odd outputs need W_N^j, j = 2t + u + SEG r:  W_N^(2t+u) * W_64^(2r)
-            const f32x4 wt = *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
+            const f32x4 wt = preload_tw_of<G>::value ? wt_first : *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
             const cx<float> w0 = {wt.x, wt.y}, w1 = {wt.z, wt.w};
             static_for<0, R1>([&](auto rI) {
                 constexpr int r = decltype(rI)::value;
