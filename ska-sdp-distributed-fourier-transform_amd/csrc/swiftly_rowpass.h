@@ -433,10 +433,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
         const unsigned base8 = (unsigned)((2 * t + A.ld_a + (N >> 1) + rot) & (N - 1)) << 3;
-        // (r4c) the inter-half twiddle of the odd half is requested FIRST: it used to follow the last data load and its
-        // L2 latency was fully exposed (load, s_waitcnt vmcnt(0))
-        f32x4 wt_first = {1.f, 0.f, 1.f, 0.f};
-        if constexpr (preload_tw_of<G>::value) wt_first = *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
         static_for<0, R1>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
             cx<float> a[2][2];  // [q][u]
@@ -494,7 +490,9 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         SWF_TRACE_POINT(1);
 #endif
         if (h) {  // uniform: odd outputs need W_N^j, j = 2t + u + SEG r:  W_N^(2t+u) * W_64^(2r)
-            const f32x4 wt = preload_tw_of<G>::value ? wt_first : *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
+            // (r4c: requesting this value before the data loads -- an asm statement, the compiler sinks an ordinary load back to
+            // here -- was measured SLOWER, 1.685 vs 1.653 ms per facet: four more VGPRs live through the load phase)
+            const f32x4 wt = *reinterpret_cast<const f32x4*>(tw_full + 2 * t);
             const cx<float> w0 = {wt.x, wt.y}, w1 = {wt.z, wt.w};
             static_for<0, R1>([&](auto rI) {
                 constexpr int r = decltype(rI)::value;
