@@ -240,3 +240,29 @@ def test_band_range_and_row_sources_for_a_padded_facet_of_3_times_2_to_the_k():
             rows = numpy.flatnonzero(tab[lvl] >= 0)
             got[rows] += flat[tab[lvl, rows] & 0xFFFFF]
     numpy.testing.assert_array_equal(got, want)
+
+
+def test_planned_wave_prediction_follows_the_walk_direction():
+    """SwiftlyForward._predict_next_wave (host logic of the planned-wave prefetch): the sorted successor of the wave
+    being served, the predecessor once the caller walks the plan downwards, nothing at either end, for an unplanned
+    key, without a plan or with the prefetch switched off."""
+    fwd = object.__new__(api.SwiftlyForward)  # the predictor only reads the plan bookkeeping
+    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (30, 10, 20, 10, 40)]
+    fwd._planned_keys = {10, 20, 30, 40}
+    assert fwd._predict_next_wave(10) == 20
+    assert fwd._predict_next_wave(20) == 30
+    assert fwd._predict_next_wave(40) is None      # end of the plan
+    assert fwd._predict_next_wave(30) == 20        # 40 -> 30: the caller turned round
+    assert fwd._predict_next_wave(20) == 10
+    assert fwd._predict_next_wave(10) is None      # start of the plan, walking down
+    assert fwd._predict_next_wave(20) == 30        # up again
+    assert fwd._predict_next_wave(25) is None      # not a planned wave
+    off = object.__new__(api.SwiftlyForward)
+    off._plan = None
+    assert off._predict_next_wave(10) is None
+    old = api._PREFETCH
+    api._PREFETCH = False
+    try:
+        assert fwd._predict_next_wave(10) is None
+    finally:
+        api._PREFETCH = old
