@@ -286,8 +286,6 @@ void swiftly_hip_destroy(swiftly_hip_t* h) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
         }
-    for (hipEvent_t ev : h->chunk_ev)
-        if (ev) (void)hipEventDestroy(ev);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -487,6 +485,11 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     // comb costs 7 % on the write side and nothing on the read side): pass A 425 -> 395 us per wave as a pure copy.
     // SWIFTLY_SCRATCH_LAYOUT=0 restores the r1-r3 layout.
     static const bool y2_major = !(getenv("SWIFTLY_SCRATCH_LAYOUT") && atoi(getenv("SWIFTLY_SCRATCH_LAYOUT")) == 0);
+    // Tile-major scratch (r5, SWIFTLY_SCRATCH_TILE=1): [item][64-column tile][row][64] instead of [item][row][columns], so
+    // that the n1 rows a pass-A workgroup writes are ONE contiguous run of n1 * 512 bytes instead of n1 pieces of 512
+    // bytes one scratch row apart
+    static const bool tile_major = getenv("SWIFTLY_SCRATCH_TILE") && atoi(getenv("SWIFTLY_SCRATCH_TILE")) != 0;
+    const bool tiles = tile_major && !f64 && qmul == 0 && l1 < 10 && l2 < 10;
     const int a_i_rows = y2_major ? 1 : n2, a_o_rows = y2_major ? n1 : 1;  // pass A: row of (e = k1, o = y2)
     const int b_i_rows = y2_major ? n1 : 1, b_o_rows = y2_major ? 1 : n2;  // pass B: row of (i = y2, o = k1)
     // Chunked, two-stream form (r4; K2 = the gathered forward transform of several facets): the batch items are worked
@@ -523,24 +526,44 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
             }
             // (events are per call: two host threads may drive the same handle on different streams)
             hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+            auto drop_events = [&ev]() {
+                for (hipEvent_t& e : ev)
+                    if (e) {
+                        (void)hipEventDestroy(e);
+                        e = nullptr;
+                    }
+            };
             for (hipEvent_t& e : ev) {
                 he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-                if (he != hipSuccess) return fail(SWIFTLY_ERR_HIP, "hipEventCreateWithFlags: %s", hipGetErrorString(he));
+                if (he != hipSuccess) {
+                    e = nullptr;
+                    drop_events();
+                    return fail(SWIFTLY_ERR_HIP, "hipEventCreateWithFlags: %s", hipGetErrorString(he));
+                }
             }
-            (void)hipEventRecord(ev[0], st);
-            for (hipStream_t s2 : h->chunk_st) (void)hipStreamWaitEvent(s2, ev[0], 0);
+            // fork: the chunk streams start behind everything queued on `st` (a failed record / wait would let them
+            // run ahead of the producer of the input: nothing has been launched yet, so just report it)
+            he = hipEventRecord(ev[0], st);
+            for (hipStream_t s2 : h->chunk_st)
+                if (he == hipSuccess) he = hipStreamWaitEvent(s2, ev[0], 0);
+            if (he != hipSuccess) {
+                drop_events();
+                return fail(SWIFTLY_ERR_HIP, "chunked four-step, fork: %s", hipGetErrorString(he));
+            }
             int i = 0;
             for (int z0 = 0; z0 < nb && !rc; z0 += zc) {
                 const int nz = std::min(zc, nb - z0);
                 for (int c0 = 0; c0 < W && !rc; c0 += Wc, i++) {
                     const int wc = std::min(Wc, W - c0);
                     hipStream_t s2 = h->chunk_st[i & 1];
-                    // item z of the launch sits at slot + (z - z0) * n * Wc: the kernels add z * bs, so shift the base back
-                    cx<float>* slot = (cx<float>*)scratch + (size_t)(i & 1) * slot_elems - (long long)z0 * (long long)(n * Wc);
+                    // item z of the launch sits at slot + (z - z0) * n * Wc (raw_z0: the kernels address the scratch
+                    // with the item index relative to the launch's first item)
+                    cx<float>* slot = (cx<float>*)scratch + (size_t)(i & 1) * slot_elems;
                     ColPassArgs A = c;
                     A.scratch_nt = 0;
-                    A.ncols = wc; A.col0 = c0; A.z0 = z0;
+                    A.ncols = wc; A.col0 = c0; A.z0 = z0; A.raw_z0 = z0;
                     A.out = slot; A.out_pitch = (unsigned)Wc; A.out_bs = (long long)(n * Wc);
+                    if (tiles) { A.out_pitch = 64; A.out_ts = (long long)n * 64; }
                     A.out_bdiv = 0; A.out_bs_hi = 0;
                     A.ld_mul = n2;
                     A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
@@ -554,8 +577,9 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
                     B.scratch_nt = 0;
                     ColZ zb = cz;
                     zb.flags &= ~(kZColGather | kZLoadB | kZLoadAF);  // the scratch is read plainly
-                    B.ncols = wc; B.col0 = 0; B.z0 = z0;
+                    B.ncols = wc; B.col0 = 0; B.z0 = z0; B.raw_z0 = z0;
                     B.in = slot; B.in_pitch = (unsigned)Wc; B.in_bs = (long long)(n * Wc);
+                    if (tiles) { B.in_pitch = 64; B.in_ts = (long long)n * 64; }
                     B.in_bdiv = 0; B.in_bs_hi = 0;
                     B.in_i_rows = b_i_rows; B.in_o_rows = b_o_rows;
                     B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr; B.gs = 0;
@@ -568,11 +592,17 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
                     rc = launch_col_checked(l2, 1, B, zb, n1, nz, s2);
                 }
             }
+            // join: `st` continues behind both chunk streams.  If the join cannot be queued, the consumer of the output
+            // on `st` must not start early: wait for the chunk streams on the host instead
             for (int k = 0; k < 2; k++) {
-                (void)hipEventRecord(ev[1 + k], h->chunk_st[k]);
-                (void)hipStreamWaitEvent(st, ev[1 + k], 0);
+                he = hipEventRecord(ev[1 + k], h->chunk_st[k]);
+                if (he == hipSuccess) he = hipStreamWaitEvent(st, ev[1 + k], 0);
+                if (he != hipSuccess) {
+                    (void)hipStreamSynchronize(h->chunk_st[k]);
+                    if (!rc) rc = fail(SWIFTLY_ERR_HIP, "chunked four-step, join: %s", hipGetErrorString(he));
+                }
             }
-            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+            drop_events();
             return rc;
         }
     }
@@ -589,6 +619,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.ncols = wc;
         A.in = c.in + c0;
         A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)Ws; A.out_bs = (long long)(n * Ws);
+        if (tiles && Ws % 64 == 0) { A.out_pitch = 64; A.out_ts = (long long)n * 64; }
         A.out_bdiv = 0; A.out_bs_hi = 0;
         A.ld_mul = n2;
         A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
@@ -610,6 +641,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         zb.flags &= ~(kZColGather | kZLoadB | kZLoadAF);  // the scratch is read plainly
         B.ncols = wc;
         B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)Ws; B.in_bs = (long long)(n * Ws);
+        if (tiles && Ws % 64 == 0) { B.in_pitch = 64; B.in_ts = (long long)n * 64; }
         B.in_bdiv = 0; B.in_bs_hi = 0;
         B.in_i_rows = b_i_rows; B.in_o_rows = b_o_rows;
         B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr; B.gs = 0;

@@ -84,9 +84,9 @@ struct swiftly_hip {
     // float64 arithmetic in the column passes of the band pipelines (K2, K3 and their backward mirrors; complex64 data):
     // 0 (default: float32 arithmetic everywhere) | 1 (swiftly_hip_set_column_precision, env SWIFTLY_COL_F64)
     int col_f64 = 0;
-    // two internal streams + events of the chunked four-step (col_transform): created on first use, under `chunk_mu`
+    // two internal streams of the chunked four-step (col_transform): created on first use, under `chunk_mu` (the fork /
+    // join events are per call: two host threads may drive one handle on different streams)
     hipStream_t chunk_st[2] = {nullptr, nullptr};
-    hipEvent_t chunk_ev[3] = {nullptr, nullptr, nullptr};
     std::mutex chunk_mu;
 };
 

@@ -70,6 +70,9 @@ struct ColPassArgs {
     // start), and the column gather sees column col0 + (tile column) -- the launch covers columns [col0, col0 + ncols) of
     // the logical one, with the un-gathered side's pointer pre-shifted by col0
     int z0, col0;
+    // raw (scratch) accesses address item z at (z - raw_z0) * {in,out}_bs: the scratch slot of a sub-launch holds only the
+    // launch's own items
+    int raw_z0;
     int full_logn;                  // log2 of the full (power-of-two) transform length of a decomposed transform
     // Sub-transform j of a length n = Q * 2^full_logn transform behind the radix-Q pass of swiftly_mixed.h (0 = off):
     // the input is the plain scratch of that pass (ld_plain: logical row = plain index, no map), the store map refers to
@@ -78,6 +81,10 @@ struct ColPassArgs {
     // load: raw -> row = o*in_o_rows + i*in_i_rows ; mapped -> plain index i*ld_mul + o through the map
     int raw_ld;
     int in_i_rows, in_o_rows;
+    // raw accesses in TILE-MAJOR order (r5, four-step scratch): the 64-column tile bx of an item starts at
+    // bx * {in,out}_ts elements and its rows are {in,out}_pitch (= 64) apart, so that a workgroup's rows are one
+    // contiguous run; 0 = plain row-major [row][column]
+    long long in_ts, out_ts;
     int ld_mul, ld_a, ld_len, ld_c, ld_mod;
     const float* ld_win;
     const float* ld_win2;
@@ -268,13 +275,15 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
     st_a = (cz.flags & kZStoreAF) ? t_fsta : st_a;
     st_a = (cz.flags & kZStoreAB) ? t_bsta : st_a;
     const long long in_off =
-        A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs : (long long)z * A.in_bs;
-    const cx<float>* __restrict__ in = gin + (GS ? 0ll : in_off) + lcol;
+        A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs
+                      : (long long)(RAW_LD ? z - A.raw_z0 : z) * A.in_bs;
+    const cx<float>* __restrict__ in =
+        gin + (GS ? 0ll : in_off) + ((RAW_LD && A.in_ts) ? (long long)bx * A.in_ts + clane : (long long)lcol);
     const long long out_off =
         (cz.flags & kZOutB) ? cz.b_out_off[zb] + (long long)zf * cz.b_out_fs[zb]
         : A.out_bdiv > 0 ? (long long)(z / A.out_bdiv) * A.out_bs_hi + (long long)(z % A.out_bdiv) * A.out_bs
-                         : (long long)z * A.out_bs;
-    cx<float>* __restrict__ out = gout + out_off + ocol;
+                         : (long long)(RAW_ST ? z - A.raw_z0 : z) * A.out_bs;
+    cx<float>* __restrict__ out = gout + out_off + ((RAW_ST && A.out_ts) ? (long long)bx * A.out_ts + clane : (long long)ocol);
     const RC sg_ld = A.conj_ld ? (RC)-1 : (RC)1;
     const RC sg_st = A.conj_st ? (RC)-1 : (RC)1;
     const RC col_w = (A.col_win && live) ? (RC)A.col_win[col] : (RC)1;

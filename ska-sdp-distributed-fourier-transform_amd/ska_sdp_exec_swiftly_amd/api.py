@@ -909,6 +909,7 @@ class SwiftlyForward:
 
     def _get_wave_columns(self, off1):
         """K2: ``Q[F, rows, m]`` for the subgrid wave ``off1`` (LRU cached like the reference's per-off0 columns)."""
+        self._take_prefetched(off1)
         hit = self.lru.get(("b", off1))
         if hit is None:
             if self._plan is not None and int(off1) not in self._planned_keys:
@@ -939,6 +940,7 @@ class SwiftlyForward:
     def _wave_Q(self, off1):
         """(Q workspace, rowmap, n_rows, needs computing) of wave ``off1`` (LRU cached like _get_wave_columns)"""
         torch = _torch()
+        self._take_prefetched(off1)
         hit = self.lru.get(("b", off1))
         if hit is not None:
             return hit[0], hit[1], hit[0].shape[1], False
@@ -952,30 +954,49 @@ class SwiftlyForward:
 
     # -- planned-wave prefetch (r4): K2 of the NEXT planned wave on the core's side stream ------------------------
     def _predict_next_wave(self, off1):
-        """the planned wave a caller that walks the plan monotonically asks for after ``off1`` (None: no plan / end)"""
-        if self._plan is None or not _PREFETCH:
+        """the planned wave a caller that walks the plan asks for after ``off1`` (None: no plan / end / prefetch off).
+        Positions are those of the PLAN (order of first appearance of the wave keys in ``subgrid_configs``): a caller
+        that walks its own plan forwards or backwards is predicted whatever the numeric order of the keys; a repeated
+        key keeps the direction of the walk."""
+        if self._plan is None or not _PREFETCH or self.__dict__.get("_prefetch_off"):
             return None
         order = self.__dict__.get("_wave_order")
         if order is None:
-            order = self.__dict__["_wave_order"] = sorted(self._planned_keys)
+            order = self.__dict__["_wave_order"] = list(dict.fromkeys(int(sg.off1) for sg in self._plan))
             self.__dict__["_wave_pos"] = {k: i for i, k in enumerate(order)}
         pos = self._wave_pos.get(int(off1))
         if pos is None:
             return None
         last = self.__dict__.get("_last_wave_pos")
-        step = -1 if last is not None and pos < last else 1  # follows the direction of the last two requests
+        step = self.__dict__.get("_wave_step", 1)
+        if last is not None and pos != last:
+            step = 1 if pos > last else -1
         self.__dict__["_last_wave_pos"] = pos
+        self.__dict__["_wave_step"] = step
         nxt = pos + step
         return order[nxt] if 0 <= nxt < len(order) else None
 
     def _take_prefetched(self, off1):
-        """hand a prefetched ``Q`` of wave ``off1`` over to the LRU cache (the current stream waits for its K2)"""
+        """hand a prefetched ``Q`` of wave ``off1`` over to the LRU cache (the current stream waits for its K2).  A
+        prefetched wave nobody asked for is a misprediction: its buffer is dropped, and after two of them the
+        prefetch is switched off for this object (a wasted K2 per wave costs more than the overlap gains)."""
         pf = self.__dict__.get("_prefetched")
-        if pf is None or pf[0] != int(off1):
+        if pf is None:
+            return
+        if pf[0] != int(off1):
+            if self.lru.get(("b", off1)) is None:  # a different wave has to be computed: the guess was wrong
+                self.__dict__["_prefetched"] = None
+                missed = self.__dict__["_prefetch_missed"] = self.__dict__.get("_prefetch_missed", 0) + 1
+                if missed >= 2:
+                    self.__dict__["_prefetch_off"] = True
             return
         self.__dict__["_prefetched"] = None
         if self.lru.get(("b", off1)) is None:
-            _torch().cuda.current_stream(self.core.device).wait_event(pf[3])
+            cur = _torch().cuda.current_stream(self.core.device)
+            cur.wait_event(pf[3])
+            # Q was allocated under the side stream and is read by kernels of the caller's stream from now on: tell the
+            # caching allocator, so that a freed Q is not handed to the next side-stream allocation while `cur` reads it
+            pf[1].record_stream(cur)
             self.lru.set(("b", off1), (pf[1], pf[2]))
 
     def _prefetch_wave(self, off1):
@@ -1010,7 +1031,6 @@ class SwiftlyForward:
         core = self.core
         self._check_planned(sgs)
         bands = self.prepare_all_facets()
-        self._take_prefetched(sgs[0].off1)
         Q, rowmap, n_rows, compute = self._wave_Q(sgs[0].off1)
         nxt = self._predict_next_wave(sgs[0].off1)
         if not compute:
@@ -1377,9 +1397,12 @@ class SwiftlyBackward:
 
     def accumulate_wave(self, sgs, parts):
         """``accumulate_column`` (reference api_helper.py:142-152) for a wave:
-        add the contributions ``parts[F, S, m, m]`` of subgrids sharing ``off0``
-        into that column's partial sums (LRU cache keyed by ``off0``, reference
-        api.py:402-438); evicted columns go to the facet accumulators."""
+        add the contributions ``parts[F, S, m, m]`` of subgrids sharing the wave key
+        into that wave's partial sums.  Grouping key: ``off0`` with ``wave_axis=0`` (the reference's schedule: LRU
+        cache keyed by ``off0``, reference api.py:402-438; evicted columns go to the facet accumulators), ``off1``
+        with ``wave_axis=1`` (band schedule: the wave is folded straight into the band accumulators).  With
+        ``wave_axis=None`` the schedule is fixed by the first data this object sees (:py:meth:`_resolve_axis`); a wave
+        whose subgrids do not share the key of the resolved schedule raises ``ValueError``."""
         self._resolve_axis(parts)
         torch = _torch()
         core = self.core
@@ -1388,6 +1411,8 @@ class SwiftlyBackward:
         if self.wave_axis == 1:
             return self._accumulate_band(sgs[0].off1, [(sgs, parts)])
         off0 = sgs[0].off0
+        if any(int(sg.off0) != int(off0) for sg in sgs):
+            raise ValueError(f"reference schedule (wave_axis=0): all subgrids of a wave must share off0={off0}")
         col = self.lru.get(off0)
         if col is None:
             col = torch.zeros((F, m, yN), dtype=parts.dtype, device=core.device)
@@ -1403,7 +1428,8 @@ class SwiftlyBackward:
 
     def accumulate_chunks(self, off0, chunks):
         """:py:meth:`accumulate_wave` for contributions that arrive in several pieces (one per source rank of
-        the multi-GPU exchange): ``chunks = [(subgrid configs, parts[F, S_c, m, m]), ...]``, all of column ``off0``."""
+        the multi-GPU exchange): ``chunks = [(subgrid configs, parts[F, S_c, m, m]), ...]``, all of wave ``off0`` --
+        the wave KEY: the subgrids' ``off0`` with ``wave_axis=0``, their ``off1`` with ``wave_axis=1`` (checked)."""
         if self._auto_axis and len(chunks):
             self._resolve_axis(chunks[0][1])
         torch = _torch()
@@ -1470,6 +1496,16 @@ class SwiftlyBackward:
         chunks = [(sgs, parts) for sgs, parts in chunks if len(sgs)]
         if not chunks:
             return None
+        for sgs, _parts in chunks:
+            # (r4 advice) the band schedule folds a wave under ONE off1: a caller that follows the reference's per-off0
+            # flow (accumulate_column, api_helper.py:142-152) on an object whose schedule resolved to wave_axis=1 must
+            # hear about it instead of getting every subgrid placed at the first one's off1
+            bad = [sg for sg in sgs if int(sg.off1) != int(off1)]
+            if bad:
+                raise ValueError(
+                    f"band schedule (wave_axis=1): all subgrids of a wave must share off1={off1}, got off1={bad[0].off1}; "
+                    "group the subgrids by off1, or construct SwiftlyBackward(wave_axis=0) for the reference's per-off0 flow"
+                )
         if self.dtype is None:
             self.dtype = chunks[0][1].dtype
         bands = self._band_state(chunks[0][1].dtype)

@@ -420,6 +420,9 @@ class DistributedForward:
                     chunk = send[pos : pos + rows * 2 * h].view(rows, 2 * h)
                     chunk[:, :w].copy_(part[:, d2 : d2 + w])
                     chunk[:, h : h + w].copy_(part[:, cb.half + d2 : cb.half + d2 + w])
+                    if w < h:  # (r4 advice) the padding columns of the two parity runs travel too: defined values
+                        chunk[:, w:h].zero_()
+                        chunk[:, h + w :].zero_()
                 pos += rows * 2 * h
         return send, in_counts, out_counts
 

@@ -243,19 +243,22 @@ def test_band_range_and_row_sources_for_a_padded_facet_of_3_times_2_to_the_k():
 
 
 def test_planned_wave_prediction_follows_the_walk_direction():
-    """SwiftlyForward._predict_next_wave (host logic of the planned-wave prefetch): the sorted successor of the wave
-    being served, the predecessor once the caller walks the plan downwards, nothing at either end, for an unplanned
-    key, without a plan or with the prefetch switched off."""
+    """SwiftlyForward._predict_next_wave (host logic of the planned-wave prefetch): the successor IN PLAN ORDER (first
+    appearance of the wave keys in subgrid_configs) of the wave being served, the predecessor once the caller walks
+    the plan backwards, the same direction after a repeated key, nothing at either end, for an unplanned key, without
+    a plan or with the prefetch switched off."""
     fwd = object.__new__(api.SwiftlyForward)  # the predictor only reads the plan bookkeeping
-    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (30, 10, 20, 10, 40)]
+    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (30, 10, 20, 10, 40)]  # plan order of the keys: 30, 10, 20, 40
     fwd._planned_keys = {10, 20, 30, 40}
+    assert fwd._predict_next_wave(30) == 10
     assert fwd._predict_next_wave(10) == 20
-    assert fwd._predict_next_wave(20) == 30
+    assert fwd._predict_next_wave(10) == 20        # the same wave again (a partial request): direction kept
     assert fwd._predict_next_wave(40) is None      # end of the plan
-    assert fwd._predict_next_wave(30) == 20        # 40 -> 30: the caller turned round
-    assert fwd._predict_next_wave(20) == 10
-    assert fwd._predict_next_wave(10) is None      # start of the plan, walking down
-    assert fwd._predict_next_wave(20) == 30        # up again
+    assert fwd._predict_next_wave(20) == 10        # 40 -> 20: the caller turned round
+    assert fwd._predict_next_wave(20) == 10        # repeated key while walking backwards
+    assert fwd._predict_next_wave(10) == 30
+    assert fwd._predict_next_wave(30) is None      # start of the plan, walking backwards
+    assert fwd._predict_next_wave(10) == 20        # forwards again
     assert fwd._predict_next_wave(25) is None      # not a planned wave
     off = object.__new__(api.SwiftlyForward)
     off._plan = None
@@ -266,3 +269,44 @@ def test_planned_wave_prediction_follows_the_walk_direction():
         assert fwd._predict_next_wave(10) is None
     finally:
         api._PREFETCH = old
+
+
+def test_mispredicted_prefetch_is_dropped_and_switches_the_prefetch_off():
+    """SwiftlyForward._take_prefetched: a prefetched wave that is not the one asked for (and the one asked for is not
+    cached) is a misprediction -- the buffer is dropped; after two of them the predictor stops predicting."""
+    fwd = object.__new__(api.SwiftlyForward)
+    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (10, 20, 30, 40)]
+    fwd._planned_keys = {10, 20, 30, 40}
+    fwd.lru = api.LRUCache(1)
+    fwd.__dict__["_prefetched"] = (20, "Q20", None, None)
+    fwd._take_prefetched(40)                       # asked for 40, 20 was prefetched
+    assert fwd.__dict__["_prefetched"] is None and fwd.__dict__["_prefetch_missed"] == 1
+    assert fwd._predict_next_wave(10) == 20        # one miss: still predicting
+    fwd.__dict__["_prefetched"] = (20, "Q20", None, None)
+    fwd.lru.set(("b", 30), ("Q30", None))
+    fwd._take_prefetched(30)                       # 30 is cached: not a miss, the prefetched wave stays
+    assert fwd.__dict__["_prefetched"][0] == 20 and fwd.__dict__["_prefetch_missed"] == 1
+    fwd._take_prefetched(40)
+    assert fwd.__dict__.get("_prefetch_off") and fwd._predict_next_wave(10) is None
+
+
+def test_backward_wave_entry_points_check_the_wave_key():
+    """(r4 advice) SwiftlyBackward.accumulate_wave / accumulate_chunks fold a wave under ONE key -- off1 in the band
+    schedule, off0 in the reference's: subgrids that do not share the key of the schedule the object resolved to must
+    raise instead of being placed at the first subgrid's offset.  (Checked before anything touches the device.)"""
+    import types
+
+    bwd = object.__new__(api.SwiftlyBackward)
+    bwd._auto_axis = False
+    bwd.wave_axis = 1
+    bwd.core = types.SimpleNamespace(xM_yN_size=4, yN_size=16)
+    bwd.facets_config_list = [api.FacetConfig(0, 0, 8)]
+    same_off0 = [api.SubgridConfig(0, 0, 8), api.SubgridConfig(0, 8, 8)]  # the reference's accumulate_column grouping
+    with pytest.raises(ValueError, match="share off1"):
+        bwd.accumulate_wave(same_off0, numpy.zeros((1, 2, 4, 4), dtype=numpy.complex64))
+    with pytest.raises(ValueError, match="share off1"):
+        bwd.accumulate_chunks(0, [(same_off0, numpy.zeros((1, 2, 4, 4), dtype=numpy.complex64))])
+    bwd.wave_axis = 0
+    same_off1 = [api.SubgridConfig(0, 0, 8), api.SubgridConfig(8, 0, 8)]
+    with pytest.raises(ValueError, match="share off0"):
+        bwd.accumulate_wave(same_off1, numpy.zeros((1, 2, 4, 4), dtype=numpy.complex64))
