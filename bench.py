@@ -412,15 +412,19 @@ def cpu_baseline(p, F, S, C):
             f"({', '.join(f'{v:.0f}' for v in values)} contributions/s); wall time of all repeats {wall:.1f} s"
         ),
         extrapolated_seconds=total,
+        # (r4 advice) what the sample was, so that values stay comparable across rounds: method 2 (r4-r5) = slabs of
+        # 2e6 / 4e6 elements and the median of three repeats; method 1 (r1-r3) = 4e6 / 8e6 elements, one repeat
+        method=dict(version=2, k1_slab_elements=int(p["yB_size"]) * int(ncol), k2_slab_elements=int(nrow) * int(p["yB_size"]),
+                    k1_slab_columns=int(ncol), k2_slab_rows=int(nrow), repeats=repeats, statistic="median"),
     )
 
 
 # --------------------------------------------------------------------------- measured traffic (PMC passes)
-PMC_FILE = os.path.join(ROOT, "profiles", "r4_pmc_kernels.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc_kernels.json")
 
 
 def _pmc_record(workload):
-    """Per-kernel counter summary of THIS round's build for the workload (profiles/r4_pmc_kernels.json, written by
+    """Per-kernel counter summary of THIS round's build for the workload (profiles/r5_pmc_kernels.json, written by
     tools/pmc_kernels.py from a rocprofv3 kernel trace and separate --pmc FETCH_SIZE / WRITE_SIZE passes), or None."""
     try:
         with open(PMC_FILE, encoding="utf-8") as fh:
@@ -483,6 +487,8 @@ def kernel_table(workload, F, C, parts):
             us_per_pass=round(us, 1),
             algorithmic_bytes_per_pass=int(alg),
             counter_bytes_per_pass=int(cnt),
+            fetch_bytes_per_pass=int(sum(k[i]["fetch_bytes_per_launch"] for i in ids) * per_pass),
+            write_bytes_per_pass=int(sum(k[i]["write_bytes_per_launch"] for i in ids) * per_pass),
             frac_algorithmic=round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             frac_sustained=round(cnt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
         ))
@@ -490,11 +496,112 @@ def kernel_table(workload, F, C, parts):
         return None
     tot_us = sum(r["us_per_pass"] for r in rows)
     return dict(
-        source="profiles/r4_pmc_kernels.json: " + rec.get("note", ""),
+        source="profiles/r5_pmc_kernels.json: " + rec.get("note", ""),
         rows=rows,
         sum_us_per_pass=round(tot_us, 1),
         counter_bytes_per_pass=int(sum(r["counter_bytes_per_pass"] for r in rows)),
         frac_sustained_whole_pass=round(sum(r["counter_bytes_per_pass"] for r in rows) / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+    )
+
+
+def backward_kernel_table(workload, F, C, parts):
+    """The same table for the subgrid -> facet direction (band schedule): every stage is the mirror
+    of a forward stage and moves the mirrored bytes, so the algorithmic figures are the forward model's
+    (B8 finish_facet <-> K1, B5 gather-sum four-step <-> K2, B4 m-point column pass <-> K3, B2 split_prepare_facets <-> K4,
+    B1 prepare_subgrid axis 0 <-> K5).  Counter bytes and durations: profiles/r5_pmc_kernels.json["<workload>:backward"]."""
+    rec = _pmc_record(workload + ":backward")
+    if not rec:
+        return None
+    k = rec["kernels"]
+    spec = [
+        ("B8", ["B8"], F, parts["K1"], "finish_facet along the contiguous axis from the band accumulator (crop x Fb x mask1 store)"),
+        ("B5-7", ["B5a", "B5b"], C, parts["K2"], "gather-sum four-step per wave: add_to_facet axis 0 in the load, strided-axis finish_facet, column scatter-add"),
+        ("B4", ["B4"], C, parts["K3"], "in-place m-point column pass (extract_from_subgrid axis 0)"),
+        ("B2-3", ["B2"], C, parts["K4"], "split_prepare_facets (prepare_subgrid axis 1 + extract_from_subgrid axis 1 per facet)"),
+        ("B1", ["B1"], C, parts["K5"], "prepare_subgrid axis 0"),
+    ]
+    rows = []
+    for stage, ids, per_pass, alg, what in spec:
+        if not all(i in k for i in ids):
+            continue
+        us = sum(k[i]["avg_us"] for i in ids) * per_pass
+        cnt = sum(k[i]["counter_bytes_per_launch"] for i in ids) * per_pass
+        rows.append(dict(
+            stage=stage, what=what, launches_per_pass=per_pass * len(ids), avg_us=[k[i]["avg_us"] for i in ids],
+            us_per_pass=round(us, 1), algorithmic_bytes_per_pass=int(alg), counter_bytes_per_pass=int(cnt),
+            fetch_bytes_per_pass=int(sum(k[i]["fetch_bytes_per_launch"] for i in ids) * per_pass),
+            write_bytes_per_pass=int(sum(k[i]["write_bytes_per_launch"] for i in ids) * per_pass),
+            frac_algorithmic=round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            frac_sustained=round(cnt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        ))
+    if not rows:
+        return None
+    tot_us = sum(r["us_per_pass"] for r in rows)
+    running = traffic_build_state(workload + ":backward")
+    return dict(
+        source="profiles/r5_pmc_kernels.json: " + rec.get("note", ""),
+        build_state=running["state"],
+        rows=rows,
+        sum_us_per_pass=round(tot_us, 1),
+        counter_bytes_per_pass=int(sum(r["counter_bytes_per_pass"] for r in rows)),
+        frac_sustained_whole_pass=round(sum(r["counter_bytes_per_pass"] for r in rows) / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+    )
+
+
+def quick_forward(torch, sw, sw_api, name, passes=3):
+    """Forward pass of another BASELINE configuration beside the headline line (`other_workloads`, r4 review): the same
+    objects as the default workload's timed region -- fresh planned SwiftlyForward per pass, K1 of every facet, every
+    wave -- `passes` timed passes after one warm-up, parity of the subgrids those objects produce against the oracle.
+    Never part of `value`."""
+    from oracle import separable as sep  # data recipe shared with the checker
+
+    wl = WORKLOADS[name]
+    p = wl["params"]
+    cfg = sw.SwiftlyConfig(backend="hip", **p)
+    facet_cfgs = sw.make_full_facet_cover(cfg)
+    cap = wl.get("max_facets_per_rank")
+    if cap is not None:
+        facet_cfgs = facet_cfgs[:cap]
+    sg_cfgs = select_subgrids(sw.make_full_subgrid_cover(cfg), p["N"], p["xA_size"], wl["sparse_radius"])
+    wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64, n_facets=len(facet_cfgs))
+    key = (lambda c: c.off1) if wave_axis == 1 else (lambda c: c.off0)
+    waves = {}
+    for i, c in enumerate(sg_cfgs):
+        waves.setdefault(key(c), []).append(i)
+    F, S, C = len(facet_cfgs), len(sg_cfgs), len(waves)
+    vectors = [sep.facet_vectors(1234 + j, p["yB_size"], rank=2) for j in range(F)]
+    data = [separable_facet(torch, vectors[j], facet_cfgs[j]) for j in range(F)]
+    picks = sep.pick_subgrids(sg_cfgs, 3)
+
+    def one_pass(keep=None):
+        fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, data)), lru_forward=1, subgrid_configs=sg_cfgs, wave_axis=wave_axis)
+        fwd.prepare_all_facets()
+        for widx in waves.values():
+            res = fwd.get_wave([sg_cfgs[i] for i in widx])
+            if keep is not None:
+                for k, i in enumerate(widx):
+                    if i in picks:
+                        keep[i] = res[k].cpu().numpy()
+
+    one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / passes
+    kept = {}
+    one_pass(kept)
+    torch.cuda.synchronize()
+    par = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept, tol=wl.get("parity_tol"))
+    total_bytes, _parts = algorithmic_bytes(p, F, S, C)
+    del data
+    torch.cuda.empty_cache()
+    return dict(
+        workload=wl["name"], facets=F, subgrids=S, subgrid_columns=C, wave_axis=wave_axis, passes=passes,
+        ms_per_step=round(ms, 3), contributions_per_s=round(F * S / (ms * 1e-3), 1),
+        hbm_algorithmic_frac_of_peak=round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        parity={k: par[k] for k in ("rel_rmse", "subgrids", "tol_rel_rmse", "ok")},
     )
 
 
@@ -522,6 +629,9 @@ def main():
     ap.add_argument("--verify", action="store_true", help="(default) kept for explicitness")
     ap.add_argument("--no-backward", action="store_true",
                     help="skip the subgrid -> facet leg (reported beside the headline metric, outside its timed region)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short forward runs of BASELINE configs 2 and 3 (`other_workloads`) that follow the default "
+                         "workload's measurement")
     ap.add_argument("--wave-axis", type=int, default=None, choices=[0, 1],
                     help="force the forward pipeline: 0 = strided axis first (waves by off0), 1 = contiguous axis first")
     args = ap.parse_args()
@@ -863,9 +973,18 @@ def main():
             return bwd.finish()
 
         try:
-            out = backward_pass()
-            torch.cuda.synchronize()
-            nb = 3
+            # two untimed passes (r4 review: one was not enough -- the first timed pass of the driver's run took 162 ms
+            # against 49 ms for the others: the caching allocator re-splitting its blocks after the float64 leg above),
+            # then the MEDIAN of five
+            warm = []
+            out = None
+            for _ in range(2):
+                del out
+                tb = time.perf_counter()
+                out = backward_pass()
+                torch.cuda.synchronize()
+                warm.append(1e3 * (time.perf_counter() - tb))
+            nb = 5
             each = []
             for _ in range(nb):
                 del out  # the previous pass's facets go back to the allocator before the next pass asks for its own
@@ -873,16 +992,32 @@ def main():
                 out = backward_pass()
                 torch.cuda.synchronize()
                 each.append(1e3 * (time.perf_counter() - tb))
-            b_ms = sum(each) / nb
+            b_ms = sorted(each)[nb // 2]
             finite = all(bool(torch.isfinite(torch.view_as_real(o)).all()) for o in out)
             backward = dict(
-                ms_per_pass=round(b_ms, 3), passes=nb, each_ms=[round(t, 2) for t in each],
+                ms_per_pass=round(b_ms, 3), statistic="median", passes=nb, each_ms=[round(t, 2) for t in each],
+                warmup_ms=[round(t, 2) for t in warm],
                 ratio_to_forward=round(b_ms / ms_per_step, 3),
+                hbm_algorithmic_frac_of_peak=round(total_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                kernels=backward_kernel_table(args.workload, F, C, parts),
                 schedule="band accumulators, waves by off1" if baxis == 1 else "reference schedule, waves by off0",
                 subgrids=S, facets=F, finite=finite,
             )
             del out, produced, lookup
             produced = lookup = None
+            bk = backward.get("kernels")
+            if bk:
+                # the dominant kernel group of the backward pass against the HBM peak (durations and counter bytes of the
+                # committed summary of this build, like `kernels`; not a live measurement)
+                top = max(bk["rows"], key=lambda r: r["us_per_pass"])
+                secs = top["us_per_pass"] * 1e-6
+                backward["roofline"] = dict(
+                    kernel=f"{top['stage']}: {top['what']}", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
+                    achieved=round(top["algorithmic_bytes_per_pass"] / secs / 1e9, 1),
+                    frac=top["frac_algorithmic"], traffic=top["counter_bytes_per_pass"] // top["launches_per_pass"],
+                    sustained=round(top["counter_bytes_per_pass"] / secs / 1e9, 1), sustained_frac=top["frac_sustained"],
+                    launches_per_pass=top["launches_per_pass"], source=bk["source"][:60] + "...", build_state=bk["build_state"],
+                )
             if picks:
                 backward["parity"] = backward_parity(sg_cfgs)
         except (ValueError, NotImplementedError) as err:  # sizes without the band kernels
@@ -1009,8 +1144,26 @@ def main():
         backward=backward,
         roundtrip=roundtrip,
     )
+    if line["roofline"] is not None:
+        # the whole pass beside its dominant kernel (r4 review: `roofline` alone shows the most flattering stage)
+        line["roofline"]["whole_pass"] = dict(
+            frac=line["hbm_algorithmic_frac_of_peak"], achieved=line["hbm_algorithmic_gbs"], ms_per_step=line["ms_per_step"],
+            sustained_frac=(line["kernels"] or {}).get("frac_sustained_whole_pass"),
+            what="algorithmic bytes of ALL stages / ms_per_step; sustained = counter bytes / sum of the kernels' own durations",
+        )
     if len(facet_cfgs) < len(all_facet_cfgs):
         line["scaling"] = "weak (a rank holds at most %d facets: the facet subset grows with the ranks)" % cap
+    if single and rank == 0 and args.workload == "64k-sparse" and not args.no_other_workloads and not args.no_verify:
+        # BASELINE configs 2 and 3 in the driver's line (r4 review): three timed forward passes each, after the headline
+        # measurement and outside its timed region; the default workload's facets go back to the allocator first
+        del facet_data[:]
+        torch.cuda.empty_cache()
+        line["other_workloads"] = {}
+        for other in ("8k", "32k-8x8"):
+            try:
+                line["other_workloads"][other] = quick_forward(torch, sw, sw_api, other)
+            except Exception as err:  # pylint: disable=broad-except
+                line["other_workloads"][other] = dict(error=f"{type(err).__name__}: {err}")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p, F, S, C)
@@ -1021,6 +1174,9 @@ def main():
         torch.distributed.destroy_process_group()
     if parity is not None and not parity["ok"]:
         raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {parity['tol_rel_rmse']}")
+    for other, rec in (line.get("other_workloads") or {}).items():
+        if rec.get("error") or not rec.get("parity", {}).get("ok", False):
+            raise SystemExit(f"bench.py: other_workloads[{other}] failed: {rec.get('error') or rec['parity']}")
     bpar = (backward or {}).get("parity") or (roundtrip or {}).get("backward_parity")
     if bpar is not None and not bpar["ok"]:
         raise SystemExit(f"bench.py: BACKWARD PARITY FAILURE rel_rmse={bpar['rel_rmse']:.3e} >= {bpar['tol_rel_rmse']}")

@@ -8,8 +8,9 @@
   pmc_write.db    : rocprofv3 --kernel-trace --pmc WRITE_SIZE     -> bytes written per launch
 
 (FETCH_SIZE / WRITE_SIZE need separate passes on gfx950; FETCH_SIZE tallies 64 B per 128 B request and is doubled;
-MI355X_MICROARCH.md, section HBM.)  Writes profiles/r4_pmc_kernels.json, which bench.py reads for `roofline.traffic`,
-`roofline.sustained` and the `kernels` table of the JSON line."""
+MI355X_MICROARCH.md, section HBM.)  Writes profiles/r5_pmc_kernels.json, which bench.py reads for `roofline.traffic`,
+`roofline.sustained` and the `kernels` table of the JSON line.  A sixth argument `backward` selects the stage table of
+the subgrid -> facet direction (trace of tools/run_backward.py; key "<workload>:backward", `backward.kernels`)."""
 import collections
 import json
 import os
@@ -30,8 +31,20 @@ STAGES = [
 ]
 
 
+# the subgrid -> facet direction, band schedule: the mirror stages, same byte model
+STAGES_BACKWARD = [
+    (r"row_pass_band_kernel.*Lb0ELi2E", "B8"),             # finish_facet along the contiguous axis (mapped store)
+    (r"col_pass_kernel.*CGeoILi[5-9]E.*EELi0ELb", "B5a"),   # gather-sum four-step pass A (add_to_facet axis 0 in the load)
+    (r"col_pass_kernel.*CGeoILi[5-9]E.*EELi1ELb", "B5b"),   # four-step pass B (crop x Fb x mask0, column scatter-add)
+    (r"col_pass_kernel.*CGeoILi9E.*EELi2ELb", "B4"),        # in-place m-point column pass of extract_from_subgrid axis 0
+    (r"split_prepare_facets_kernel", "B2"),                 # prepare_subgrid axis 1 + extract_from_subgrid axis 1 per facet
+    (r"col_pass_kernel.*CGeoILi10E.*EELi2ELb", "B1"),       # prepare_subgrid axis 0 (1024-point single pass)
+]
+_ACTIVE = STAGES
+
+
 def stage_of(name):
-    for pat, st in STAGES:
+    for pat, st in _ACTIVE:
         if re.search(pat, name):
             return st
     return None
@@ -66,12 +79,15 @@ def per_kernel(path, counter=None):
 
 
 def main():
+    global _ACTIVE  # pylint: disable=global-statement
     kt, pf, pw = sys.argv[1:4]
-    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r4_pmc_kernels.json")
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r5_pmc_kernels.json")
     workload = sys.argv[5] if len(sys.argv) > 5 else "64k-sparse"
+    direction = sys.argv[6] if len(sys.argv) > 6 else "forward"
+    _ACTIVE = STAGES_BACKWARD if direction == "backward" else STAGES
     t, f, w = per_kernel(kt), per_kernel(pf, "FETCH_SIZE"), per_kernel(pw, "WRITE_SIZE")
     table = {}
-    for stg in [s for _, s in STAGES]:
+    for stg in [s for _, s in _ACTIVE]:
         if stg not in t or stg not in f or stg not in w:
             continue
         fetch = 2.0 * 1024.0 * f[stg]["kib"] / f[stg]["n"]
@@ -95,16 +111,19 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd"))
     from ska_sdp_exec_swiftly_amd import _lib  # noqa: E402  pylint: disable=import-outside-toplevel
 
-    rec[workload] = dict(
-        build=_lib.build_info(),
-        kernels=table,
-        note="rocprofv3 --kernel-trace (durations) and --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
-             "`SWIFTLY_PREFETCH=0 SWIFTLY_K2_CHUNK=0 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify "
-             "--no-backward` of this build (every kernel alone on the chip; the production pass overlaps K2 of the next "
-             "wave with K3-K5 and the two K2 passes of different chunks); per-launch "
-             "averages over all launches of the kernel in the run; FETCH_SIZE doubled per MI355X_MICROARCH.md (64 B "
-             "tallied per 128 B request on gfx950)",
-    )
+    how = ("rocprofv3 --kernel-trace (durations) and --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
+           "`%s` of this build (%s); per-launch averages over all launches of the kernel in the run; FETCH_SIZE doubled "
+           "per MI355X_MICROARCH.md (64 B tallied per 128 B request on gfx950)")
+    if direction == "backward":
+        key = workload + ":backward"
+        note = how % ("tools/run_backward.py", "band schedule of SwiftlyBackward on random subgrids of the workload's plan, "
+                      "no forward pass in the process, one kernel at a time")
+    else:
+        key = workload
+        note = how % ("SWIFTLY_PREFETCH=0 SWIFTLY_K2_CHUNK=0 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify "
+                      "--no-backward", "every kernel alone on the chip; the production pass overlaps K2 of the next wave with "
+                      "K3-K5 and the two K2 passes of different chunks")
+    rec[key] = dict(build=_lib.build_info(), kernels=table, note=note)
     with open(out, "w", encoding="utf-8") as fh:
         json.dump(rec, fh, indent=1)
     for stg, e in table.items():
