@@ -66,17 +66,12 @@ static int launch_split(const RowPassArgs& a, const cx<float>* tw_part, const cx
     return (int)hipGetLastError();
 }
 using SplitGeo2 = RGeo<14, 4, true>;   // 2 x 16384 points, 1024 threads x 16 (one workgroup per CU)
-using SplitGeo2N = RGeo<14, 4, false>; // same with interleaved (re,im) exchange: 136 KB LDS, half the LDS instructions and barriers
-using SplitGeo4 = RGeo<13, 4, true>;   // 4 x  8192 points,  512 threads x 16, 34 KB LDS (split exchange): 4 per CU
-using SplitGeo4N = RGeo<13, 4, false>; // same, interleaved exchange (68 KB): 2 per CU, half the LDS instructions
+// (4 x 8192 points in 512-thread workgroups and the interleaved-exchange forms were measured slower in r1-r2)
 int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw13, const cx<float>* tw_full,
                           hipStream_t s) {
+    (void)tw13;
     if (a.nrows <= 0) return 0;
-    static const int variant = getenv("SWIFTLY_K2_SPLIT") ? atoi(getenv("SWIFTLY_K2_SPLIT")) : 2;  // tuning knob: 2 (default, fastest measured), 4, 41
-    if (variant == 2) return launch_split<SplitGeo2, 1>(a, tw14, tw_full, s);
-    if (variant == 21) return launch_split<SplitGeo2N, 1>(a, tw14, tw_full, s);
-    if (variant == 41) return launch_split<SplitGeo4N, 2>(a, tw13, tw_full, s);
-    return launch_split<SplitGeo4, 2>(a, tw13, tw_full, s);
+    return launch_split<SplitGeo2, 1>(a, tw14, tw_full, s);
 }
 using BandGeo5 = RGeo<14, 5, true>;  // 2 x 16384 points, 512 threads x 32, 66 KB LDS: two workgroups per CU
 using BandGeo4 = RGeo<14, 4, true>;  // 2 x 16384 points, 1024 threads x 16, one workgroup per CU
@@ -107,11 +102,6 @@ static void launch_band_inst(const RowPassArgs& a, unsigned blocks, const cx<flo
     hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, NSEG, CJ>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a,
                        a.in, a.out, a.ld_win, tw14, tw_full);
 }
-// tuning knob SWIFTLY_ROW_SEGSKIP=0: always the all-segments kernel
-static bool segskip_enabled() {
-    static const bool on = !(getenv("SWIFTLY_ROW_SEGSKIP") && atoi(getenv("SWIFTLY_ROW_SEGSKIP")) == 0);
-    return on;
-}
 template <class G, bool PAIR = false>
 static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
     RowPassArgs a = a0;
@@ -122,9 +112,9 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
     // forward K1 (window, band store) and the backward finish (no load window, mapped store)
     constexpr bool SEGS = PAIR || (G::LOGN == 15 && G::LOGP == 5);
     if constexpr (SEGS) {
-        constexpr int SEGLEN = PAIR ? 2 * G::T : G::T, NSEGTOT = 2 * G::N / SEGLEN;
+        constexpr int SEGLEN = PAIR ? 2 * G::T : G::T;
         int first = 0;
-        const int run = segskip_enabled() ? data_segment_run(a, 2 * G::N, SEGLEN, &first) : NSEGTOT;
+        const int run = data_segment_run(a, 2 * G::N, SEGLEN, &first);
 #define SWF_TRY_SEG(WIN, ST, NS, CJ)                                   \
     if (run <= NS) {                                                   \
         a.seg_rot = first;                                             \
@@ -184,16 +174,11 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
     if (logn == 14) return launch_band_geo<BandGeo16k>(a, tw_half, tw_full, s);
     if (logn != 15) return -1;
     const cx<float>* tw14 = tw_half;
-    // tuning knob SWIFTLY_ROW_GEO: 5 (512 threads x 32 points, two workgroups per CU) | 4 (1024 x 16, one per CU);
-    // default: 5 for the band store (1 spilled VGPR), 4 for the plain store (the 512-thread form spills ~49 there)
-    static const int geo_env = getenv("SWIFTLY_ROW_GEO") ? atoi(getenv("SWIFTLY_ROW_GEO")) : 0;
-    static const int geo_fin = getenv("SWIFTLY_ROW_GEO_FIN") ? atoi(getenv("SWIFTLY_ROW_GEO_FIN")) : 5;
-    const int geo = geo_env ? geo_env : (a.band_len > 0 ? 5 : a.band_len < 0 ? geo_fin : 4);
-    if (geo == 4) return launch_band_geo<BandGeo4>(a, tw14, tw_full, s);
-    // adjacent-point (16-byte) loads need even shifts / lengths / pitches; tuning knob SWIFTLY_ROW_PAIR=0 turns them off
-    static const bool pair_env = !(getenv("SWIFTLY_ROW_PAIR") && atoi(getenv("SWIFTLY_ROW_PAIR")) == 0);
-    const bool pair_ok = pair_env && !(a.ld_a & 1) && !(a.ld_len & 1) && !(a.in_pitch & 1) &&
-                         (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
+    // 512 threads x 32 points (two workgroups per CU) for the band store and the mapped store; 1024 x 16 (one per CU) for
+    // the plain store, where the 512-thread form spills ~49 VGPRs (1024 x 16 for the band store: 1.95 vs 1.73 ms per facet, r4)
+    if (a.band_len == 0) return launch_band_geo<BandGeo4>(a, tw14, tw_full, s);
+    // adjacent-point (16-byte) loads need even shifts / lengths / pitches
+    const bool pair_ok = !(a.ld_a & 1) && !(a.ld_len & 1) && !(a.in_pitch & 1) && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
     if (pair_ok) return launch_band_geo<BandGeo5, true>(a, tw14, tw_full, s);
     return launch_band_geo<BandGeo5>(a, tw14, tw_full, s);
 }
@@ -225,8 +210,8 @@ static int init_band_geo() {
 // occupancy query (blocks per CU) for tuning / DESIGN.md
 int row_pass_half_occupancy(int lds_bytes) {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_split_kernel<SplitGeo4, 2, false>, SplitGeo4::NT,
-                                                       lds_bytes < 0 ? SplitGeo4::LDS_BYTES : (size_t)lds_bytes);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, row_pass_split_kernel<SplitGeo2, 1, false>, SplitGeo2::NT,
+                                                       lds_bytes < 0 ? SplitGeo2::LDS_BYTES : (size_t)lds_bytes);
     return n;
 }
 template <class G, int LOGS>
@@ -259,9 +244,6 @@ int init_row_pass() {
     }
     {
         int rc0 = init_split<SplitGeo2, 1>();
-        if (!rc0) rc0 = init_split<SplitGeo2N, 1>();
-        if (!rc0) rc0 = init_split<SplitGeo4, 2>();
-        if (!rc0) rc0 = init_split<SplitGeo4N, 2>();
         if (rc0) return rc0;
     }
     int rc = init_one<13>();

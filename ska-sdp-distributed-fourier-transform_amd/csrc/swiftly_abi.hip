@@ -428,8 +428,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     // 512 points: longer gather-sum transforms go through the four-step, whose pass A carries the load (r3 bug: a
     // 1024-point gather-sum transform ran the plain 32-column kernel, which read the encoded table as a row map)
     const bool two = logn > (c.gs ? 9 : kColPassMaxLog);
-    static const int l1_bias = getenv("SWIFTLY_L1_BIAS") ? atoi(getenv("SWIFTLY_L1_BIAS")) : 0;  // tuning knob
-    const int l1 = two ? logn / 2 + l1_bias : logn, l2 = logn - l1;
+    const int l1 = two ? logn / 2 : logn, l2 = logn - l1;  // (32768 = 128 x 256; 256 x 128 and 64 x 512 measured slower, r4)
     if (l1 < kColPassMinLog || l1 > kColPassMaxLog || (two && (l2 < kColPassMinLog || l2 > kColPassMaxLog))) return -1;
     const uint64_t n = uint64_t(1) << logn;
     // float64 arithmetic where the caller asks for it and the instances exist (else float32, silently: same results to
@@ -460,12 +459,8 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     const cx<double>* twdf = f64 ? twiddles<double>(h, logn) : nullptr;
     if (f64 && (!twd1 || !twd2 || !twdf)) return -1;
     if (n * (uint64_t)W >= (uint64_t(1) << 32)) return -1;
-    // Column slabs (tuning knob SWIFTLY_SLAB_COLS, 0 = off): both passes of a slab run back to back so that the
-    // four-step intermediate of the slab is re-read while it may still sit in the 256 MiB Infinity Cache.
-    static const long long slab_env = getenv("SWIFTLY_SLAB_COLS") ? atoll(getenv("SWIFTLY_SLAB_COLS")) : 0;
     const bool gathered = (cz.flags & kZColGather) != 0;
-    const long long slab = (slab_env >= 64 && nb == 1 && !gathered) ? (slab_env / 64) * 64 : (long long)W;
-    const long long Ws = std::min<long long>(slab, (long long)W);  // scratch row width
+    const long long Ws = (long long)W;  // scratch row width (column slabs that keep the intermediate cache-sized: no gain, r2-r4)
     const size_t scratch_bytes = (size_t)nb * n * (size_t)Ws * sizeof(cx<float>);
     void* scratch = nullptr;
     hipError_t he = hipSuccess;
@@ -481,15 +476,12 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     int rc = 0;
     // Layout of the intermediate (r4): row y2 * n1 + k1 -- a pass-A workgroup (one y2) WRITES n1 consecutive rows and a
     // pass-B workgroup (one k1) reads a comb -- instead of row k1 * n2 + y2 (comb written, consecutive rows read).  HBM
-    // writes are the expensive direction on this chip (tools/mall_pipe.hip: ~4.2 TB/s against ~7.6 TB/s for reads, and a
-    // comb costs 7 % on the write side and nothing on the read side): pass A 425 -> 395 us per wave as a pure copy.
-    // SWIFTLY_SCRATCH_LAYOUT=0 restores the r1-r3 layout.
-    static const bool y2_major = !(getenv("SWIFTLY_SCRATCH_LAYOUT") && atoi(getenv("SWIFTLY_SCRATCH_LAYOUT")) == 0);
-    // Tile-major scratch (r5, SWIFTLY_SCRATCH_TILE=1): [item][64-column tile][row][64] instead of [item][row][columns], so
-    // that the n1 rows a pass-A workgroup writes are ONE contiguous run of n1 * 512 bytes instead of n1 pieces of 512
-    // bytes one scratch row apart
-    static const bool tile_major = getenv("SWIFTLY_SCRATCH_TILE") && atoi(getenv("SWIFTLY_SCRATCH_TILE")) != 0;
-    const bool tiles = tile_major && !f64 && qmul == 0 && l1 < 10 && l2 < 10;
+    // writes are the expensive direction on this chip (tools/mall_pipe.hip: a comb costs 7 % on the write side and nothing
+    // on the read side): pass A 425 -> 395 us per wave as a pure copy, 427 -> 386 us for the kernel.
+    constexpr bool y2_major = true;
+    // (r5: a TILE-major scratch -- [item][64-column tile][row][64], the n1 rows of a pass-A workgroup one contiguous run
+    // of n1 * 512 bytes -- measured the same within the run-to-run spread: 38.87 / 39.64 / 39.33 against 39.29 / 38.75 /
+    // 38.58 ms per pass, interleaved on one box; not kept)
     const int a_i_rows = y2_major ? 1 : n2, a_o_rows = y2_major ? n1 : 1;  // pass A: row of (e = k1, o = y2)
     const int b_i_rows = y2_major ? n1 : 1, b_o_rows = y2_major ? 1 : n2;  // pass B: row of (i = y2, o = k1)
     // Chunked, two-stream form (r4; K2 = the gathered forward transform of several facets): the batch items are worked
@@ -511,8 +503,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
             chunk_items = (int)std::max<uint64_t>(1, (uint64_t(128) << 20) / (n * 256 * sizeof(cx<float>)));
         }
     }
-    if (chunk_cols >= 64 && gathered && !(cz.flags & kZColScatter) && !c.gs && qmul == 0 && slab == (long long)W &&
-        (nb > chunk_items || W > chunk_cols) && !own) {
+    if (chunk_cols >= 64 && gathered && !(cz.flags & kZColScatter) && !c.gs && qmul == 0 &&         (nb > chunk_items || W > chunk_cols) && !own) {
         const int Wc = std::min<int>((chunk_cols / 64) * 64, W), zc = std::min(chunk_items, nb);
         const size_t slot_elems = (size_t)n * (size_t)Wc * (size_t)zc;
         if (2 * slot_elems * sizeof(cx<float>) <= ws_bytes) {
@@ -563,7 +554,6 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
                     A.scratch_nt = 0;
                     A.ncols = wc; A.col0 = c0; A.z0 = z0; A.raw_z0 = z0;
                     A.out = slot; A.out_pitch = (unsigned)Wc; A.out_bs = (long long)(n * Wc);
-                    if (tiles) { A.out_pitch = 64; A.out_ts = (long long)n * 64; }
                     A.out_bdiv = 0; A.out_bs_hi = 0;
                     A.ld_mul = n2;
                     A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
@@ -579,7 +569,6 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
                     zb.flags &= ~(kZColGather | kZLoadB | kZLoadAF);  // the scratch is read plainly
                     B.ncols = wc; B.col0 = 0; B.z0 = z0; B.raw_z0 = z0;
                     B.in = slot; B.in_pitch = (unsigned)Wc; B.in_bs = (long long)(n * Wc);
-                    if (tiles) { B.in_pitch = 64; B.in_ts = (long long)n * 64; }
                     B.in_bdiv = 0; B.in_bs_hi = 0;
                     B.in_i_rows = b_i_rows; B.in_o_rows = b_o_rows;
                     B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr; B.gs = 0;
@@ -608,9 +597,8 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     }
     // scratch accesses: a small intermediate is left cacheable so that pass B finds it in the 256 MiB Infinity
     // Cache (measured: the 160 MB of a K5b wave, K3-5 12.5 -> 11.6 ms per pass); a large one is streamed
-    // non-temporally (measured: K2, 1.2 GB per wave, 18.5 ms vs 19.6 ms cacheable).  SWIFTLY_SCRATCH_NT forces.
-    static const int scratch_nt_env = getenv("SWIFTLY_SCRATCH_NT") ? atoi(getenv("SWIFTLY_SCRATCH_NT")) : -1;
-    const int scratch_nt = scratch_nt_env >= 0 ? scratch_nt_env : (scratch_bytes > (size_t(192) << 20) ? 1 : 0);
+    // non-temporally (measured: K2, 1.2 GB per wave, 18.5 ms vs 19.6 ms cacheable).
+    const int scratch_nt = scratch_bytes > (size_t(192) << 20) ? 1 : 0;
     for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
         const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
         // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2
@@ -619,7 +607,6 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.ncols = wc;
         A.in = c.in + c0;
         A.out = (cx<float>*)scratch; A.out_pitch = (unsigned)Ws; A.out_bs = (long long)(n * Ws);
-        if (tiles && Ws % 64 == 0) { A.out_pitch = 64; A.out_ts = (long long)n * 64; }
         A.out_bdiv = 0; A.out_bs_hi = 0;
         A.ld_mul = n2;
         A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
@@ -641,7 +628,6 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         zb.flags &= ~(kZColGather | kZLoadB | kZLoadAF);  // the scratch is read plainly
         B.ncols = wc;
         B.in = (const cx<float>*)scratch; B.in_pitch = (unsigned)Ws; B.in_bs = (long long)(n * Ws);
-        if (tiles && Ws % 64 == 0) { B.in_pitch = 64; B.in_ts = (long long)n * 64; }
         B.in_bdiv = 0; B.in_bs_hi = 0;
         B.in_i_rows = b_i_rows; B.in_o_rows = b_o_rows;
         B.ld_rowmap = nullptr; B.ld_win = nullptr; B.ld_win2 = nullptr; B.gs = 0;
@@ -742,8 +728,6 @@ static int single_store_window(RowPassArgs& r, hipStream_t st, void** tmp) {
 // fit (generic kernel handles it).
 static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, const OffTab& tab, hipStream_t st,
                          int* rc_out) {
-    static const bool disabled = getenv("SWIFTLY_NO_ROWPASS") != nullptr;
-    if (disabled) return false;
     if (a.rowfast || a.in_cs != 1 || a.out_cs != 1 || tab.use != 0 || (a.nbatch > 1)) return false;
     if (logn < kRowPassMinLog || logn > kRowPassMaxLog + 1) return false;
     if (a.ld.win2 || a.st_win_bs != 0) return false;
@@ -766,16 +750,13 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
     if (!r.tw) return false;
     r.scale = a.scale; r.conj_ld = a.conj_ld; r.conj_st = a.conj_st; r.accumulate = a.accumulate;
     const int mode = ident_st ? 0 : (ident_ld ? 1 : 2);
-    static const bool no_half = getenv("SWIFTLY_NO_HALF") != nullptr;
-    // default for N = 32768: the r2 kernel (all loads of a lane in flight, buffer accesses); SWIFTLY_K2_SPLIT
-    // selects the r1 multi-workgroup kernels for A/B runs
-    static const bool legacy = getenv("SWIFTLY_K2_SPLIT") != nullptr;
+    // N = 32768: the two-workgroup band kernel for the load map of a prepare_* primitive, else the r1 split kernel
     const bool prep_ld = r.ld_c == 0 && r.ld_mod == r.ld_len;    // load map of a prepare_* primitive (or identity)
     const bool fin_st = r.st_c == 0 && r.st_mod == r.st_len;     // store map of a finish_* primitive
-    if (logn == 15 && mode == 0 && !a.accumulate && !no_half) {
+    if (logn == 15 && mode == 0 && !a.accumulate) {
         const cx<float>* tw14 = twiddles<float>(h, 14);
         const cx<float>* tw13 = twiddles<float>(h, 13);
-        if (tw14 && !legacy && prep_ld) {
+        if (tw14 && prep_ld) {
             int e2 = launch_row_pass_band(r, tw14, r.tw, st);
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
             return true;
@@ -786,7 +767,7 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
             return true;
         }
     }
-    if (logn == 15 && mode != 0 && fin_st && prep_ld && !r.ld_win && !legacy && !no_half) {  // finish_* along the contiguous axis
+    if (logn == 15 && mode != 0 && fin_st && prep_ld && !r.ld_win) {  // finish_* along the contiguous axis
         const cx<float>* tw14 = twiddles<float>(h, 14);
         if (tw14) {
             r.band_len = -1;  // selects the mapped-store variant
@@ -845,8 +826,9 @@ static int run_rows_chunk(swiftly_hip* h, int logn, RowsArgs<R>& a, const OffTab
     a.ld_addmul = 0;
     a.st_addmul = all_j ? 1 : 0;
     a.outer = all_j ? qmul : 1;
-    // SWIFTLY_MIXED_GROUP=0: plain workgroup order for the one-launch form (A/B)
-    a.outer_group = (all_j && !(getenv("SWIFTLY_MIXED_GROUP") && !atoi(getenv("SWIFTLY_MIXED_GROUP")))) ? 1 : 0;
+    // the Q sub-transforms of a row write interleaved elements of the same lines: their workgroups are enumerated 8 block
+    // ids apart = on one XCD, whose L2 merges the partial lines (K1 of 24k[1]-n12k-1k 1.52 -> 0.88 ms per facet, r3)
+    a.outer_group = all_j ? 1 : 0;
     if (!all_j) a.in_os = 0;
     a.out_os = 0;
     a.tw_full = nullptr;

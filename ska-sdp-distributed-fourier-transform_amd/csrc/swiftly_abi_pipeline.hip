@@ -273,9 +273,7 @@ static int prepare_facet_columns_impl(swiftly_hip_t* h, int dtype, const void* i
     c.cg_mod = m; c.cg_full = yN;
     c.cg_band_start = (int)band_start; c.cg_band_len = (int)band_len; c.cg_band_half = band_half_of(h, band_len);
     c.f64 = h->col_f64;  // (col_transform falls back to float32 where the instances do not exist)
-    // tuning knob: facets per launch group (both passes of a group run back to back)
-    static const int per_env = getenv("SWIFTLY_K2_FACETS") ? atoi(getenv("SWIFTLY_K2_FACETS")) : kColZF;
-    const int per_f = std::max(1, std::min(per_env, (int)kColZF));
+    const int per_f = kColZF;  // facets per launch group (smaller groups: no gain, r4)
     // keep the four-step scratch of one launch group below ~4 GB
     const int64_t group_cap = ws ? (int64_t)ws_bytes : (int64_t(4) << 30);
     const int64_t per_w_cap = std::max<int64_t>(1, group_cap / ((int64_t)yN * m * 8) / std::min<int64_t>(per_f, nfacets));

@@ -16,10 +16,7 @@
 namespace swf {
 
 // streaming (non-temporal) global accesses for the column passes: every byte is touched once per pass
-// (same-box A/B on MI355X: whole pass 74.0 -> 70.6-72.0 ms)
-#ifndef SWF_NT
-#define SWF_NT 1
-#endif
+// (same-box A/B on MI355X against cacheable accesses: whole pass 74.0 -> 70.6-72.0 ms, r1; K3-5 11.9 -> 12.8 ms cacheable, r2)
 template <bool NT>
 __device__ __forceinline__ cx<float> cp_load(const cx<float>* p) {
     if constexpr (NT) {
@@ -81,10 +78,6 @@ struct ColPassArgs {
     // load: raw -> row = o*in_o_rows + i*in_i_rows ; mapped -> plain index i*ld_mul + o through the map
     int raw_ld;
     int in_i_rows, in_o_rows;
-    // raw accesses in TILE-MAJOR order (r5, four-step scratch): the 64-column tile bx of an item starts at
-    // bx * {in,out}_ts elements and its rows are {in,out}_pitch (= 64) apart, so that a workgroup's rows are one
-    // contiguous run; 0 = plain row-major [row][column]
-    long long in_ts, out_ts;
     int ld_mul, ld_a, ld_len, ld_c, ld_mod;
     const float* ld_win;
     const float* ld_win2;
@@ -235,7 +228,7 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
     constexpr bool HALF = G::HALF;
     static_assert(!(HALF && GS), "gather-sum load: 64-column tiles only");
     constexpr bool RAW_LD = MODE == 1, RAW_ST = MODE == 0;
-    constexpr bool NT_LD = RAW_LD ? SNT : (SWF_NT != 0), NT_ST = RAW_ST ? SNT : (SWF_NT != 0);
+    constexpr bool NT_LD = RAW_LD ? SNT : true, NT_ST = RAW_ST ? SNT : true;
     // last Stockham phase: radix 2^LR at stride 2^LNS  (phases are LOGP, LOGP, ..., remainder)
     constexpr int LR = G::LOGN <= G::LOGP ? G::LOGN : (G::LOGN % G::LOGP == 0 ? G::LOGP : G::LOGN % G::LOGP);
     constexpr int LNS = G::LOGN - LR;
@@ -277,13 +270,12 @@ __device__ __forceinline__ void col_pass_body(const ColPassArgs& A, const cx<flo
     const long long in_off =
         A.in_bdiv > 0 ? (long long)(z / A.in_bdiv) * A.in_bs_hi + (long long)(z % A.in_bdiv) * A.in_bs
                       : (long long)(RAW_LD ? z - A.raw_z0 : z) * A.in_bs;
-    const cx<float>* __restrict__ in =
-        gin + (GS ? 0ll : in_off) + ((RAW_LD && A.in_ts) ? (long long)bx * A.in_ts + clane : (long long)lcol);
+    const cx<float>* __restrict__ in = gin + (GS ? 0ll : in_off) + lcol;
     const long long out_off =
         (cz.flags & kZOutB) ? cz.b_out_off[zb] + (long long)zf * cz.b_out_fs[zb]
         : A.out_bdiv > 0 ? (long long)(z / A.out_bdiv) * A.out_bs_hi + (long long)(z % A.out_bdiv) * A.out_bs
                          : (long long)(RAW_ST ? z - A.raw_z0 : z) * A.out_bs;
-    cx<float>* __restrict__ out = gout + out_off + ((RAW_ST && A.out_ts) ? (long long)bx * A.out_ts + clane : (long long)ocol);
+    cx<float>* __restrict__ out = gout + out_off + ocol;
     const RC sg_ld = A.conj_ld ? (RC)-1 : (RC)1;
     const RC sg_st = A.conj_st ? (RC)-1 : (RC)1;
     const RC col_w = (A.col_win && live) ? (RC)A.col_win[col] : (RC)1;

@@ -39,61 +39,24 @@ template <typename R>
 __device__ __forceinline__ cx<R> cmul(cx<R> a, cx<R> b) {
     return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
-// complex64 products written on 2-vectors so that they lower to v_pk_mul_f32 + v_pk_fma_f32 (2 packed
-// instructions instead of 4 scalar ones): (a.x, a.x)*(b.x, b.y) + (-a.y, a.y)*(b.y, b.x)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// Measured on MI355X (same-box A/B, bench.py): the packed forms make the column passes ~18 % SLOWER
-// (K1 32.5 -> 38.5 ms) and leave the row kernels unchanged, so they are compiled out by default.
-#ifndef SWF_PACKED_CMUL
-#define SWF_PACKED_CMUL 0
-#endif
-// packed complex add / subtract (one v_pk_add_f32 per complex operation): A/B switch
-#ifndef SWF_PACKED_ADD
-#define SWF_PACKED_ADD 0
-#endif
-#if SWF_PACKED_ADD
-__device__ __forceinline__ cx<float> operator+(cx<float> a, cx<float> b) {
-    const f32x2 r = f32x2{a.x, a.y} + f32x2{b.x, b.y};
-    return {r.x, r.y};
-}
-__device__ __forceinline__ cx<float> operator-(cx<float> a, cx<float> b) {
-    const f32x2 r = f32x2{a.x, a.y} - f32x2{b.x, b.y};
-    return {r.x, r.y};
-}
-#endif
-#if SWF_PACKED_CMUL
-template <>
-__device__ __forceinline__ cx<float> cmul<float>(cx<float> a, cx<float> b) {
-    const f32x2 bv = {b.x, b.y}, bs = {b.y, b.x};
-    const f32x2 ax = {a.x, a.x}, ay = {-a.y, a.y};
-    const f32x2 r = __builtin_elementwise_fma(ay, bs, ax * bv);
-    return {r.x, r.y};
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------------------
-// SWF_PK: hand-packed complex64 arithmetic.  A complex value is one 64-bit VGPR pair; add / subtract are one
-// v_pk_add_f32, a general product is v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers doing the swaps and
-// sign changes (the compiler's own lowering of the same expressions needs a v_xor per product because it does not
-// fold a one-lane negation into neg_lo), and the (a - c) * {-i, W8, W8^3} butterflies fold their rotation into the
-// subtraction.  VOP3P modifiers: op_sel[i] / op_sel_hi[i] pick the half of source i that feeds the low / high
-// result lane, neg_lo / neg_hi negate source i for that lane.
-// Measured on MI355X (r2, same-box A/B, -DSWF_PK=0 vs 1): the band row kernel 1675 instead of 2416 VALU instructions
-// per wave, 117 instead of 128 VGPRs and no spills in any geometry (the 65536-point one spilled 100 B/lane), K1 2.03
-// -> 1.93 ms per facet; column passes and the subgrid-side kernels unchanged (bandwidth / LDS bound).  With the
-// VALU share at ~58 % of the kernel's cycles the row kernel is now bound by its LDS exchanges and by how well the
-// two resident workgroups' load and compute phases interleave.
-#ifndef SWF_PK
-#define SWF_PK 1
-#endif
+// Hand-packed complex64 arithmetic.  A complex value is one 64-bit VGPR pair; add / subtract are one v_pk_add_f32, a
+// general product is v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers doing the swaps and sign changes (the
+// compiler's own lowering of the same expressions needs a v_xor per product because it does not fold a one-lane
+// negation into neg_lo), and the (a - c) * {-i, W8, W8^3} butterflies fold their rotation into the subtraction.
+// VOP3P modifiers: op_sel[i] / op_sel_hi[i] pick the half of source i that feeds the low / high result lane,
+// neg_lo / neg_hi negate source i for that lane.
+// Measured on MI355X (r2, same-box A/B against the plain scalar forms): the band row kernel 1675 instead of 2416 VALU
+// instructions per wave, 117 instead of 128 VGPRs and no spills in any geometry, K1 2.03 -> 1.93 ms per facet; column
+// passes and the subgrid-side kernels unchanged (bandwidth / LDS bound).  Forms that were measured and dropped (numbers
+// in DESIGN.md section 4): the compiler's own 2-vector lowering of the product (column passes 18 % slower: v_mov
+// shuffles), both halves of a product in ONE asm statement (r5: drops 92 `s_nop 0` per wave, K1 1.644 vs 1.644 ms).
 __device__ __forceinline__ f32x2 pkv(cx<float> a) { return f32x2{a.x, a.y}; }
 __device__ __forceinline__ cx<float> pkc(f32x2 v) { return {v.x, v.y}; }
-#if SWF_PK
-#if !SWF_PACKED_ADD
 __device__ __forceinline__ cx<float> operator+(cx<float> a, cx<float> b) { return pkc(pkv(a) + pkv(b)); }
 __device__ __forceinline__ cx<float> operator-(cx<float> a, cx<float> b) { return pkc(pkv(a) - pkv(b)); }
-#endif
-#if !SWF_PACKED_CMUL
 template <>
 __device__ __forceinline__ cx<float> cmul<float>(cx<float> a, cx<float> b) {
     f32x2 t, r;
@@ -104,8 +67,6 @@ __device__ __forceinline__ cx<float> cmul<float>(cx<float> a, cx<float> b) {
         : "v"(av), "v"(bv), "v"(t));
     return pkc(r);
 }
-#endif
-#endif  // SWF_PK
 // (a - c) * (-i) = (a.y - c.y, c.x - a.x)
 __device__ __forceinline__ cx<float> pk_sub_mi(cx<float> a, cx<float> c) {
     f32x2 r;
@@ -206,10 +167,10 @@ __device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
         return {-d.x, -d.y};
     } else if constexpr (n == 48) {  // +i
         return {-d.y, d.x};
-    } else if constexpr (n == 8 && std::is_same<R, float>::value && SWF_PK) {
+    } else if constexpr (n == 8 && std::is_same<R, float>::value) {
         constexpr float c = 0.70710678118654752f;
         return pkc(pk_rot8(pkv(d)) * f32x2{c, c});
-    } else if constexpr (n == 24 && std::is_same<R, float>::value && SWF_PK) {
+    } else if constexpr (n == 24 && std::is_same<R, float>::value) {
         constexpr float c = 0.70710678118654752f;
         return pkc(pk_rot24(pkv(d)) * f32x2{c, c});
     } else if constexpr (n == 8) {  // (1 - i)/sqrt2
@@ -220,7 +181,7 @@ __device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
         return {(d.y - d.x) * c, -(d.x + d.y) * c};
     } else {
         constexpr R c = (R)cos64(n), s = (R)(-sin64(n));
-        if constexpr (std::is_same<R, float>::value && (SWF_PACKED_CMUL || SWF_PK)) {
+        if constexpr (std::is_same<R, float>::value) {
             // (d.x, d.x)*(c, s) + (d.y, d.y)*(-s, c) as two packed instructions
             const f32x2 dx = {d.x, d.x}, dy = {d.y, d.y};
             const f32x2 k0 = {c, s}, k1 = {-s, c};
@@ -235,9 +196,9 @@ __device__ __forceinline__ cx<R> mul_w64(cx<R> d) {
 // (a - c) * exp(-2 pi i NUM / 64): the lower output of a DIF butterfly
 template <typename R, int NUM>
 __device__ __forceinline__ cx<R> sub_mul_w64(cx<R> a, cx<R> c) {
-    if constexpr (std::is_same<R, float>::value && SWF_PK && (NUM & 63) == 16) {
+    if constexpr (std::is_same<R, float>::value && (NUM & 63) == 16) {
         return pk_sub_mi(a, c);
-    } else if constexpr (std::is_same<R, float>::value && SWF_PK && (NUM & 63) == 48) {
+    } else if constexpr (std::is_same<R, float>::value && (NUM & 63) == 48) {
         return pk_sub_pi(a, c);
     } else {
         return mul_w64<R, NUM>(a - c);
@@ -308,22 +269,10 @@ constexpr int lds_delta(int d, bool rowfast) {
 // butterfly inputs x[U + r*NB], r = 1..RAD-1.  Powers of two come from the
 // table (tw[k] = exp(-2 pi i k / N)), the rest from at most log2(RAD)-1
 // complex products, which keeps the error at a few ulp.
-// Two-factor form (SWF_TW_TWO_FACTOR=1, off by default): r = Q*hi + lo with Q = 2^ceil(LOGR/2); w^lo (lo < Q) and
-// w^(Q hi) come straight from the table (exactly rounded), every other w^r is ONE product of two table values.
-// Measured on MI355X (r2, same-box A/B): end-to-end complex64 error 1.0137e-5 vs 1.0172e-5 for the chained form
-// below -- twiddle rounding is NOT what sets the float32 floor (storage rounding of window-amplified intermediates
-// is) -- while its Q live table values cost registers in the 128-VGPR row kernel
-// (K1 20.3 -> 21.8 ms per pass).
-#ifndef SWF_TW_TWO_FACTOR
-#define SWF_TW_TWO_FACTOR 0
-#endif
-// SWF_TW_TABLE=1: every inter-phase twiddle w^r loaded from the table instead of LOGR loads + products (saves ~330
-// of the row kernel's ~3200 VALU instructions per wave, costs 48 more 8-byte loads per lane).  Measured on MI355X
-// (r2, same-box A/B): K1 2.06 -> 3.30 ms per facet, whole pass 47.8 -> 58.1 ms -- the dependent loads sit in the
-// critical path of every phase; the kernel is VALU-issue-bound only because its memory latency is already hidden.
-#ifndef SWF_TW_TABLE
-#define SWF_TW_TABLE 0
-#endif
+// Forms that were measured and dropped (r2, same-box A/B): a two-factor form (every w^r ONE product
+// of two exactly rounded table values): end-to-end complex64 error 1.0137e-5 vs 1.0172e-5 -- twiddle rounding is not what
+// sets the float32 error -- at +1.5 ms of K1 per pass (registers); every w^r loaded from the table (-330 VALU, +48 loads per
+// lane): K1 2.06 -> 3.30 ms per facet, the dependent loads sit in the critical path of every phase.
 // geometries may ask for the register-lean twiddle form at every radix (kernels that keep an accumulator in registers
 // next to the transform: swiftly_groupfinish.h): `static constexpr bool LEAN_TW = true`
 template <class G, class = void>
@@ -339,42 +288,11 @@ template <typename R, int LOGR, int NB, int U, int PTOT, int N, bool LEAN = fals
 __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __restrict__ tw, int kidx,
                                                const cx<R>* pre = nullptr) {
     constexpr int RAD = 1 << LOGR;
-    if constexpr (SWF_TW_TWO_FACTOR && LOGR >= 2) {
-        constexpr int LQ = (LOGR + 1) / 2, Q = 1 << LQ, NH = RAD / Q;
-        cx<R> wlo[Q];
-        static_for<1, Q>([&](auto lI) {
-            constexpr int lo = decltype(lI)::value;
-            wlo[lo] = tw[(kidx * lo) & (N - 1)];
-        });
-        static_for<0, NH>([&](auto hI) {
-            constexpr int hi = decltype(hI)::value;
-            cx<R> wh = {(R)1, (R)0};
-            if constexpr (hi > 0) wh = tw[(kidx * (Q * hi)) & (N - 1)];
-            static_for<0, Q>([&](auto lI) {
-                constexpr int lo = decltype(lI)::value;
-                constexpr int r = Q * hi + lo;
-                if constexpr (r > 0) {
-                    cx<R> w;
-                    if constexpr (hi == 0)
-                        w = wlo[lo];
-                    else if constexpr (lo == 0)
-                        w = wh;
-                    else
-                        w = cmul(wh, wlo[lo]);
-                    x[U + r * NB] = cmul(x[U + r * NB], w);
-                }
-            });
-        });
-    } else if constexpr (SWF_TW_TABLE && std::is_same<R, float>::value) {
-        // every w^r straight from the table: RAD-1 loads (L1/L2-resident table) instead of LOGR loads and
-        // sum(popcount(r) - 1) complex products -- trades VALU issue slots for vector-memory ones
-        static_for<1, RAD>([&](auto rI) {
-            constexpr int r = decltype(rI)::value;
-            x[U + r * NB] = cmul(x[U + r * NB], tw[(kidx * r) & (N - 1)]);
-        });
-    } else if constexpr (LOGR >= 5 || LEAN) {
-        // register-lean form: keep only the LOGR table values alive and build
-        // each w^r from the set bits of r
+    if constexpr (LOGR >= 5 || LEAN) {
+        // register-lean form: keep only the LOGR table values alive and build each w^r from the set bits of r (the
+        // partial products of different powers are the same asm statements on the same operands, which the compiler
+        // merges: 26 products per radix-32 phase in the ISA, i.e. one per composite power -- an explicit tree walk
+        // compiles to the same instruction counts, r5)
         cx<R> wp[LOGR];
         static_for<0, LOGR>([&](auto bI) {
             constexpr int b = decltype(bI)::value;
@@ -422,19 +340,16 @@ __device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<
         fft_reg<R, LOGR, NB, u, G::P>(x);
     });
 }
-// SWF_TW_PRELOAD (default 1; geometries with `static constexpr bool PRELOAD_TW = true`, r4c: RGeoPre = the forward K1): the LOGR table values the next phase's
-// inter-phase twiddles are built from are requested BEFORE the exchange that precedes the phase, so that their latency
-// (an L2 hit: the table is shared by every workgroup) hides under the exchange instead of following its last barrier
-#ifndef SWF_TW_PRELOAD
-#define SWF_TW_PRELOAD 1
-#endif
+// Geometries with `static constexpr bool PRELOAD_TW = true` (r4c: RGeoPre = the forward K1): the LOGR table values the next
+// phase's inter-phase twiddles are built from are requested BEFORE the exchange that precedes the phase, so that their
+// latency (an L2 hit: the table is shared by every workgroup) hides under the exchange instead of following its last barrier
 template <class G, class = void>
 struct preload_tw_of {
     static constexpr bool value = false;
 };
 template <class G>
 struct preload_tw_of<G, std::enable_if_t<G::PRELOAD_TW>> {
-    static constexpr bool value = SWF_TW_PRELOAD != 0;
+    static constexpr bool value = true;
 };
 
 // One Stockham phase, scatter part: f(e, value) for every output element of
@@ -500,14 +415,10 @@ __device__ __forceinline__ void gather_pass(int t, int rb, bool rowfast, const T
 
 // Synchronisation between the scatter and the gather of an exchange.  A row whose T threads sit inside ONE wave
 // (T <= 64, row-per-wave-slice layout) needs no workgroup barrier: the LDS operations of a wave execute in order, so
-// an ordering point for the compiler is enough and the waves of the workgroup stop marching in lock-step
-// (SWF_WAVE_SYNC=0 restores the barriers for A/B runs).
-#ifndef SWF_WAVE_SYNC
-#define SWF_WAVE_SYNC 1
-#endif
+// an ordering point for the compiler is enough and the waves of the workgroup stop marching in lock-step.
 template <class G>
 __device__ __forceinline__ void row_sync(bool rowfast) {
-    if constexpr (SWF_WAVE_SYNC && G::WAVE_ROWS) {
+    if constexpr (G::WAVE_ROWS) {
         if (rowfast)
             __syncthreads();
         else

@@ -16,15 +16,9 @@ namespace swf {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// buffer (range-checked) accesses in the band row kernel: A/B switches.  Measured (r2, same box, K1 per pass):
-// global loads + exec-masked stores 20.2 ms (at 86 spilled VGPRs in some variants: 51 ms -- the kernel sits at the
-// 128-VGPR limit), buffer loads 20.3 ms with ~10 % fewer instructions and no spills (default), buffer stores too 20.7 ms.
-#ifndef SWF_ROW_BUFFER
-#define SWF_ROW_BUFFER 1
-#endif
-#ifndef SWF_ROW_BUFFER_ST
-#define SWF_ROW_BUFFER_ST 0
-#endif
+// The band row kernel loads through BUFFER (range-checked) accesses.  Measured (r2, same box, K1 per pass): global loads +
+// exec-masked stores 20.2 ms (at 86 spilled VGPRs in some variants: 51 ms -- the kernel sits at the 128-VGPR limit), buffer
+// loads 20.3 ms with ~10 % fewer instructions and no spills (kept), buffer stores too 20.7 ms (not kept).
 
 struct RowPassArgs {
     const cx<float>* in;
@@ -90,30 +84,8 @@ struct RGeoPre : RGeo<LOGN_, LOGP_, SPLIT_, PAD_> {
 
 __device__ const float kRowOne = 1.f;
 
-// non-temporal accesses in the long-row kernel: loads measured much slower (the input row is read by two
-// workgroups: K2 25 -> 37.5 ms); stores are a separate switch
-#ifndef SWF_NT_ROW
-#define SWF_NT_ROW 0
-#endif
-#ifndef SWF_NT_ROW_ST
-#define SWF_NT_ROW_ST 0
-#endif
-__device__ __forceinline__ cx<float> rp_load(const cx<float>* p) {
-#if SWF_NT_ROW
-    const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
-    return {v.x, v.y};
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void rp_store(cx<float>* p, cx<float> v) {
-#if SWF_NT_ROW || SWF_NT_ROW_ST
-    const f32x2 w = {v.x, v.y};
-    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
-#else
-    *p = v;
-#endif
-}
+// (non-temporal accesses in the long-row kernels: loads measured much slower -- the input row is read by two workgroups:
+// K2 25 -> 37.5 ms, r2; non-temporal band stores: K1 1.73 -> 1.95 ms per facet, r4 -- so they are plain)
 
 // MODE 0: mapped load (window, pad, shift), identity store   -- prepare_facet / prepare_subgrid style
 // MODE 1: identity load, mapped store (shift, crop, windows)  -- finish_facet / finish_subgrid style
@@ -298,7 +270,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
             const int qs = ok ? qq : 0;
             unsigned idx = (unsigned)(qs + A.ld_c);
             if (idx >= (unsigned)A.ld_mod) idx -= (unsigned)A.ld_mod;
-            const cx<float> a = rp_load(in + idx);
+            const cx<float> a = in[idx];
             float w = ok ? alive : 0.f;
             if constexpr (HAS_WIN) w *= ld_win[qs];
             const float ax = a.x * w, ay = a.y * w * sg_ld;
@@ -313,7 +285,7 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
         const int ck = (S * e + h) ^ (N >> 1);
         v.x *= A.scale;
         v.y *= A.scale * sg_st;
-        rp_store(out + ck, v);
+        out[ck] = v;
     });
 }
 
@@ -362,9 +334,6 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // but at most two r the whole wave is inside or outside the band: that decision is made on the SCALAR unit, outputs the
 // wave does not keep (65 % on the 64k workload) cost two scalar instructions instead of the rotation phase product,
 // the scale and five address / compare operations, and kept outputs are stored at  SGPR base + lane * 8.
-#ifndef SWF_ROW_UNIFORM_ST
-#define SWF_ROW_UNIFORM_ST 1
-#endif
 template <class G, bool HAS_WIN, int ST, bool PAIR = false, int NSEG = 0, int CJ = -1>
 __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                  cx<float>* __restrict__ gout,
@@ -501,7 +470,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
             });
         }
     } else {
-#if SWF_ROW_BUFFER
     const unsigned valid = dead ? 0u : (unsigned)A.ld_len;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
@@ -530,29 +498,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         else
             x[v] = cx<float>{0.f, 0.f};
     });
-#else
-    static_assert(!SEGSKIP, "segment skipping is implemented on the buffer-load path");
-    const int base = (t + A.ld_a + (N >> 1)) & (N - 1);  // q of plain index j = t (centred index j ^ N/2 = j + N/2 mod N)
-    const float alive = dead ? 0.f : 1.f;
-    static_for<0, P>([&](auto vI) {
-        constexpr int v = decltype(vI)::value;
-        cx<float> a[2];
-        static_for<0, 2>([&](auto qI) {
-            constexpr int q = decltype(qI)::value;
-            const int qq = (base + v * T + q * H) & (N - 1);
-            const bool ok = qq < A.ld_len;
-            const unsigned qs = ok ? (unsigned)qq : 0u;
-            const f32x2 val = *reinterpret_cast<const f32x2*>(inb + (qs << 3));
-            float w = ok ? alive : 0.f;
-            if constexpr (HAS_WIN) {
-                const float wv = *reinterpret_cast<const float*>(winb + (qs << 2));
-                w = ok ? wv * alive : 0.f;
-            }
-            a[q] = cx<float>{val.x * w, val.y * w};
-        });
-        x[v] = cx<float>{a[0].x + sgn * a[1].x, (a[0].y + sgn * a[1].y) * sg_ld};
-    });
-#endif
     if (h) {  // uniform: odd outputs need W_N^j = W_N^t * W_64^v
         const cx<float> wt = tw_full[t];
         static_for<0, P>([&](auto vI) {
@@ -578,12 +523,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     // band store: d = (ck - band_start) mod N has the parity of h ^ band_start for the whole workgroup, so the
     // destination (d & 1) * band_half + (d >> 1) is  region base + (d >> 1)
     const unsigned region = BAND ? (unsigned)(((h ^ A.band_start) & 1) * A.band_half) << 3 : 0u;
-#if SWF_ROW_BUFFER_ST
-    // buffer stores: an offset outside the descriptor is dropped by the hardware, so outputs outside the band need
-    // no branch -- their offset is simply pushed out of range
-    const unsigned out_bytes = (unsigned)(BAND ? 2 * A.band_half : N) << 3;
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb, (short)0, (int)out_bytes, 0x00020000);
-#endif
     if constexpr (ST == 2) {
         // ONE output window (the host combines mask and 1/PSWF), fetched for all P outputs of the lane before the
         // last butterflies: a load per output inside the store loop costs a full memory latency per element
@@ -625,7 +564,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         return;
     }
     constexpr bool ONEBLK = PAIR || (G::LOGN % G::LOGP == 0);  // last phase: one block per lane, outputs e = t + r T
-    if constexpr (BAND && ONEBLK && CJ >= 0 && SWF_ROW_UNIFORM_ST) {
+    if constexpr (BAND && ONEBLK && CJ >= 0) {
         constexpr int LNS = G::LOGN - G::LOGP;
         static_assert(T == (1 << LNS), "e = t + (r << LNS)");
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -665,16 +604,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         const int ck = (2 * e + h) ^ (N >> 1);
         if constexpr (SEGSKIP) v = cmul(v, rphi);
         const f32x2 val = {v.x * scale, v.y * scale_im};
-#if SWF_ROW_BUFFER_ST
-        unsigned off;
-        if constexpr (BAND) {
-            const int d = (ck - A.band_start) & (N - 1);
-            off = d < A.band_len ? region + ((unsigned)(d >> 1) << 3) : 0x40000000u;
-        } else {
-            off = (unsigned)ck << 3;
-        }
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)off, 0, 0);
-#else
         if constexpr (BAND) {
             const int d = (ck - A.band_start) & (N - 1);
             if (d < A.band_len)
@@ -682,7 +611,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         } else {
             *reinterpret_cast<f32x2*>(outb + ((unsigned)ck << 3)) = val;
         }
-#endif
     });
 #if SWF_TRACE
     SWF_TRACE_POINT(7);

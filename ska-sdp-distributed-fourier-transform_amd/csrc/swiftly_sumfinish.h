@@ -16,13 +16,9 @@ namespace swf {
 
 // threads per workgroup of the row-wise fused kernels (one wave per row: NT / 64 rows per workgroup).
 // Measured (r2, same-box A/B): 128 gives the same time as 256 (K3-5 10.8 vs 10.7 ms per pass).
-#ifndef SWF_SF_NT
-#define SWF_SF_NT 256
-#endif
-// facets whose rows are in flight together in sum_finish_facets_kernel (registers: SF_NB * m / 64 complex values)
-#ifndef SWF_SF_NB
-#define SWF_SF_NB 3
-#endif
+constexpr int kSumFinishThreads = 256;
+// facets whose rows are in flight together in sum_finish_facets_kernel (registers: kSumFinishInFlight * m / 64 complex values)
+constexpr int kSumFinishInFlight = 3;
 constexpr int kSumFinishMaxGroups = 8;
 constexpr int kSumFinishMaxBatch = 64;
 
@@ -54,7 +50,7 @@ struct SFGeo {
     // threads per workgroup.  2048-point rows (21.7 KB of LDS per row): ONE row per workgroup so that seven rows fit
     // a CU (four rows per workgroup = 87 KB = one workgroup of four waves per CU: measured r3 on the N = 8192
     // workload, 485 us per wave of 8 subgrids); 4096-point rows: the row IS the workgroup (four waves)
-    static constexpr int NT = LOGX >= 12 ? 256 : (LOGX == 11 ? 64 : SWF_SF_NT);
+    static constexpr int NT = LOGX >= 12 ? 256 : (LOGX == 11 ? 64 : kSumFinishThreads);
     using GM = Geo<float, LOGM, LOGM - LOGTR, NT, false>;
     using GX = Geo<float, LOGX, LOGX - LOGTR, NT, false>;
     static_assert(LOGM - LOGTR >= 1, "at least two points per lane");
@@ -330,7 +326,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
     static_for<0, PX>([&](auto vI) { y[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
     __syncthreads();
     // (8 points per lane and 1024-point rows: two facets in flight keep the kernel at 128 VGPRs without spills)
-    constexpr int NB = (PM >= 8 && LOGX <= 10 && SWF_SF_NB > 2) ? 2 : SWF_SF_NB;
+    constexpr int NB = (PM >= 8 && LOGX <= 10 && kSumFinishInFlight > 2) ? 2 : kSumFinishInFlight;
     for (int g = 0; g < A.ngroups; g++) {  // workgroup-uniform
         cx<float> xs[PM];
         static_for<0, PM>([&](auto vI) { xs[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
