@@ -83,7 +83,11 @@ constexpr size_t sum_finish_facets_lds() {
     return SFWide<LOGM, LOGX>::ON ? SFWide<LOGM, LOGX>::LDS_BYTES : SFGeo<LOGM, LOGX>::LDS_BYTES;
 }
 // sum_finish_facets_kernel, one wave per row (r4): the accumulator row lives in REGISTERS (see the kernel), so LDS only
-// holds ONE exchange buffer per row -- used by the m-point transforms first, by the xM-point transform last -- and Fn
+// holds ONE exchange buffer per row -- used by the m-point transforms first, by the xM-point transform last -- and Fn.
+// (r5: re / im exchanged separately -- rows are wave-private, so it costs LDS instructions but no barrier -- halves the
+// buffer and would admit 32 instead of 16 waves per CU, but the <9,10> instance needs 113 VGPRs: at 5 waves per SIMD
+// (96 VGPRs, 64 B of scratch per lane) the subgrid side takes 9.58 instead of 8.98 ms per pass, at 8 waves per SIMD (64
+// VGPRs, 184 B of scratch) 14.1 ms; not kept)
 template <int LOGM, int LOGX>
 constexpr size_t sum_finish_facets_reg_lds() {
     using S = SFGeo<LOGM, LOGX>;
