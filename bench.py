@@ -605,6 +605,17 @@ def quick_forward(torch, sw, sw_api, name, passes=3):
     )
 
 
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a process group is created; with stdout redirected it sits in
+    the C buffer until exit, i.e. AFTER the JSON line.  Flushing it as soon as it exists keeps the JSON line last."""
+    import ctypes  # pylint: disable=import-outside-toplevel
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -629,6 +640,11 @@ def main():
     ap.add_argument("--verify", action="store_true", help="(default) kept for explicitness")
     ap.add_argument("--no-backward", action="store_true",
                     help="skip the subgrid -> facet leg (reported beside the headline metric, outside its timed region)")
+    ap.add_argument("--rccl-dry", action="store_true",
+                    help="1 GPU only, unmeasured-on-links rehearsal of the multi-GPU path: a one-rank RCCL process group is "
+                         "created and the pass runs through DistributedForward with the REAL all_to_all_single calls (split "
+                         "sizes of one rank, the real send / receive buffers, RCCL's stream against the compute stream); "
+                         "the line says so in `config.parallelism` and is not a scaling measurement")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short forward runs of BASELINE configs 2 and 3 (`other_workloads`) that follow the default "
                          "workload's measurement")
@@ -663,11 +679,22 @@ def main():
     if torch.cuda.device_count() < world and os.environ.get("SWIFTLY_BENCH_OVERSUBSCRIBE") != "1":
         raise SystemExit(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if args.rccl_dry:
+        if world != 1:
+            raise SystemExit("bench.py: --rccl-dry is a one-rank rehearsal (use it with --gpus 1)")
+        from ska_sdp_exec_swiftly_amd import distributed as sw_dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        _flush_c_stdio()
+        sw_dist.FORCE_COLLECTIVE = True  # one-rank exchanges go through RCCL instead of being short-circuited
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; SWIFTLY_BENCH_BACKEND=gloo (+ SWIFTLY_BENCH_OVERSUBSCRIBE=1) runs several ranks on ONE
         # GPU with a host-staged exchange -- a functional check of this launcher path, not a measurement
         torch.distributed.init_process_group(os.environ.get("SWIFTLY_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        _flush_c_stdio()
 
     wl = WORKLOADS[args.workload]
     p = wl["params"]
@@ -681,7 +708,7 @@ def main():
     all_sg_cfgs = sw.make_full_subgrid_cover(cfg)
     sg_cfgs = select_subgrids(all_sg_cfgs, p["N"], p["xA_size"], wl["sparse_radius"])
     force_dist = os.environ.get("SWIFTLY_BENCH_FORCE_DIST") == "1"  # exercise the multi-GPU code path on 1 GPU
-    single = world == 1 and not force_dist
+    single = world == 1 and not force_dist and not args.rccl_dry
     wave_axis = sw_api.preferred_wave_axis(cfg, torch.complex64, n_facets=len(facet_cfgs))
     if args.wave_axis is not None:
         wave_axis = args.wave_axis
@@ -736,7 +763,7 @@ def main():
 
     else:
 
-        grouped = args.exchange == "group" and wave_axis == 1 and world > 1
+        grouped = args.exchange == "group" and wave_axis == 1 and (world > 1 or args.rccl_dry)
         index_of = {(c.off0, c.off1): i for i, c in enumerate(sg_cfgs)}
 
         def one_pass(timer=None, keep=None):  # pylint: disable=unused-argument
@@ -1114,7 +1141,7 @@ def main():
         value=round(F * S / (ms_per_step * 1e-3), 1),
         unit="contributions/s",
         n_gpus=world,
-        rccl_ranks=world if world > 1 and os.environ.get("SWIFTLY_BENCH_BACKEND", "nccl") == "nccl" else 0,
+        rccl_ranks=world if (world > 1 or args.rccl_dry) and os.environ.get("SWIFTLY_BENCH_BACKEND", "nccl") == "nccl" else 0,
         steps=args.steps,
         warmup=args.warmup,
         ms_per_step=round(ms_per_step, 3),
@@ -1131,7 +1158,8 @@ def main():
             parallelism=(f"facets sharded over {world} rank(s) (facets beyond a full round worked on cooperatively: K1 by "
                          f"row blocks, K2/K3 by wave ranges), contribution all-to-all per "
                          + ("group of waves with distinct owners" if args.exchange == "group" and wave_axis == 1 else "wave"))
-            if world > 1 else "1 GPU",
+            if world > 1 else ("1 GPU, ONE-RANK RCCL REHEARSAL of the multi-GPU path (--rccl-dry): every exchange is a real "
+                               "all_to_all_single of one rank; not a scaling measurement" if args.rccl_dry else "1 GPU"),
         ),
         hbm_algorithmic_gbs=round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
         hbm_algorithmic_frac_of_peak=round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4),
@@ -1164,14 +1192,17 @@ def main():
                 line["other_workloads"][other] = quick_forward(torch, sw, sw_api, other)
             except Exception as err:  # pylint: disable=broad-except
                 line["other_workloads"][other] = dict(error=f"{type(err).__name__}: {err}")
+    if world > 1 or args.rccl_dry:
+        torch.cuda.synchronize()
+        torch.distributed.destroy_process_group()
+        _flush_c_stdio()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p, F, S, C)
             line["cpu_baseline"]["value"] = round(line["cpu_baseline"]["value"], 3)
             line["speedup_vs_cpu_host"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
-        print(json.dumps(line))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
     if parity is not None and not parity["ok"]:
         raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {parity['tol_rel_rmse']}")
     for other, rec in (line.get("other_workloads") or {}).items():

@@ -65,6 +65,7 @@ class FacetSharding:
 
     def __init__(self, n_facets, rank, world, balance=True, wave_keys=None, wave_sizes=None):
         self.n_facets, self.rank, self.world = n_facets, rank, world
+        self._memo = {}  # layouts by (direction, subgrids, block size, wave key): a plan's waves come back every pass
         # wave_sizes = {wave key: subgrids in the wave}: WHOLE waves are owned by single ranks (largest waves first,
         # always to the rank with the fewest subgrids so far) instead of every wave being dealt out subgrid by subgrid.
         # At 8 ranks a rank then finishes ~3 whole waves of ~20 subgrids instead of 25 x 2-3 subgrids: the subgrid-side
@@ -74,7 +75,7 @@ class FacetSharding:
         # `world` waves with distinct owners (``wave_groups``): one balanced all-to-all per group
         # (DistributedForward.start_group / finish_group).
         self.wave_rank, self.wave_groups = None, None
-        if wave_sizes is not None and world > 1:
+        if wave_sizes is not None:  # (world = 1 too: groups of one wave -- the one-rank rehearsal of bench.py --rccl-dry)
             load = [0] * world
             self.wave_rank, self.wave_groups = {}, []
             by_size = sorted(wave_sizes.items(), key=lambda kv: (-kv[1], kv[0]))
@@ -181,30 +182,59 @@ def _all_to_all(send, in_counts, out_counts, group=None, async_op=True):
     return _Pending(work if async_op else None, recv, send)
 
 
+def _shared_sharding(core, n_facets, rank, world, wave_keys, wave_sizes):
+    """The sharding of a (cover, plan, rank) -- pure bookkeeping derived from the arguments -- is kept on the core, so
+    that the objects of consecutive passes over one plan share it and its layout memo (r4 review: 3.8 ms of Python per
+    pass and rank against a 6.4 ms GPU budget at 8 ranks)."""
+    cache = core.__dict__.setdefault("_sharding_cache", {})
+    ck = (n_facets, rank, world, None if wave_keys is None else tuple(int(k) for k in wave_keys),
+          None if wave_sizes is None else tuple(sorted((int(k), int(v)) for k, v in wave_sizes.items())))
+    hit = cache.get(ck)
+    if hit is None:
+        if len(cache) >= 64:
+            cache.clear()
+        hit = cache[ck] = FacetSharding(n_facets, rank, world, wave_keys=wave_keys, wave_sizes=wave_sizes)
+    return hit
+
+
 def forward_layout(sharding, n_subgrids, blk, key=None):
     """Element counts of the forward exchange: (per-destination subgrid index lists, in_counts, out_counts); ``key``
     = the wave key when facets are worked on cooperatively (the senders' item counts depend on the wave)."""
-    F_local = len(sharding.items_of(sharding.rank, key))
-    mine = sharding.subgrids_of(n_subgrids, key=key)
-    dests = [sharding.subgrids_of(n_subgrids, r, key) for r in range(sharding.world)]
-    in_counts = [F_local * len(d) * blk for d in dests]
-    out_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
-    return dests, in_counts, out_counts
+    memo = sharding._memo  # pylint: disable=protected-access
+    hit = memo.get(("f", n_subgrids, blk, key))
+    if hit is None:
+        F_local = len(sharding.items_of(sharding.rank, key))
+        mine = sharding.subgrids_of(n_subgrids, key=key)
+        dests = [sharding.subgrids_of(n_subgrids, r, key) for r in range(sharding.world)]
+        in_counts = [F_local * len(d) * blk for d in dests]
+        out_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
+        hit = memo[("f", n_subgrids, blk, key)] = (dests, in_counts, out_counts)  # shared: callers do not modify them
+    return hit
 
 
 def backward_layout(sharding, n_subgrids, blk, key=None):
     """Element counts of the backward exchange (subgrid holder -> facet owner)."""
-    mine = sharding.subgrids_of(n_subgrids, key=key)
-    F_local = len(sharding.items_of(sharding.rank, key))
-    in_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
-    out_counts = [F_local * len(sharding.subgrids_of(n_subgrids, r, key)) * blk for r in range(sharding.world)]
-    return in_counts, out_counts
+    memo = sharding._memo  # pylint: disable=protected-access
+    hit = memo.get(("b", n_subgrids, blk, key))
+    if hit is None:
+        mine = sharding.subgrids_of(n_subgrids, key=key)
+        F_local = len(sharding.items_of(sharding.rank, key))
+        in_counts = [len(sharding.items_of(r, key)) * len(mine) * blk for r in range(sharding.world)]
+        out_counts = [F_local * len(sharding.subgrids_of(n_subgrids, r, key)) * blk for r in range(sharding.world)]
+        hit = memo[("b", n_subgrids, blk, key)] = (in_counts, out_counts)
+    return hit
+
+
+# One-rank rehearsal (bench.py --rccl-dry, tests): with FORCE_COLLECTIVE the exchange of a ONE-rank group still goes
+# through the backend's all_to_all_single (a self-copy through RCCL on its own stream) instead of being short-circuited.
+FORCE_COLLECTIVE = False
 
 
 def exchange_blocks(send, in_counts, out_counts, group=None, async_op=True):
     """Start the all-to-all of an already laid-out send buffer; ``wait()`` returns the flat receive buffer."""
     torch = _torch()
-    if not (torch.distributed.is_available() and torch.distributed.is_initialized()) or len(in_counts) == 1:
+    ready = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if not ready or (len(in_counts) == 1 and not FORCE_COLLECTIVE):
         return _Pending(None, send, send)
     return _all_to_all(send.reshape(-1), in_counts, out_counts, group, async_op)
 
@@ -357,8 +387,8 @@ class DistributedForward:
             keys, band = _plan_wave_keys(self.core, self._plan)
             if band == (0, self.core.yN_size):
                 keys = None  # the plan needs the whole padded axis: no sub-bands to hand out
-        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys,
-                                      wave_sizes=_wave_sizes(self._plan, self.wave_axis) if whole_waves else None)
+        self.sharding = _shared_sharding(self.core, len(self.facet_configs), self.rank, self.world, keys,
+                                         _wave_sizes(self._plan, self.wave_axis) if whole_waves else None)
         local = self.sharding.local_facets
         self.local = None
         if local or not self.sharding.coop:
@@ -479,13 +509,17 @@ class DistributedForward:
         if self.fused and self.wave_axis == 1 and items:
             # one native call for the whole wave: block (f, i) of subgrid i = dests[d][k] goes to
             # chunk_base[d] + f * len(dests[d]) * m^2 + k * m^2
-            offs, fstr = [0] * len(sgs), [0] * len(sgs)
-            base = 0
-            for d, cnt in zip(dests, in_counts):
-                for k, i in enumerate(d):
-                    offs[i] = base + k * m * m
-                    fstr[i] = len(d) * m * m
-                base += cnt
+            placed = self.sharding._memo.get(("p", len(sgs), key))  # pylint: disable=protected-access
+            if placed is None:
+                offs, fstr = [0] * len(sgs), [0] * len(sgs)
+                base = 0
+                for d, cnt in zip(dests, in_counts):
+                    for k, i in enumerate(d):
+                        offs[i] = base + k * m * m
+                        fstr[i] = len(d) * m * m
+                    base += cnt
+                placed = self.sharding._memo[("p", len(sgs), key)] = (offs, fstr)  # pylint: disable=protected-access
+            offs, fstr = placed
             if F_whole:
                 self.local.wave_blocks_into(sgs, send, (offs, fstr))
             for n, j in enumerate(items[F_whole:]):  # cooperative facets this rank owns for this wave: items F_whole + n
@@ -632,8 +666,8 @@ class DistributedBackward:
             keys, band = _plan_wave_keys(core, plan)  # the same wave ranges as DistributedForward
             if band == (0, core.yN_size):
                 keys = None
-        self.sharding = FacetSharding(len(self.facet_configs), self.rank, self.world, wave_keys=keys,
-                                      wave_sizes=_wave_sizes(plan, self.wave_axis) if whole_waves else None)
+        self.sharding = _shared_sharding(core, len(self.facet_configs), self.rank, self.world, keys,
+                                         _wave_sizes(plan, self.wave_axis) if whole_waves else None)
         sh = self.sharding
         # facet owner side: accumulators of the local facets
         self.local = None
