@@ -317,6 +317,25 @@ def _import_reference():
 _CPU_CORE = {}
 
 
+def _cpu_warm(args):
+    """Untimed: bring one worker process up (imports, the PSWF and window tables of its core) so that the timed repeats
+    of all workers start together and run under full contention from their first second."""
+    p, _F, _seed = args
+    from oracle import swiftly_oracle as orc  # checker / baseline only
+
+    key = (p["W"], p["N"], p["xM_size"], p["yN_size"])
+    if _CPU_CORE.get("key") != key:
+        ref = _import_reference()
+        if ref is not None:
+            _CPU_CORE.update(key=key, core=ref[0](p["W"], p["N"], p["xM_size"], p["yN_size"]),
+                             finish=ref[1].sum_and_finish_subgrid, kind="reference")
+        else:
+            _CPU_CORE.update(key=key, core=orc.OracleCore(p["W"], p["N"], p["xM_size"], p["yN_size"]),
+                             finish=orc.sum_and_finish_subgrid, kind="port")
+    time.sleep(0.5)  # keeps this worker busy until every other worker has taken its own warm-up task
+    return _CPU_CORE["kind"]
+
+
 def _cpu_sample(args):
     """One worker's share of the CPU sample (runs in a separate process): the three task kinds Dask would run --
     prepare_facet of a facet slab (api.py:281-298), extract_column of some rows (api_helper.py:200-210),
@@ -376,6 +395,9 @@ def cpu_baseline(p, F, S, C):
     per_repeat = []
     # spawn: the parent holds an initialised HIP runtime, which must not be forked
     with ProcessPoolExecutor(cores, mp_context=multiprocessing.get_context("spawn")) as pool:
+        # (r5) untimed warm-up: in r4 the first repeat ran while the workers were still being spawned -- staggered, i.e.
+        # under less contention -- and came out 1.7-2.2x faster than the others (247 / 145 / 111 contributions/s)
+        list(pool.map(_cpu_warm, [(p, F, i) for i in range(cores)]))
         for rep in range(repeats):  # every repeat keeps all cores busy at once; the pool (and each worker's core) is reused
             per_repeat.append(list(pool.map(_cpu_sample, [(p, F, 1000 + rep * cores + i) for i in range(cores)])))
     wall = time.perf_counter() - t0
@@ -412,9 +434,10 @@ def cpu_baseline(p, F, S, C):
             f"({', '.join(f'{v:.0f}' for v in values)} contributions/s); wall time of all repeats {wall:.1f} s"
         ),
         extrapolated_seconds=total,
-        # (r4 advice) what the sample was, so that values stay comparable across rounds: method 2 (r4-r5) = slabs of
-        # 2e6 / 4e6 elements and the median of three repeats; method 1 (r1-r3) = 4e6 / 8e6 elements, one repeat
-        method=dict(version=2, k1_slab_elements=int(p["yB_size"]) * int(ncol), k2_slab_elements=int(nrow) * int(p["yB_size"]),
+        # (r4 advice) what the sample was, so that values stay comparable across rounds: method 3 (r5) = method 2 + an
+        # untimed warm-up task per worker; method 2 (r4) = slabs of 2e6 / 4e6 elements and the median of three repeats;
+        # method 1 (r1-r3) = 4e6 / 8e6 elements, one repeat
+        method=dict(version=3, warmup="one untimed task per worker (process start, PSWF tables) before the timed repeats", k1_slab_elements=int(p["yB_size"]) * int(ncol), k2_slab_elements=int(nrow) * int(p["yB_size"]),
                     k1_slab_columns=int(ncol), k2_slab_rows=int(nrow), repeats=repeats, statistic="median"),
     )
 
@@ -595,9 +618,39 @@ def quick_forward(torch, sw, sw_api, name, passes=3):
     torch.cuda.synchronize()
     par = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept, tol=wl.get("parity_tol"))
     total_bytes, _parts = algorithmic_bytes(p, F, S, C)
+    roundtrip = None
+    baxis = 1 if cfg.core.supports_backward_band(torch.complex64) else 0
+    if wl.get("roundtrip") and wave_axis == baxis:
+        # BASELINE config 5 is a round trip: the streaming form of the workload's own run (every forward wave folded
+        # straight into the backward accumulators), one warm-up + two timed passes
+        def roundtrip_pass():
+            fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, data)), lru_forward=1, subgrid_configs=sg_cfgs, wave_axis=wave_axis)
+            fwd.prepare_all_facets()
+            bwd = sw.SwiftlyBackward(cfg, facet_cfgs, lru_backward=1, subgrid_configs=sg_cfgs, wave_axis=baxis)
+            for widx in waves.values():
+                wave = [sg_cfgs[i] for i in widx]
+                res = fwd.get_wave(wave)
+                bwd.add_new_subgrid_tasks(wave, [res[k] for k in range(len(wave))])
+            del fwd
+            return bwd.finish()
+
+        each = []
+        for rep in range(3):
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            out = roundtrip_pass()
+            torch.cuda.synchronize()
+            if rep:
+                each.append(1e3 * (time.perf_counter() - tb))
+            finite = all(bool(torch.isfinite(torch.view_as_real(o)).all()) for o in out)
+            del out
+        rt = sum(each) / len(each)
+        roundtrip = dict(ms_per_pass=round(rt, 3), each_ms=[round(t, 2) for t in each], finite=finite,
+                         contributions_per_s_both_directions=round(2 * F * S / (rt * 1e-3), 1))
     del data
     torch.cuda.empty_cache()
     return dict(
+        roundtrip=roundtrip,
         workload=wl["name"], facets=F, subgrids=S, subgrid_columns=C, wave_axis=wave_axis, passes=passes,
         ms_per_step=round(ms, 3), contributions_per_s=round(F * S / (ms * 1e-3), 1),
         hbm_algorithmic_frac_of_peak=round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -646,7 +699,7 @@ def main():
                          "sizes of one rank, the real send / receive buffers, RCCL's stream against the compute stream); "
                          "the line says so in `config.parallelism` and is not a scaling measurement")
     ap.add_argument("--no-other-workloads", action="store_true",
-                    help="skip the short forward runs of BASELINE configs 2 and 3 (`other_workloads`) that follow the default "
+                    help="skip the short forward runs of BASELINE configs 2, 3 and 5 (`other_workloads`) that follow the default "
                          "workload's measurement")
     ap.add_argument("--wave-axis", type=int, default=None, choices=[0, 1],
                     help="force the forward pipeline: 0 = strided axis first (waves by off0), 1 = contiguous axis first")
@@ -1182,12 +1235,12 @@ def main():
     if len(facet_cfgs) < len(all_facet_cfgs):
         line["scaling"] = "weak (a rank holds at most %d facets: the facet subset grows with the ranks)" % cap
     if single and rank == 0 and args.workload == "64k-sparse" and not args.no_other_workloads and not args.no_verify:
-        # BASELINE configs 2 and 3 in the driver's line (r4 review): three timed forward passes each, after the headline
+        # BASELINE configs 2, 3 and 5 in the driver's line (r4 review): three timed forward passes each, after the headline
         # measurement and outside its timed region; the default workload's facets go back to the allocator first
         del facet_data[:]
         torch.cuda.empty_cache()
         line["other_workloads"] = {}
-        for other in ("8k", "32k-8x8"):
+        for other in ("8k", "32k-8x8", "128k"):  # BASELINE configs 2, 3 and 5 (5: the two facets one rank of eight holds)
             try:
                 line["other_workloads"][other] = quick_forward(torch, sw, sw_api, other)
             except Exception as err:  # pylint: disable=broad-except
