@@ -332,6 +332,8 @@ def _cpu_warm(args):
         else:
             _CPU_CORE.update(key=key, core=orc.OracleCore(p["W"], p["N"], p["xM_size"], p["yN_size"]),
                              finish=orc.sum_and_finish_subgrid, kind="port")
+    one = numpy.zeros((p["yB_size"], 1), dtype=numpy.complex64)
+    _CPU_CORE["core"].prepare_facet(one, 0, axis=0)  # first use of the length-yN transform in this process (plan, tables)
     time.sleep(0.5)  # keeps this worker busy until every other worker has taken its own warm-up task
     return _CPU_CORE["kind"]
 
