@@ -503,7 +503,10 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
             chunk_items = (int)std::max<uint64_t>(1, (uint64_t(128) << 20) / (n * 256 * sizeof(cx<float>)));
         }
     }
-    if (chunk_cols >= 64 && gathered && !(cz.flags & kZColScatter) && !c.gs && qmul == 0 &&         (nb > chunk_items || W > chunk_cols) && !own) {
+    // (r5: three or four chunk streams instead of two -- 41.4-42.1 ms per pass against 38.9-39.8 with the default chunks,
+    // 39.5-39.7 against 39.1-39.3 with chunks of 1 facet x 256 columns; one stream: 41.7 -- two streams stay)
+    if (chunk_cols >= 64 && gathered && !(cz.flags & kZColScatter) && !c.gs && qmul == 0 &&
+        (nb > chunk_items || W > chunk_cols) && !own) {
         const int Wc = std::min<int>((chunk_cols / 64) * 64, W), zc = std::min(chunk_items, nb);
         const size_t slot_elems = (size_t)n * (size_t)Wc * (size_t)zc;
         if (2 * slot_elems * sizeof(cx<float>) <= ws_bytes) {
