@@ -46,8 +46,8 @@ def relrms(a, b):
 # (golden file, parameters, facet seed, dtype, forward relRMSE bound, backward relRMSE bound)
 #  complex128: rounding only; the 1/pswf window (max ~4.9e3 at W=13.56) sets the level.
 #  complex64 is specified for the W~11 family (max 1/pswf ~ 90): float32 arithmetic in the
-#  length-yN transforms acts on window-amplified data, which puts the floor at ~1e-5 relative
-#  (numpy's own float32 FFT path reaches 7e-6 on these inputs, tools/f32_emulation.py).
+#  length-yN transforms acts on window-amplified data, which puts the error at ~1e-5 relative
+#  (tests/accuracy_model.py: float32 ARITHMETIC in K2 and K3 sets it; the float32 STORAGE floor is 3.3e-6).
 CASES = [
     ("roundtrip2d.npz", SMALL_PARAMS, 1234, numpy.complex128, 1e-10, 1e-9),
     ("roundtrip2d_w11.npz", SMALL11_PARAMS, 4321, numpy.complex128, 1e-11, 1e-10),
@@ -231,8 +231,8 @@ def test_sparse_plan_is_bit_identical():
 def test_forward_c64_test_params_fused_paths():
     """complex64 forward at the reference TEST_PARAMS sizes (m=128, xM=256): exercises the fused
     sum+finish row kernel instance (7, 8) and the batched K4a path against the oracle.  W=13.56 has
-    max 1/pswf ~ 4.9e3, so float32 only reaches ~1e-2 here (tools/f32_emulation.py: 8e-3 for numpy's
-    own float32 path); the check is against that floor, the tight complex64 checks use W=11."""
+    max 1/pswf ~ 4.9e3, so float32 only reaches ~1e-2 here (measured r2 with a float32 numpy chain: 8e-3);
+    the check is against that level, the tight complex64 checks use W=11."""
     import ska_sdp_exec_swiftly_amd as sw
 
     cfg = sw.SwiftlyConfig(backend="hip", **TEST_PARAMS)
