@@ -237,6 +237,7 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
     h->log_xM = ilog2_exact(xM);
     h->log_m = ilog2_exact(h->m);
     if (const char* e = getenv("SWIFTLY_COL_F64")) h->col_f64 = atoi(e) != 0;
+    if (const char* e = getenv("SWIFTLY_COL_F64_STAGES")) h->col_f64_stages = atoi(e) & 7;
     // windows: 1/pswf (Fb, core.py:104-108) and Fn (core.py:110-117)
     std::vector<double> ip(yN);
     std::vector<float> ipf(yN);
@@ -439,7 +440,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         ColPassArgs one = c;
         one.tw = twiddles<float>(h, logn);
         if (!one.tw) return -1;
-        one.f64 = f64 ? 1 : 0;
+        one.f64 = (f64 && (h->col_f64_stages & 4)) ? 1 : 0;
         one.twd = f64 ? twiddles<double>(h, logn) : nullptr;
         one.twd_full = one.twd;
         if (f64 && !one.twd) return -1;
@@ -561,7 +562,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
                     A.ld_mul = n2;
                     A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
                     A.tw = tw1; A.tw_full = twf;
-                    A.f64 = f64 ? 1 : 0; A.twd = twd1; A.twd_full = twdf;
+                    A.f64 = (f64 && (h->col_f64_stages & 1)) ? 1 : 0; A.twd = twd1; A.twd_full = twdf;
                     A.conj_st = 0; A.accumulate = 0; A.scale = 1.f;
                     A.col_win = nullptr; A.st_rowmap = nullptr; A.st_win = nullptr; A.st_win2 = nullptr;
                     rc = launch_col_checked(l1, 0, A, cz, n2, nz, s2);
@@ -578,7 +579,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
                     B.out = c.out + c0;
                     B.st_mul = n1;
                     B.tw = tw2; B.tw_full = twf;
-                    B.f64 = f64 ? 1 : 0; B.twd = twd2; B.twd_full = twdf;
+                    B.f64 = (f64 && (h->col_f64_stages & 2)) ? 1 : 0; B.twd = twd2; B.twd_full = twdf;
                     B.conj_ld = 0;
                     if (B.col_win) B.col_win += c0;
                     rc = launch_col_checked(l2, 1, B, zb, n1, nz, s2);
@@ -614,7 +615,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         A.ld_mul = n2;
         A.out_i_rows = a_i_rows; A.out_o_rows = a_o_rows;
         A.tw = tw1; A.tw_full = twf;
-        A.f64 = f64 ? 1 : 0; A.twd = twd1; A.twd_full = twdf;
+        A.f64 = (f64 && (h->col_f64_stages & 1)) ? 1 : 0; A.twd = twd1; A.twd_full = twdf;
         if (qmul > 0) {
             A.full_logn = logn; A.full_n = 0; A.ld_plain = 1; A.st_qmul = 0;
         }
@@ -637,7 +638,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
         B.out = c.out + c0;
         B.st_mul = n1;
         B.tw = tw2; B.tw_full = twf;
-        B.f64 = f64 ? 1 : 0; B.twd = twd2; B.twd_full = twdf;
+        B.f64 = (f64 && (h->col_f64_stages & 2)) ? 1 : 0; B.twd = twd2; B.twd_full = twdf;
         if (qmul > 0) {
             B.full_logn = logn; B.full_n = full_n; B.st_qmul = qmul; B.st_qadd = qadd;
         }

@@ -84,6 +84,10 @@ struct swiftly_hip {
     // float64 arithmetic in the column passes of the band pipelines (K2, K3 and their backward mirrors; complex64 data):
     // 0 (default: float32 arithmetic everywhere) | 1 (swiftly_hip_set_column_precision, env SWIFTLY_COL_F64)
     int col_f64 = 0;
+    // which of the column-pass stages compute in float64 when col_f64 is set (SWIFTLY_COL_F64_STAGES, default 7 = all; for
+    // the measured error / cost table of DESIGN.md section 2): 1 = pass A of a four-step, 2 = pass B, 4 = single-pass
+    // transforms (K3 and its backward mirror)
+    int col_f64_stages = 7;
     // two internal streams of the chunked four-step (col_transform): created on first use, under `chunk_mu` (the fork /
     // join events are per call: two host threads may drive one handle on different streams)
     hipStream_t chunk_st[2] = {nullptr, nullptr};
@@ -136,7 +140,7 @@ ColZ plain_colz();
 // single-pass launch of length 2^logn: float64 arithmetic when the handle asks for it and the instance exists
 inline void set_col_precision(const swiftly_hip* h, ColPassArgs& c, int logn) {
     c.f64 = 0;
-    if (!h->col_f64 || !col_pass_f64_supported(logn) || c.gs) return;
+    if (!h->col_f64 || !(h->col_f64_stages & 4) || !col_pass_f64_supported(logn) || c.gs) return;
     const cx<double>* t = twiddles<double>(h, logn);
     if (!t) return;
     c.f64 = 1;
