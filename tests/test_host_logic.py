@@ -310,3 +310,40 @@ def test_backward_wave_entry_points_check_the_wave_key():
     same_off1 = [api.SubgridConfig(0, 0, 8), api.SubgridConfig(8, 0, 8)]
     with pytest.raises(ValueError, match="share off0"):
         bwd.accumulate_wave(same_off1, numpy.zeros((1, 2, 4, 4), dtype=numpy.complex64))
+
+
+def test_trace_timeline_gap_accounting(tmp_path, capsys):
+    """tools/trace_timeline.py gaps: busy / idle / overlap accounting of a dispatch timeline split into passes at the K1
+    launches (the tool behind profiles/r5_timeline_64k_sparse.txt), on a hand-made timeline."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "trace_timeline.py")
+    spec = importlib.util.spec_from_file_location("trace_timeline", path)
+    tl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tl)
+    assert tl.short("_ZN3swf20row_pass_band_kernelINS_7RGeoPreILi14ELi5ELb1ELb1EEELb1ELi1ELb1ELi22ELi1EEEvNS_11RowPassArgsE") == "K1_row_pass_band"
+    assert tl.short("_ZN3swf15col_pass_kernelINS_4CGeoILi7ELi5ELb1ELi64ELi4EEELi0ELb1ELb0EfEEvNS_11ColPassArgsE") == "col_pass<128,c64,mode0>"
+    rows = []
+    t = 0
+    for _ in range(2):  # two passes: 2 K1 launches back to back, then 10 waves of two overlapping column passes + a gap
+        for _ in range(2):
+            rows.append((t, t + 1000_000, 1, "K1_row_pass_band"))
+            t += 1000_000
+        for _ in range(10):
+            rows.append((t, t + 100_000, 1, "col_pass<128,c64,mode0>"))
+            rows.append((t + 50_000, t + 150_000, 2, "col_pass<256,c64,mode1>"))
+            t += 150_000 + 30_000  # 30 us of idle behind every wave
+    import csv as csvmod
+
+    path_csv = tmp_path / "tl.csv"
+    with open(path_csv, "w", newline="") as fh:  # (the kernel names contain commas: quoted as `dump` writes them)
+        csvmod.writer(fh).writerows(rows)
+    tl.gaps(str(path_csv))
+    out = capsys.readouterr().out
+    assert out.count("pass ") == 2
+    first = out.splitlines()[0]
+    # 2 ms of K1 + 10 x 150 us of waves, 9 gaps of 30 us inside the pass (the 10th follows its last dispatch), 50 us of
+    # every wave with two kernels running
+    assert "wall 3.770 ms" in first and "busy 3.500 ms" in first and "idle 0.270 ms" in first
+    assert ">=2 kernels running 0.500 ms" in first
