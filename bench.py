@@ -400,6 +400,9 @@ def cpu_baseline(p, F, S, C):
         # (r5) untimed warm-up: in r4 the first repeat ran while the workers were still being spawned -- staggered, i.e.
         # under less contention -- and came out 1.7-2.2x faster than the others (247 / 145 / 111 contributions/s)
         list(pool.map(_cpu_warm, [(p, F, i) for i in range(cores)]))
+        # ... and one untimed repeat of the sample itself: with the workers merely started, the first timed repeat still came
+        # out 1.1 - 1.9x faster than the following ones (187 / 97 / 92): the host reaches its sustained clocks only under load
+        list(pool.map(_cpu_sample, [(p, F, 500 + i) for i in range(cores)]))
         for rep in range(repeats):  # every repeat keeps all cores busy at once; the pool (and each worker's core) is reused
             per_repeat.append(list(pool.map(_cpu_sample, [(p, F, 1000 + rep * cores + i) for i in range(cores)])))
     wall = time.perf_counter() - t0
@@ -436,10 +439,11 @@ def cpu_baseline(p, F, S, C):
             f"({', '.join(f'{v:.0f}' for v in values)} contributions/s); wall time of all repeats {wall:.1f} s"
         ),
         extrapolated_seconds=total,
-        # (r4 advice) what the sample was, so that values stay comparable across rounds: method 3 (r5) = method 2 + an
-        # untimed warm-up task per worker; method 2 (r4) = slabs of 2e6 / 4e6 elements and the median of three repeats;
+        # (r4 advice) what the sample was, so that values stay comparable across rounds: method 4 (r5) = method 2 + an
+        # untimed warm-up task per worker + one untimed repeat of the sample; method 2 (r4) = slabs of 2e6 / 4e6 elements and the median of three repeats;
         # method 1 (r1-r3) = 4e6 / 8e6 elements, one repeat
-        method=dict(version=3, warmup="one untimed task per worker (process start, PSWF tables) before the timed repeats", k1_slab_elements=int(p["yB_size"]) * int(ncol), k2_slab_elements=int(nrow) * int(p["yB_size"]),
+        method=dict(version=4, warmup="per worker: process start + PSWF tables + first padded-length transform, then ONE "
+                                      "untimed repeat of the whole sample under full contention, before the timed repeats", k1_slab_elements=int(p["yB_size"]) * int(ncol), k2_slab_elements=int(nrow) * int(p["yB_size"]),
                     k1_slab_columns=int(ncol), k2_slab_rows=int(nrow), repeats=repeats, statistic="median"),
     )
 

@@ -5,9 +5,30 @@
 
 namespace swf {
 
+// The single 512-point pass on 32-column tiles (ColPassArgs::tile32; r5): 512 threads and 64 KiB per workgroup instead of
+// 1024 threads and 128 KiB.  Alone on the chip the two forms are equal (r3: 43.37 vs 43.29 ms per pass); in the overlapped
+// wave loop K3 shares the CUs with the K2 workgroups of the following waves, which a whole-CU workgroup cannot: 64k pass
+// 38.07 / 37.84 / 38.14 -> 37.79 / 37.68 / 37.95 ms (interleaved same-box pairs, gpurun_out/r5r).  SWIFTLY_COL512_TILE32=0
+// switches it off (A/B runs).  (The same tiles for the two passes of K2's four-step, same session: pass A 38.2 / 37.6 ->
+// 39.1 / 39.7 ms, pass B 37.7 / 38.4 -- not kept.)
+using CGeo512Half = CGeo<9, 5, true, 32>;
+static int col512_tile32() {
+    static const int v = getenv("SWIFTLY_COL512_TILE32") ? atoi(getenv("SWIFTLY_COL512_TILE32")) : 1;
+    return v;
+}
+
 template <int LOGN, int MODE>
 static int launch_mode(const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     using G = typename CGeoFor<LOGN>::type;
+    if constexpr (LOGN == 9 && MODE == 2) {
+        if (a.tile32 && !a.gs && col512_tile32()) {
+            using GH = CGeo512Half;
+            dim3 hgrid((unsigned)((a.ncols + GH::COLS - 1) / GH::COLS), (unsigned)outer, (unsigned)nbatch);
+            hipLaunchKernelGGL((col_pass_kernel<GH, 2, true>), hgrid, dim3(GH::NT), GH::LDS_BYTES, s, a, a.in, a.out, a.ld_win,
+                               a.ld_win2, a.st_win, a.st_win2, a.st_rowmap, a.tw, a.tw_full, cz);
+            return (int)hipGetLastError();
+        }
+    }
     dim3 grid((unsigned)((a.ncols + G::COLS - 1) / G::COLS), (unsigned)outer, (unsigned)nbatch);
     if constexpr (MODE == 1 || G::HALF) {
         if (a.gs) return (int)hipErrorInvalidConfiguration;  // no gather-sum instance of this geometry: never fall through to the plain load
@@ -136,7 +157,12 @@ struct CDispatch {
 int launch_col_pass(int logn, int mode, const ColPassArgs& a, const ColZ& cz, int outer, int nbatch, hipStream_t s) {
     return CDispatch<kColPassMinLog, kColPassMaxLog>::launch(logn, mode, a, cz, outer, nbatch, s);
 }
-int init_col_pass() { return CDispatch<kColPassMinLog, kColPassMaxLog>::init(); }
+int init_col_pass() {
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&col_pass_kernel<CGeo512Half, 2, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)CGeo512Half::LDS_BYTES);
+    if (rc) return rc;
+    return CDispatch<kColPassMinLog, kColPassMaxLog>::init();
+}
 bool col_pass_f64_supported(int logn) { return logn >= kColF64MinLog && logn <= kColPassMaxLogF64; }
 
 }  // namespace swf

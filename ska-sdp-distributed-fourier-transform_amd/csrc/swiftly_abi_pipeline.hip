@@ -373,6 +373,7 @@ static int transform_contributions_impl(swiftly_hip_t* h, int dtype, const void*
     } else if (layout == 1) {  // in[f] = [kept rows of yN, m]: window gather along the strided axis
         c.ld_mod = yN;
         c.ld_rowmap = in_rowmap;
+        c.tile32 = 1;  // K3 of the band pipeline: runs next to K2 of the following waves (col_pass.hip)
     }
     for (int64_t f0 = 0; f0 < nfacets; f0 += kColZF) {
         const int nf = (int)std::min<int64_t>(kColZF, nfacets - f0);

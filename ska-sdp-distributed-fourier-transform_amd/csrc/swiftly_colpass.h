@@ -107,6 +107,10 @@ struct ColPassArgs {
     // accesses to the four-step scratch (pass A stores, pass B loads) non-temporal (1, default) or cacheable (0:
     // lets the intermediate live in the 256 MiB Infinity Cache when both passes of a slab run back to back)
     int scratch_nt;
+    // single 512-point pass on 32-column tiles (512 threads, 64 KiB of LDS: two workgroups per CU, or one next to the
+    // workgroups of another kernel) instead of 64-column tiles (1024 threads, 128 KiB: the CU to itself); set by the
+    // callers for which it was measured -- K3 of the forward wave loop, which runs next to K2 of the following waves (r5)
+    int tile32;
 };
 
 // Per-batch-item parameters (by value).  Batch item z = f * nb + b  (f: facet index, b: subgrid index of the

@@ -293,6 +293,8 @@ class TaskQueue:
 
 # tuning knob: SWIFTLY_PREFETCH=0 turns the planned-wave prefetch of SwiftlyForward off (A/B runs)
 _PREFETCH = os.environ.get("SWIFTLY_PREFETCH", "1") != "0"
+# how many planned waves K2 may run ahead of the wave being served (SwiftlyForward._prefetch_wave): 1 = the r4 schedule
+_PREFETCH_DEPTH = max(1, int(os.environ.get("SWIFTLY_PREFETCH_DEPTH", "2")))
 
 
 def _torch():
@@ -895,6 +897,9 @@ class SwiftlyForward:
                     timer.stop("K1_full_facet_transform", t0)
                 self._ingest.prefetch(j + 1)
             self.BF_Fs_persist = bands
+            if self._plan is not None and _PREFETCH and _PREFETCH_DEPTH >= 2:
+                ready = self.__dict__["_bands_ready"] = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(core.device))
         return self.BF_Fs_persist
 
     def _wave_rows(self, off1):
@@ -952,67 +957,90 @@ class SwiftlyForward:
         self.lru.set(("b", off1), (Q, rowmap))
         return Q, rowmap, n_rows, True
 
-    # -- planned-wave prefetch (r4): K2 of the NEXT planned wave on the core's side stream ------------------------
-    def _predict_next_wave(self, off1):
-        """the planned wave a caller that walks the plan asks for after ``off1`` (None: no plan / end / prefetch off).
-        Positions are those of the PLAN (order of first appearance of the wave keys in ``subgrid_configs``): a caller
-        that walks its own plan forwards or backwards is predicted whatever the numeric order of the keys; a repeated
-        key keeps the direction of the walk."""
+    # -- planned-wave prefetch (r4): K2 of the NEXT planned wave(s) on the core's side stream ------------------------
+    def _predict_next_waves(self, off1, depth):
+        """the planned waves a caller that walks the plan asks for after ``off1``, nearest first, at most ``depth`` of
+        them ([]: no plan / end / prefetch off).  Positions are those of the PLAN (order of first appearance of the wave
+        keys in ``subgrid_configs``): a caller that walks its own plan forwards or backwards is predicted whatever the
+        numeric order of the keys; a repeated key keeps the direction of the walk."""
         if self._plan is None or not _PREFETCH or self.__dict__.get("_prefetch_off"):
-            return None
+            return []
         order = self.__dict__.get("_wave_order")
         if order is None:
             order = self.__dict__["_wave_order"] = list(dict.fromkeys(int(sg.off1) for sg in self._plan))
             self.__dict__["_wave_pos"] = {k: i for i, k in enumerate(order)}
         pos = self._wave_pos.get(int(off1))
         if pos is None:
-            return None
+            return []
         last = self.__dict__.get("_last_wave_pos")
         step = self.__dict__.get("_wave_step", 1)
         if last is not None and pos != last:
             step = 1 if pos > last else -1
         self.__dict__["_last_wave_pos"] = pos
         self.__dict__["_wave_step"] = step
-        nxt = pos + step
-        return order[nxt] if 0 <= nxt < len(order) else None
+        out = []
+        for d in range(1, int(depth) + 1):
+            nxt = pos + d * step
+            if not 0 <= nxt < len(order):
+                break
+            out.append(order[nxt])
+        return out
+
+    def _predict_next_wave(self, off1):
+        """the nearest of :py:meth:`_predict_next_waves` (None: nothing to predict)"""
+        nxt = self._predict_next_waves(off1, 1)
+        return nxt[0] if nxt else None
 
     def _take_prefetched(self, off1):
-        """hand a prefetched ``Q`` of wave ``off1`` over to the LRU cache (the current stream waits for its K2).  A
-        prefetched wave nobody asked for is a misprediction: its buffer is dropped, and after two of them the
-        prefetch is switched off for this object (a wasted K2 per wave costs more than the overlap gains)."""
-        pf = self.__dict__.get("_prefetched")
-        if pf is None:
+        """hand a prefetched ``Q`` of wave ``off1`` over to the LRU cache (the current stream waits for its K2).  When a
+        wave that is neither prefetched nor cached has to be computed, the prefetched ones were mispredictions: their
+        buffers are dropped, and after two such misses the prefetch is switched off for this object (a wasted K2 per
+        wave costs more than the overlap gains)."""
+        pending = self.__dict__.get("_prefetched")
+        if not pending:
             return
-        if pf[0] != int(off1):
+        pf = pending.pop(int(off1), None)
+        if pf is None:
             if self.lru.get(("b", off1)) is None:  # a different wave has to be computed: the guess was wrong
-                self.__dict__["_prefetched"] = None
+                pending.clear()
                 missed = self.__dict__["_prefetch_missed"] = self.__dict__.get("_prefetch_missed", 0) + 1
                 if missed >= 2:
                     self.__dict__["_prefetch_off"] = True
             return
-        self.__dict__["_prefetched"] = None
         if self.lru.get(("b", off1)) is None:
             cur = _torch().cuda.current_stream(self.core.device)
-            cur.wait_event(pf[3])
+            cur.wait_event(pf[2])
             # Q was allocated under the side stream and is read by kernels of the caller's stream from now on: tell the
             # caching allocator, so that a freed Q is not handed to the next side-stream allocation while `cur` reads it
-            pf[1].record_stream(cur)
-            self.lru.set(("b", off1), (pf[1], pf[2]))
+            pf[0].record_stream(cur)
+            self.lru.set(("b", off1), (pf[0], pf[1]))
 
     def _prefetch_wave(self, off1):
         """Enqueue K2 of planned wave ``off1`` on the side stream: it runs next to the subgrid side (K3-K5) of the wave
         the caller is being served now.  The bandwidth-bound column passes and the issue-bound ``sum_finish`` share
-        the chip better than they follow each other (measured r4, 64k workload: 25.5 -> 24.2 ms for the 25 waves)."""
+        the chip better than they follow each other (measured r4, 64k workload: 25.5 -> 24.2 ms for the 25 waves).
+
+        Depth 1 (r4): the side stream starts behind everything queued on the caller's stream so far, i.e. K2 of wave
+        w + 1 begins when K2 of wave w AND the subgrid side of wave w - 1 have finished -- one cross-stream hand-over
+        (a 20-50 us idle gap, tools/trace_timeline.py) per wave.  Depth >= 2 (r5, SWIFTLY_PREFETCH_DEPTH): the side
+        stream waits for the band buffers only (an event recorded behind K1), so the K2s of consecutive waves follow
+        each other without a hand-over, up to ``depth`` waves ahead of the wave being served; ``Q`` is allocated under
+        the side stream and handed over with ``record_stream``, which is what keeps a recycled block from being
+        written while the caller's stream still reads it."""
         torch = _torch()
         core = self.core
-        pf = self.__dict__.get("_prefetched")
-        if off1 is None or (pf is not None and pf[0] == int(off1)) or self.lru.get(("b", off1)) is not None:
+        pending = self.__dict__.setdefault("_prefetched", {})
+        if off1 is None or int(off1) in pending or self.lru.get(("b", off1)) is not None:
             return
         rowmap, n_rows = self._wave_rows(off1)
         main, side = torch.cuda.current_stream(core.device), core.side_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)  # bands ready; every reader of a Q buffer that the allocator may hand out again has been enqueued
-        side.wait_event(ev)
+        ready = self.__dict__.get("_bands_ready")
+        if _PREFETCH_DEPTH >= 2 and ready is not None:
+            side.wait_event(ready)  # K1 of every facet (recorded by _prepare_all_bands)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(main)  # bands ready; every reader of a Q buffer that the allocator may hand out again has been enqueued
+            side.wait_event(ev)
         with torch.cuda.stream(side):
             Q = torch.empty((len(self.facet_configs), n_rows, core.xM_yN_size), dtype=self.dtype, device=core.device)
             core.prepare_facet_columns(
@@ -1020,7 +1048,14 @@ class SwiftlyForward:
             )
             done = torch.cuda.Event()
             done.record(side)
-        self.__dict__["_prefetched"] = (int(off1), Q, rowmap, done)
+        pending[int(off1)] = (Q, rowmap, done)
+
+    def _prefetch_waves(self, waves):
+        """:py:meth:`_prefetch_wave` for the predicted waves, nearest first, at most SWIFTLY_PREFETCH_DEPTH in flight"""
+        for off1 in waves:
+            if len(self.__dict__.get("_prefetched") or ()) >= _PREFETCH_DEPTH:
+                break
+            self._prefetch_wave(off1)
 
     def _wave_b(self, sgs):
         """One wave = two native calls: facet side (K2 + K3 + K4a) and subgrid side (K4b + K5).  (r3's grouped subgrid
@@ -1032,9 +1067,9 @@ class SwiftlyForward:
         self._check_planned(sgs)
         bands = self.prepare_all_facets()
         Q, rowmap, n_rows, compute = self._wave_Q(sgs[0].off1)
-        nxt = self._predict_next_wave(sgs[0].off1)
+        nxt = self._predict_next_waves(sgs[0].off1, _PREFETCH_DEPTH)
         if not compute:
-            self._prefetch_wave(nxt)
+            self._prefetch_waves(nxt)
         m = core.xM_yN_size
         G = torch.empty((len(self.facet_configs), len(sgs), m, m), dtype=self.dtype, device=core.device)
         try:
@@ -1045,7 +1080,7 @@ class SwiftlyForward:
                 self.lru._items.pop(("b", sgs[0].off1), None)  # pylint: disable=protected-access
             raise
         if compute:  # (this wave's own K2 was enqueued on the current stream just now: the next one goes behind it)
-            self._prefetch_wave(nxt)
+            self._prefetch_waves(nxt)
         return _finish_from_G(core, G, self.facet_configs, sgs)
 
 

@@ -278,16 +278,30 @@ def test_mispredicted_prefetch_is_dropped_and_switches_the_prefetch_off():
     fwd._plan = [api.SubgridConfig(0, k, 8) for k in (10, 20, 30, 40)]
     fwd._planned_keys = {10, 20, 30, 40}
     fwd.lru = api.LRUCache(1)
-    fwd.__dict__["_prefetched"] = (20, "Q20", None, None)
+    fwd.__dict__["_prefetched"] = {20: ("Q20", None, None)}
     fwd._take_prefetched(40)                       # asked for 40, 20 was prefetched
-    assert fwd.__dict__["_prefetched"] is None and fwd.__dict__["_prefetch_missed"] == 1
+    assert not fwd.__dict__["_prefetched"] and fwd.__dict__["_prefetch_missed"] == 1
     assert fwd._predict_next_wave(10) == 20        # one miss: still predicting
-    fwd.__dict__["_prefetched"] = (20, "Q20", None, None)
+    fwd.__dict__["_prefetched"] = {20: ("Q20", None, None), 30: ("Q30", None, None)}
     fwd.lru.set(("b", 30), ("Q30", None))
-    fwd._take_prefetched(30)                       # 30 is cached: not a miss, the prefetched wave stays
-    assert fwd.__dict__["_prefetched"][0] == 20 and fwd.__dict__["_prefetch_missed"] == 1
+    fwd._take_prefetched(30)                       # 30 is cached: not a miss, the other prefetched wave stays
+    assert list(fwd.__dict__["_prefetched"]) == [20] and fwd.__dict__["_prefetch_missed"] == 1
     fwd._take_prefetched(40)
     assert fwd.__dict__.get("_prefetch_off") and fwd._predict_next_wave(10) is None
+
+
+def test_planned_wave_prediction_depth():
+    """SwiftlyForward._predict_next_waves: up to `depth` waves ahead in the walk direction, nearest first, cut at the
+    ends of the plan (the r5 free-running K2 chain, SWIFTLY_PREFETCH_DEPTH)."""
+    fwd = object.__new__(api.SwiftlyForward)
+    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (10, 20, 30, 40, 50)]
+    fwd._planned_keys = {10, 20, 30, 40, 50}
+    assert fwd._predict_next_waves(10, 2) == [20, 30]
+    assert fwd._predict_next_waves(30, 3) == [40, 50]
+    assert fwd._predict_next_waves(50, 2) == []
+    assert fwd._predict_next_waves(40, 2) == [30, 20]   # turned round
+    assert fwd._predict_next_waves(20, 2) == [10]
+    assert fwd._predict_next_waves(15, 2) == []          # not a planned wave
 
 
 def test_backward_wave_entry_points_check_the_wave_key():
