@@ -96,14 +96,71 @@ static int data_segment_run(const RowPassArgs& a, int n, int seglen, int* first)
     return run == count ? run : nseg;  // two runs cannot happen for one cyclic range; be safe
 }
 
-template <class G, bool PAIR, bool WIN, int ST, int NSEG, int CJ = -1>
+template <class G, bool PAIR, bool WIN, int ST, int NSEG, int CJ = -1, bool W4 = false>
 static void launch_band_inst(const RowPassArgs& a, unsigned blocks, const cx<float>* tw14, const cx<float>* tw_full,
                              hipStream_t s) {
-    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, NSEG, CJ>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a,
+    hipLaunchKernelGGL((row_pass_band_kernel<G, WIN, ST, PAIR, NSEG, CJ, W4>), dim3(blocks), dim3(G::NT), G::LDS_BYTES, s, a,
                        a.in, a.out, a.ld_win, tw14, tw_full);
 }
+
+// -- re-laid-out load windows (Win4Cache, swiftly_rowpass.h) ------------------------------------------------------
+// entry (p * T + t), T = seglen / 2 lanes: the window pairs of the p-th segment pair of the K1 load loop -- segments
+// (p, p + 16) for p < ns - 16, then (s, s + 1) -- at the lane's elements q = (2 t + u + c + seglen * segment) mod n
+__global__ void build_win4_kernel(const float* __restrict__ win, float* __restrict__ tab, int c, int len, int ns, int n,
+                                  int seglen) {
+    const int T = seglen >> 1, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (ns >> 1) * T) return;
+    const int p = idx / T, t = idx - p * T, nb1 = ns - 16;
+    const int s0 = p < nb1 ? p : nb1 + 2 * (p - nb1), s1 = p < nb1 ? p + 16 : s0 + 1;
+    const int q0 = (2 * t + c + seglen * s0) & (n - 1), q1 = (2 * t + c + seglen * s1) & (n - 1);
+    f32x4 v;
+    v.x = q0 < len ? win[q0] : 0.f;
+    v.y = q0 + 1 < len ? win[q0 + 1] : 0.f;
+    v.z = q1 < len ? win[q1] : 0.f;
+    v.w = q1 + 1 < len ? win[q1 + 1] : 0.f;
+    reinterpret_cast<f32x4*>(tab)[idx] = v;
+}
+static int win4_enabled() {  // SWIFTLY_K1_WIN4=0: the plain window loads (A/B runs)
+    static const int v = getenv("SWIFTLY_K1_WIN4") ? atoi(getenv("SWIFTLY_K1_WIN4")) : 1;
+    return v;
+}
+const float* Win4Cache::get(const float* win, int c, int len, int ns, int n, int seglen, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& e : items)
+        if (e.win == win && e.c == c && e.len == len && e.ns == ns) {
+            if (e.built_on != s && hipStreamWaitEvent(s, e.ready, 0) != hipSuccess) return nullptr;
+            return e.tab;
+        }
+    if (items.size() >= kMaxEntries) return nullptr;
+    Entry e{win, c, len, ns, nullptr, nullptr, s};
+    const int count = (ns >> 1) * (seglen >> 1);
+    if (hipMalloc(&e.tab, (size_t)count * 16) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(e.tab);
+        return nullptr;
+    }
+    hipLaunchKernelGGL(build_win4_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, win, e.tab, c, len, ns, n, seglen);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(e.ready, s) != hipSuccess) {
+        (void)hipStreamSynchronize(s);
+        (void)hipEventDestroy(e.ready);
+        (void)hipFree(e.tab);
+        return nullptr;
+    }
+    items.push_back(e);
+    return e.tab;
+}
+void Win4Cache::clear() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry& e : items) {
+        (void)hipEventDestroy(e.ready);
+        (void)hipFree(e.tab);
+    }
+    items.clear();
+}
+
 template <class G, bool PAIR = false>
-static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
+static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s,
+                           Win4Cache* w4cache = nullptr) {
     RowPassArgs a = a0;
     a.seg_rot = 0;
     const unsigned blocks = (unsigned)(((a.nrows + 7) / 8) * 16);
@@ -128,10 +185,17 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
             if (a.band_len > 0 && a.ld_win && inv) {
                 // forward K1: geometry with the twiddle preload (RGeoPre)
                 using GP = RGeoPre<G::LOGN, G::LOGP, G::SPLIT>;
+                // ... and, when the caller owns a table cache, the window through 16-byte loads (W4)
 #define SWF_TRY_SEG_PRE(NS)                                                                    \
     if (run <= NS) {                                                                           \
         a.seg_rot = first;                                                                     \
-        launch_band_inst<GP, PAIR, true, 1, NS, 1>(a, blocks, tw14, tw_full, s);               \
+        constexpr int n_ = 2 * G::N;                                                           \
+        const int c_ = (int)(((long long)a.ld_a + n_ / 2 + (long long)first * SEGLEN) % n_);   \
+        a.ld_win4 = (w4cache && win4_enabled()) ? w4cache->get(a.ld_win, c_, a.ld_len, NS, n_, SEGLEN, s) : nullptr; \
+        if (a.ld_win4)                                                                         \
+            launch_band_inst<GP, PAIR, true, 1, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
+        else                                                                                   \
+            launch_band_inst<GP, PAIR, true, 1, NS, 1>(a, blocks, tw14, tw_full, s);           \
         return (int)hipGetLastError();                                                         \
     }
                 SWF_TRY_SEG_PRE(16)
@@ -164,11 +228,12 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
 }
 using BandGeo64k = RGeo<15, 5, true>;  // yN = 65536: 2 x 32768 points, 1024 threads x 32, 132 KB LDS, one workgroup per CU
 using BandGeo16k = RGeo<13, 4, true>;  // yN = 16384: 2 x  8192 points,  512 threads x 16, 33 KB LDS
-int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
-    return launch_row_pass_band_n(15, a, tw14, tw_full, s);
+int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s, Win4Cache* w4) {
+    return launch_row_pass_band_n(15, a, tw14, tw_full, s, w4);
 }
 // logn = log2 of the full row length (14, 15 or 16); tw_half = table of length 2^(logn-1), tw_full of length 2^logn
-int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s) {
+int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s,
+                           Win4Cache* w4) {
     if (a.nrows <= 0) return 0;
     if (logn == 16) return launch_band_geo<BandGeo64k>(a, tw_half, tw_full, s);
     if (logn == 14) return launch_band_geo<BandGeo16k>(a, tw_half, tw_full, s);
@@ -179,7 +244,7 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
     if (a.band_len == 0) return launch_band_geo<BandGeo4>(a, tw14, tw_full, s);
     // adjacent-point (16-byte) loads need even shifts / lengths / pitches
     const bool pair_ok = !(a.ld_a & 1) && !(a.ld_len & 1) && !(a.in_pitch & 1) && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
-    if (pair_ok) return launch_band_geo<BandGeo5, true>(a, tw14, tw_full, s);
+    if (pair_ok) return launch_band_geo<BandGeo5, true>(a, tw14, tw_full, s, w4);
     return launch_band_geo<BandGeo5>(a, tw14, tw_full, s);
 }
 int row_pass_band_occupancy() {
@@ -193,9 +258,9 @@ static int init_band() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
-template <class G, bool WIN, int ST, int NSEG = 0, bool PAIR = true, int CJ = -1>
+template <class G, bool WIN, int ST, int NSEG = 0, bool PAIR = true, int CJ = -1, bool W4 = false>
 static int init_band_pair() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, PAIR, NSEG, CJ>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_band_kernel<G, WIN, ST, PAIR, NSEG, CJ, W4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
 }
 template <class G>
@@ -234,6 +299,9 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 16, true, 1>();
         if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 22, true, 1>();
         if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 24, true, 1>();
+        if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 16, true, 1, true>();
+        if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 22, true, 1, true>();
+        if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 24, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false, 1>();

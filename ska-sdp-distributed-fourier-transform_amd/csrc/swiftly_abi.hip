@@ -288,6 +288,7 @@ void swiftly_hip_destroy(swiftly_hip_t* h) {
             (void)hipStreamDestroy(st);
         }
     for (void* p : h->allocs) (void)hipFree(p);
+    h->win4.clear();
     delete h;
 }
 
@@ -1498,7 +1499,7 @@ int swiftly_hip_prepare_facet_band_rows(swiftly_hip_t* h, int dtype, const void*
     const cx<float>* twh = twiddles<float>(h, h->log_yN - 1);
     const cx<float>* twf = twiddles<float>(h, h->log_yN);
     if (!twh || !twf) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    int e = launch_row_pass_band_n(h->log_yN, r, twh, twf, (hipStream_t)stream);
+    int e = launch_row_pass_band_n(h->log_yN, r, twh, twf, (hipStream_t)stream, &h->win4);
     if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return 0;
 }

@@ -92,6 +92,8 @@ struct swiftly_hip {
     // join events are per call: two host threads may drive one handle on different streams)
     hipStream_t chunk_st[2] = {nullptr, nullptr};
     std::mutex chunk_mu;
+    // re-laid-out load windows of the forward K1 (swiftly_rowpass.h), built on first use per facet offset
+    Win4Cache win4;
 };
 
 template <typename R>

@@ -9,6 +9,9 @@
 // are batched the same way.  Register budget: P complex points + P window
 // values, no spills at 128 VGPRs.
 #pragma once
+#include <mutex>
+#include <vector>
+
 #include "swiftly_fft.h"
 
 namespace swf {
@@ -51,6 +54,11 @@ struct RowPassArgs {
     // cyclically rotated by seg_rot segments so that every segment that can hold data is one of the first NSEG ones;
     // the outputs get the compensating phase W_nseg^(seg_rot k)
     int seg_rot;
+    // W4 instances (r5, forward K1): the load window of the lane's segments re-laid out so that ONE 16-byte load fetches
+    // the window pairs of TWO segments (Win4Cache below builds it per (window, facet offset, segment count)): table entry
+    // (p * T + t) holds {w[s0][2t], w[s0][2t+1], w[s1][2t], w[s1][2t+1]} for the p-th segment pair (s0, s1) of the load
+    // loop, zeros where the padded row has no data
+    const float* ld_win4;
 };
 
 // physical column of logical (centred) column ck in a parity-split band buffer, or -1
@@ -334,7 +342,11 @@ __global__ __launch_bounds__(G::NT) void row_pass_split_kernel(const RowPassArgs
 // but at most two r the whole wave is inside or outside the band: that decision is made on the SCALAR unit, outputs the
 // wave does not keep (65 % on the 64k workload) cost two scalar instructions instead of the rotation phase product,
 // the scale and five address / compare operations, and kept outputs are stored at  SGPR base + lane * 8.
-template <class G, bool HAS_WIN, int ST, bool PAIR = false, int NSEG = 0, int CJ = -1>
+// W4 (r5): the window of the pair loads comes from the re-laid-out table RowPassArgs::ld_win4 -- NS / 2 loads of 16 bytes
+// per lane instead of NS of 8 bytes, the same bytes and bit-identical products; a shape probe of the kernel measured
+// 1.64 against 1.73 ms per facet (tools/k1_shape_probe.hip V=64: the load phase is bound by the NUMBER of vector-memory
+// instructions).
+template <class G, bool HAS_WIN, int ST, bool PAIR = false, int NSEG = 0, int CJ = -1, bool W4 = false>
 __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                  cx<float>* __restrict__ gout,
                                                                  const float* __restrict__ ld_win,
@@ -402,16 +414,39 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, (int)(valid << 3), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(winb), (short)0, (int)(valid << 2), 0x00020000);
         const unsigned base8 = (unsigned)((2 * t + A.ld_a + (N >> 1) + rot) & (N - 1)) << 3;
+        // W4: segment pairs of the re-laid-out window table, in the order of this loop -- (r, r + 16) while segment r + 16
+        // can hold data (r < NB1: both windows of an iteration in one load), then (r, r + 1) for the rest
+        static_assert(!W4 || (HAS_WIN && SEGSKIP && NS >= R1 && NS % 2 == 0), "re-laid-out window: forward K1 instances");
+        constexpr int NB1 = NS - R1;
+        const __amdgpu_buffer_rsrc_t rs_w4 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W4 ? A.ld_win4 : nullptr), (short)0, W4 ? (NS / 2) * T * 16 : 0, 0x00020000);
+        f32x4 wcarry = {0.f, 0.f, 0.f, 0.f};
         static_for<0, R1>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
             cx<float> a[2][2];  // [q][u]
+            f32x2 w4[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            if constexpr (W4) {
+                if constexpr (r < NB1) {
+                    const f32x4 wv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w4, (r * T + t) << 4, 0, 0));
+                    w4[0] = f32x2{wv.x, wv.y};
+                    w4[1] = f32x2{wv.z, wv.w};
+                } else if constexpr (((r - NB1) & 1) == 0) {
+                    wcarry = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w4, ((NB1 + (r - NB1) / 2) * T + t) << 4, 0, 0));
+                    w4[0] = f32x2{wcarry.x, wcarry.y};
+                } else {
+                    w4[0] = f32x2{wcarry.z, wcarry.w};
+                }
+            }
             static_for<0, 2>([&](auto qI) {
                 constexpr int q = decltype(qI)::value;
                 if constexpr (r + R1 * q < NS) {  // segment r + 16 q can hold data
                     const unsigned off8 = (base8 + (unsigned)((r * SEG + q * H) << 3)) & (unsigned)((N << 3) - 1);
                     const f32x4 val = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off8, 0, 0));
                     if constexpr (HAS_WIN) {
-                        const f32x2 w = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(off8 >> 1), 0, 0));
+                        f32x2 w;
+                        if constexpr (W4)
+                            w = w4[q];
+                        else
+                            w = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(off8 >> 1), 0, 0));
                         if constexpr (CJ >= 0) {  // one packed product per point; CJ = 1: (x w, -y w)
                             const f32x2 p0 = {val.x, val.y}, p1 = {val.z, val.w};
                             f32x2 r0, r1;
@@ -628,8 +663,27 @@ int row_pass_half_occupancy(int lds_bytes);
 int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw13, const cx<float>* tw_full,
                           hipStream_t s);
 // 2 x 16384-point form with 512-thread workgroups (two per CU); a.band_len > 0 selects the band store
-int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s);
-int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s);
+// Re-laid-out load windows of the W4 instances (RowPassArgs::ld_win4), built on first use per (window, position of the
+// facet in the rotated padded row, facet size, segment count) and kept for the life of the owner (a handle: the tables
+// are constants of the configuration like the twiddle tables; 4 KB per segment).  A table is built on the stream of the
+// launch that first needs it; launches on other streams wait for its event.
+struct Win4Cache {
+    struct Entry {
+        const float* win;
+        int c, len, ns;
+        float* tab;
+        hipEvent_t ready;
+        hipStream_t built_on;
+    };
+    std::mutex mu;
+    std::vector<Entry> items;
+    static constexpr size_t kMaxEntries = 64;  // beyond: the plain instances (nothing is ever evicted: a kernel may be reading)
+    const float* get(const float* win, int c, int len, int ns, int n, int seglen, hipStream_t s);
+    void clear();  // frees the tables (owner's teardown, device idle)
+};
+int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s, Win4Cache* w4 = nullptr);
+int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s,
+                           Win4Cache* w4 = nullptr);
 int row_pass_band_occupancy();
 
 }  // namespace swf

@@ -172,6 +172,154 @@ __global__ __launch_bounds__(Shape<S>::G::NT, 4) void probe(const cx<float>* __r
     }
 }
 
+
+// Third use (r5): ONE 1024-thread workgroup per row -- waves 0-7 transform the even outputs, waves 8-15 the odd ones, and the
+// two halves SHARE the load phase: every lane loads (and windows) half of the lane pair's 16 first-stage slots, forms
+// a + b and a - b for them, keeps the one of its own half and hands the other to its partner lane through the idle
+// exchange buffer of the partner's half (8 x 16 bytes out, 8 x 16 bytes in, two workgroup barriers).  Per row: 22 x 16-byte
+// data loads + 22 x 8-byte window loads per lane PAIR instead of per lane, the same HBM bytes; the price: one workgroup per
+// CU with all 16 waves in the same phase, barriers among 16 waves, 128 KB through the LDS.  W = 1: window through 16-byte
+// loads of a re-laid-out table on top.
+constexpr int pair_owner(int r) {
+    constexpr int NB1 = NSEG - 16;
+    return r < NB1 ? (r < NB1 / 2 ? 0 : 1) : ((r - NB1) < (16 - NB1) / 2 ? 0 : 1);
+}
+constexpr int pair_slot_index(int r) {  // position of slot r among the slots of its owner
+    int k = 0;
+    for (int i = 0; i < r; i++) k += pair_owner(i) == pair_owner(r);
+    return k;
+}
+template <int W>
+__global__ __launch_bounds__(1024) void probe_pair(const cx<float>* __restrict__ facet, const float* __restrict__ win,
+                                                    cx<float>* __restrict__ out, const cx<float>* __restrict__ tw_part,
+                                                    const cx<float>* __restrict__ tw_full, int nrows, float scale) {
+    using G = Shape<2>::G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int P = G::P, T = G::T, R1 = 16, SEG = 1024, NB1 = NSEG - R1;  // NB1 slots have an a and a b segment
+    const int h = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 9), t = threadIdx.x & 511;
+    const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    if (row >= nrows) return;
+    const char* inb = reinterpret_cast<const char*>(facet + (long long)row * YB);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), (short)0, YB << 3, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(win), (short)0, YB << 2, 0x00020000);
+    unsigned char* mine = smem + h * G::LDS_BYTES;          // exchange buffer of this half
+    unsigned char* theirs = smem + (1 - h) * G::LDS_BYTES;  // ... of the partner half
+    // slot r of the first stage (points 2t, 2t+1 of segments r and r + 16) belongs to half OWNER(r): 3 + 5 slots each
+    cx<float> x[P];
+    constexpr auto owner = [](int r) constexpr { return pair_owner(r); };
+    constexpr auto slot_index = [](int r) constexpr { return pair_slot_index(r); };
+    // both halves run the same code on their own slots: hand-unrolled per half so that the slot numbers stay compile-time
+    auto load_phase = [&](auto HI) {
+        constexpr int HH = decltype(HI)::value;
+        f32x4 wcarry = {0.f, 0.f, 0.f, 0.f};
+        int wcount = 0;
+        (void)wcount;
+        static_for<0, R1>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            if constexpr (owner(r) == HH) {
+                constexpr int k = slot_index(r);
+                cx<float> a[2][2];
+                static_for<0, 2>([&](auto qI) {
+                    constexpr int q = decltype(qI)::value;
+                    constexpr int seg = r + R1 * q;
+                    if constexpr (seg < NSEG) {
+                        const unsigned e0 = (unsigned)(2 * t + SEG * seg);
+                        f32x2 wv;
+                        if constexpr (W) {
+                            if constexpr (r < NB1) {  // one 16-byte load: the windows of segments r and r + 16
+                                if constexpr (q == 0) {
+                                    wcarry = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((r * 512 + t) << 4), 0, 0));
+                                    wv = f32x2{wcarry.x, wcarry.y};
+                                } else {
+                                    wv = f32x2{wcarry.z, wcarry.w};
+                                }
+                            } else if constexpr ((k & 1) == 1) {  // a-only slots: one load per two slots of the lane
+                                wcarry = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((r * 512 + t) << 4), 0, 0));
+                                wv = f32x2{wcarry.x, wcarry.y};
+                            } else {
+                                wv = f32x2{wcarry.z, wcarry.w};
+                            }
+                        } else {
+                            wv = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (int)(e0 << 2), 0, 0));
+                        }
+                        const f32x4 val = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(e0 << 3), 0, 0));
+                        a[q][0] = pkc(f32x2{val.x, val.y} * f32x2{wv.x, wv.x});
+                        a[q][1] = pkc(f32x2{val.z, val.w} * f32x2{wv.y, wv.y});
+                    }
+                });
+                cx<float> keep[2], give[2];
+                static_for<0, 2>([&](auto uI) {
+                    constexpr int u = decltype(uI)::value;
+                    if constexpr (r < NB1) {
+                        const cx<float> sum = a[0][u] + a[1][u], dif = a[0][u] - a[1][u];
+                        keep[u] = HH ? dif : sum;
+                        give[u] = HH ? sum : dif;
+                    } else {
+                        keep[u] = a[0][u];
+                        give[u] = a[0][u];
+                    }
+                    x[u + 2 * r] = keep[u];
+                });
+                *reinterpret_cast<f32x4*>(theirs + ((k * 512 + t) << 4)) = f32x4{give[0].x, give[0].y, give[1].x, give[1].y};
+            }
+        });
+    };
+    auto take_phase = [&](auto HI) {  // the slots the partner loaded
+        constexpr int HH = decltype(HI)::value;
+        static_for<0, R1>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            if constexpr (owner(r) != HH) {
+                constexpr int k = slot_index(r);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(mine + ((k * 512 + t) << 4));
+                x[2 * r] = cx<float>{v.x, v.y};
+                x[2 * r + 1] = cx<float>{v.z, v.w};
+            }
+        });
+    };
+    if (h == 0) load_phase(std::integral_constant<int, 0>{}); else load_phase(std::integral_constant<int, 1>{});
+    __syncthreads();
+    if (h == 0) take_phase(std::integral_constant<int, 0>{}); else take_phase(std::integral_constant<int, 1>{});
+    __syncthreads();
+    if (h) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tw_full + ((2 * t) & (NFULL - 1)));
+        const cx<float> w0 = {v.x, v.y}, w1 = {v.z, v.w};
+        static_for<0, R1>([&](auto rI) {
+            constexpr int r = decltype(rI)::value;
+            x[2 * r] = mul_w64<float, 2 * r>(cmul(x[2 * r], w0));
+            x[2 * r + 1] = mul_w64<float, 2 * r>(cmul(x[2 * r + 1], w1));
+        });
+    }
+    const cx<float> rphi = tw_full[(unsigned)(1024 * (2 * t + h)) & (unsigned)(NFULL - 1)];
+    cx<float>* orow = out + (long long)row * OUT_PITCH + h * (OUT_PITCH / 2);
+    const f32x2 sc = {scale, scale};
+    fft_phases_pair<G, float>(x, t, mine, tw_part, [&](int, cx<float> v, auto sI) {
+        constexpr int s = decltype(sI)::value;
+        if constexpr (s < KEEP) {
+            v = cmul(v, rphi);
+            *reinterpret_cast<f32x2*>(orow + s * T + t) = pkv(v) * sc;
+        }
+    });
+}
+
+template <int W>
+static float run_pair(const cx<float>* facet, const float* win, cx<float>* out, const cx<float>* tw_part, const cx<float>* tw_full,
+                      int launches) {
+    using G = Shape<2>::G;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_pair<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * G::LDS_BYTES)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < launches; i++)
+        hipLaunchKernelGGL((probe_pair<W>), dim3(YB), dim3(1024), 2 * G::LDS_BYTES, 0, facet, win, out, tw_part, tw_full, YB, 0.5f);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / launches;
+}
+
 __global__ void fill(float* p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         p[i] = (float)((i * 2654435761u >> 8) & 0xffff) * (1.f / 65536.f) - 0.5f;
@@ -234,6 +382,14 @@ int main() {
         const float b = run<4>(facet, win, out, tw13, twf, 9);
         printf("rep %d: two half-row workgroups %.4f ms per facet    four quarter-row workgroups %.4f ms per facet\n", rep, a, b);
     }
+    for (int rep = 0; rep < 3; rep++) {
+        run_pair<0>(facet, win, out, tw14, twf, 2);
+        const float a = run<2>(facet, win, out, tw14, twf, 9), b = run_pair<0>(facet, win, out, tw14, twf, 9);
+        run_pair<1>(facet, win, out, tw14, twf, 2);
+        const float c = run<2, 64>(facet, win, out, tw14, twf, 9), d = run_pair<1>(facet, win, out, tw14, twf, 9);
+        printf("rep %d: two 512-thread workgroups %.4f   one 1024-thread workgroup, shared loads %.4f   |  16-byte window loads: %.4f  %.4f ms per facet\n", rep, a, b, c, d);
+    }
+    if (getenv("PROBE_PAIR_ONLY")) return 0;
 #define ABL(V, what)                                                                                   \
     {                                                                                                  \
         run<2, V>(facet, win, out, tw14, twf, 2);                                                      \
