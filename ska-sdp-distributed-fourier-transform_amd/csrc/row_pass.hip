@@ -120,8 +120,44 @@ __global__ void build_win4_kernel(const float* __restrict__ win, float* __restri
     v.w = q1 + 1 < len ? win[q1 + 1] : 0.f;
     reinterpret_cast<f32x4*>(tab)[idx] = v;
 }
-static int win4_enabled() {  // SWIFTLY_K1_WIN4=0: the plain window loads (A/B runs)
-    static const int v = getenv("SWIFTLY_K1_WIN4") ? atoi(getenv("SWIFTLY_K1_WIN4")) : 1;
+// compact twiddle sections of geometry (LOGN, LOGP) in the pair schedule (swiftly_fft.h, preload_compact): copies of table entries
+__global__ void build_compact_tw_kernel(const cx<float>* __restrict__ tw, cx<float>* __restrict__ out, int logn, int logp) {
+    const int total = compact_tw_entries(logn, logp), idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int ns = logn % logp;
+    while (compact_tw_offset(logn, logp, ns + logp) <= idx) ns += logp;
+    const int rel = idx - compact_tw_offset(logn, logp, ns), i = rel / logp, b = rel % logp;
+    const int kidx = i << (logn - ns - logp);
+    out[idx] = tw[(kidx << b) & ((1 << logn) - 1)];
+}
+const cx<float>* Win4Cache::compact_tw(const cx<float>* tw_half, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (twc) {
+        if (twc_built_on != s && hipStreamWaitEvent(s, twc_ready, 0) != hipSuccess) return nullptr;
+        return twc;
+    }
+    constexpr int logn = 14, logp = 5, count = compact_tw_entries(logn, logp);
+    cx<float>* buf = nullptr;
+    hipEvent_t ev = nullptr;
+    if (hipMalloc(&buf, (size_t)count * sizeof(cx<float>)) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(buf);
+        return nullptr;
+    }
+    hipLaunchKernelGGL(build_compact_tw_kernel, dim3((count + 255) / 256), dim3(256), 0, s, tw_half, buf, logn, logp);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
+        (void)hipStreamSynchronize(s);
+        (void)hipEventDestroy(ev);
+        (void)hipFree(buf);
+        return nullptr;
+    }
+    twc = buf;
+    twc_ready = ev;
+    twc_built_on = s;
+    return twc;
+}
+static int win4_enabled() {  // SWIFTLY_K1_WIN4: 0 = the plain window loads, 1 = re-laid-out window, 2 = + compact twiddle sections (A/B runs)
+    static const int v = getenv("SWIFTLY_K1_WIN4") ? atoi(getenv("SWIFTLY_K1_WIN4")) : 2;
     return v;
 }
 const float* Win4Cache::get(const float* win, int c, int len, int ns, int n, int seglen, hipStream_t s) {
@@ -156,6 +192,11 @@ void Win4Cache::clear() {
         (void)hipFree(e.tab);
     }
     items.clear();
+    if (twc) {
+        (void)hipEventDestroy(twc_ready);
+        (void)hipFree(twc);
+        twc = nullptr;
+    }
 }
 
 template <class G, bool PAIR = false>
@@ -185,6 +226,7 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
             if (a.band_len > 0 && a.ld_win && inv) {
                 // forward K1: geometry with the twiddle preload (RGeoPre)
                 using GP = RGeoPre<G::LOGN, G::LOGP, G::SPLIT>;
+                using GC = RGeoPreC<G::LOGN, G::LOGP, G::SPLIT>;
                 // ... and, when the caller owns a table cache, the window through 16-byte loads (W4)
 #define SWF_TRY_SEG_PRE(NS)                                                                    \
     if (run <= NS) {                                                                           \
@@ -192,7 +234,10 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
         constexpr int n_ = 2 * G::N;                                                           \
         const int c_ = (int)(((long long)a.ld_a + n_ / 2 + (long long)first * SEGLEN) % n_);   \
         a.ld_win4 = (w4cache && win4_enabled()) ? w4cache->get(a.ld_win, c_, a.ld_len, NS, n_, SEGLEN, s) : nullptr; \
-        if (a.ld_win4)                                                                         \
+        a.twc = (a.ld_win4 && win4_enabled() >= 2) ? w4cache->compact_tw(tw14, s) : nullptr; \
+        if (a.twc)                                                                             \
+            launch_band_inst<GC, PAIR, true, 1, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
+        else if (a.ld_win4)                                                                    \
             launch_band_inst<GP, PAIR, true, 1, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
         else                                                                                   \
             launch_band_inst<GP, PAIR, true, 1, NS, 1>(a, blocks, tw14, tw_full, s);           \
@@ -302,6 +347,10 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 16, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 22, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5Pre, true, 1, 24, true, 1, true>();
+        using BandGeo5PreC = RGeoPreC<14, 5, true>;
+        if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 1, 16, true, 1, true>();
+        if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 1, 22, true, 1, true>();
+        if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 1, 24, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false, 1>();

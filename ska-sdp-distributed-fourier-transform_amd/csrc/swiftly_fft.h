@@ -352,6 +352,35 @@ struct preload_tw_of<G, std::enable_if_t<G::PRELOAD_TW>> {
     static constexpr bool value = true;
 };
 
+// Geometries with `static constexpr bool COMPACT_TW = true` (r5: RGeoPreC = the forward K1 with the re-laid-out window):
+// the table values of a radix-2^LOGP phase come from a COMPACT copy of the table -- per phase boundary NLOGNS a section of
+// 2^NLOGNS entries of LOGP values {tw[kidx << b], b < LOGP}, the lane's values in consecutive bytes -- so that the LOGP
+// 8-byte loads of a wave touch 20 cache lines together instead of being gathers with strides of 8 .. 128 bytes between
+// lanes (124 lines per wave in the last phase of K1).  The copy is made from the table itself (bit-identical values).
+// Measured (r5, same box, K1 per facet): 1.61 - 1.63 ms with the table gathers, 1.53 - 1.55 ms with two 16-byte and one
+// 8-byte load per section, 1.51 - 1.52 ms with five 8-byte loads (kept): what the vector-memory path charges for is the
+// number of lines a wave instruction touches, not the number of instructions.
+template <class G, class = void>
+struct compact_tw_of {
+    static constexpr bool value = false;
+};
+template <class G>
+struct compact_tw_of<G, std::enable_if_t<G::COMPACT_TW>> {
+    static constexpr bool value = true;
+};
+// section offsets (entries) for the phase boundaries of the pair schedule: LOGR1 = LOGN % LOGP, then + LOGP each
+constexpr int compact_tw_offset(int logn, int logp, int nlogns) {
+    int off = 0;
+    for (int ns = logn % logp; ns < nlogns; ns += logp) off += logp << ns;
+    return off;
+}
+constexpr int compact_tw_entries(int logn, int logp) { return compact_tw_offset(logn, logp, logn); }
+template <class G, typename R, int NLOGNS>
+__device__ __forceinline__ void preload_compact(cx<R> (&nxt)[G::LOGP], int t, const cx<R>* __restrict__ twc) {
+    const cx<R>* p = twc + compact_tw_offset(G::LOGN, G::LOGP, NLOGNS) + (t & ((1 << NLOGNS) - 1)) * G::LOGP;
+    static_for<0, G::LOGP>([&](auto bI) { nxt[decltype(bI)::value] = p[decltype(bI)::value]; });
+}
+
 // One Stockham phase, scatter part: f(e, value) for every output element of
 // this thread, e = natural-order index within the phase's output array.
 template <class G, typename R, int LOGNS, int LOGR, class F>
@@ -463,7 +492,8 @@ __device__ __forceinline__ void phase_exchange_impl(cx<R> (&x)[G::P], int t, int
 // order); the last phase hands (natural-order output index, value) to `fin`.
 template <class G, typename R, int LOGNS, class F>
 __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool rowfast, void* lds,
-                                           const cx<R>* __restrict__ tw, F&& fin, const cx<R>* pre = nullptr) {
+                                           const cx<R>* __restrict__ tw, F&& fin, const cx<R>* pre = nullptr,
+                                           const cx<R>* __restrict__ twc = nullptr) {
     constexpr int REM = G::LOGN - LOGNS;
     constexpr int LOGR = REM < G::LOGP ? REM : G::LOGP;
     phase_compute<G, R, LOGNS, LOGR>(x, t, tw, pre);
@@ -473,16 +503,20 @@ __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool
         constexpr int NLOGNS = LOGNS + LOGR, NREM = G::LOGN - NLOGNS, NLOGR = NREM < G::LOGP ? NREM : G::LOGP;
         if constexpr (preload_tw_of<G>::value && G::P == (1 << NLOGR) && NLOGR >= 5) {
             cx<R> nxt[NLOGR];
-            const int kidx = (t & ((1 << NLOGNS) - 1)) << (G::LOGN - NLOGNS - NLOGR);
-            static_for<0, NLOGR>([&](auto bI) {
-                constexpr int b = decltype(bI)::value;
-                nxt[b] = tw[(kidx << b) & (G::N - 1)];
-            });
+            if constexpr (compact_tw_of<G>::value) {
+                preload_compact<G, R, NLOGNS>(nxt, t, twc);
+            } else {
+                const int kidx = (t & ((1 << NLOGNS) - 1)) << (G::LOGN - NLOGNS - NLOGR);
+                static_for<0, NLOGR>([&](auto bI) {
+                    constexpr int b = decltype(bI)::value;
+                    nxt[b] = tw[(kidx << b) & (G::N - 1)];
+                });
+            }
             phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
-            fft_phases<G, R, NLOGNS>(x, t, rb, rowfast, lds, tw, fin, nxt);
+            fft_phases<G, R, NLOGNS>(x, t, rb, rowfast, lds, tw, fin, nxt, twc);
         } else {
             phase_exchange<G, R, LOGNS, LOGR>(x, t, rb, rowfast, lds);
-            fft_phases<G, R, NLOGNS>(x, t, rb, rowfast, lds, tw, fin);
+            fft_phases<G, R, NLOGNS>(x, t, rb, rowfast, lds, tw, fin, nullptr, twc);
         }
     }
 }
@@ -490,19 +524,24 @@ __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool
 // Schedule with the SHORT radix first (2^LOGR1 = N / P^k, two blocks per lane) and adjacent virtual threads per
 // lane: on entry x[u + NB*r] = input[(t*NB + u) + r * N / 2^LOGR1]  (u < NB = P / 2^LOGR1).
 template <class G, typename R, class F>
-__device__ __forceinline__ void fft_phases_pair(cx<R> (&x)[G::P], int t, void* lds, const cx<R>* __restrict__ tw, F&& fin) {
+__device__ __forceinline__ void fft_phases_pair(cx<R> (&x)[G::P], int t, void* lds, const cx<R>* __restrict__ tw, F&& fin,
+                                                const cx<R>* __restrict__ twc = nullptr) {
     constexpr int LOGR1 = G::LOGN % G::LOGP;
     static_assert(LOGR1 > 0 && LOGR1 < G::LOGP, "needs a short first phase");
     phase_compute<G, R, 0, LOGR1>(x, t, tw);
     if constexpr (preload_tw_of<G>::value && G::LOGP >= 5 && G::LOGN - LOGR1 >= G::LOGP) {
         cx<R> nxt[G::LOGP];
-        const int kidx = (t & ((1 << LOGR1) - 1)) << (G::LOGN - LOGR1 - G::LOGP);
-        static_for<0, G::LOGP>([&](auto bI) {
-            constexpr int b = decltype(bI)::value;
-            nxt[b] = tw[(kidx << b) & (G::N - 1)];
-        });
+        if constexpr (compact_tw_of<G>::value) {
+            preload_compact<G, R, LOGR1>(nxt, t, twc);
+        } else {
+            const int kidx = (t & ((1 << LOGR1) - 1)) << (G::LOGN - LOGR1 - G::LOGP);
+            static_for<0, G::LOGP>([&](auto bI) {
+                constexpr int b = decltype(bI)::value;
+                nxt[b] = tw[(kidx << b) & (G::N - 1)];
+            });
+        }
         phase_exchange<G, R, 0, LOGR1, true>(x, t, 0, false, lds);
-        fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin, nxt);
+        fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin, nxt, twc);
     } else {
         phase_exchange<G, R, 0, LOGR1, true>(x, t, 0, false, lds);
         fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin);

@@ -59,6 +59,8 @@ struct RowPassArgs {
     // (p * T + t) holds {w[s0][2t], w[s0][2t+1], w[s1][2t], w[s1][2t+1]} for the p-th segment pair (s0, s1) of the load
     // loop, zeros where the padded row has no data
     const float* ld_win4;
+    // ... and the compact twiddle sections of geometries with COMPACT_TW (Win4Cache::compact_tw; swiftly_fft.h, preload_compact)
+    const cx<float>* twc;
 };
 
 // physical column of logical (centred) column ck in a parity-split band buffer, or -1
@@ -88,6 +90,12 @@ struct RGeo {
 template <int LOGN_, int LOGP_, bool SPLIT_, bool PAD_ = true>
 struct RGeoPre : RGeo<LOGN_, LOGP_, SPLIT_, PAD_> {
     static constexpr bool PRELOAD_TW = true;
+};
+// ... and with the preloaded values taken from the compact sections of RowPassArgs::twc (swiftly_fft.h, compact_tw_of):
+// the W4 instances of the forward K1 (r5)
+template <int LOGN_, int LOGP_, bool SPLIT_, bool PAD_ = true>
+struct RGeoPreC : RGeoPre<LOGN_, LOGP_, SPLIT_, PAD_> {
+    static constexpr bool COMPACT_TW = true;
 };
 
 __device__ const float kRowOne = 1.f;
@@ -545,10 +553,11 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     SWF_TRACE_POINT(2);
     // rotated input: output k = 2 e + h, e = t + (last radix digit) * H / P, carries W_N^(rot k) = W_N^(rot (2 t + h))
     cx<float> rphi = {1.f, 0.f};
+    // (the 32 distinct rotation phases from a compact table too: 12 bytes of scratch per lane in the NSEG = 22 instance, not kept)
     if constexpr (SEGSKIP) rphi = tw_full[(unsigned)(rot * (2 * t + h)) & (unsigned)(N - 1)];
     auto run_phases = [&](auto&& fin) {
         if constexpr (PAIR)
-            fft_phases_pair<G, float>(x, t, smem, tw, fin);
+            fft_phases_pair<G, float>(x, t, smem, tw, fin, compact_tw_of<G>::value ? A.twc : nullptr);
         else
             fft_phases<G, float, 0>(x, t, 0, false, smem, tw, fin);
     };
@@ -677,6 +686,11 @@ struct Win4Cache {
     };
     std::mutex mu;
     std::vector<Entry> items;
+    // compact twiddle sections (RowPassArgs::twc) of the 2 x 16384-point pair geometry, built once from the owner's tables
+    cx<float>* twc = nullptr;
+    hipEvent_t twc_ready = nullptr;
+    hipStream_t twc_built_on = nullptr;
+    const cx<float>* compact_tw(const cx<float>* tw_half, hipStream_t s);
     static constexpr size_t kMaxEntries = 64;  // beyond: the plain instances (nothing is ever evicted: a kernel may be reading)
     const float* get(const float* win, int c, int len, int ns, int n, int seglen, hipStream_t s);
     void clear();  // frees the tables (owner's teardown, device idle)
