@@ -120,42 +120,6 @@ __global__ void build_win4_kernel(const float* __restrict__ win, float* __restri
     v.w = q1 + 1 < len ? win[q1 + 1] : 0.f;
     reinterpret_cast<f32x4*>(tab)[idx] = v;
 }
-// compact twiddle sections of geometry (LOGN, LOGP) in the pair schedule (swiftly_fft.h, preload_compact): copies of table entries
-__global__ void build_compact_tw_kernel(const cx<float>* __restrict__ tw, cx<float>* __restrict__ out, int logn, int logp) {
-    const int total = compact_tw_entries(logn, logp), idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    int ns = logn % logp;
-    while (compact_tw_offset(logn, logp, ns + logp) <= idx) ns += logp;
-    const int rel = idx - compact_tw_offset(logn, logp, ns), i = rel / logp, b = rel % logp;
-    const int kidx = i << (logn - ns - logp);
-    out[idx] = tw[(kidx << b) & ((1 << logn) - 1)];
-}
-const cx<float>* Win4Cache::compact_tw(const cx<float>* tw_half, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (twc) {
-        if (twc_built_on != s && hipStreamWaitEvent(s, twc_ready, 0) != hipSuccess) return nullptr;
-        return twc;
-    }
-    constexpr int logn = 14, logp = 5, count = compact_tw_entries(logn, logp);
-    cx<float>* buf = nullptr;
-    hipEvent_t ev = nullptr;
-    if (hipMalloc(&buf, (size_t)count * sizeof(cx<float>)) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-        (void)hipFree(buf);
-        return nullptr;
-    }
-    hipLaunchKernelGGL(build_compact_tw_kernel, dim3((count + 255) / 256), dim3(256), 0, s, tw_half, buf, logn, logp);
-    if (hipGetLastError() != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
-        (void)hipStreamSynchronize(s);
-        (void)hipEventDestroy(ev);
-        (void)hipFree(buf);
-        return nullptr;
-    }
-    twc = buf;
-    twc_ready = ev;
-    twc_built_on = s;
-    return twc;
-}
 static int win4_enabled() {  // SWIFTLY_K1_WIN4: 0 = the plain window loads, 1 = re-laid-out window, 2 = + compact twiddle sections (A/B runs)
     static const int v = getenv("SWIFTLY_K1_WIN4") ? atoi(getenv("SWIFTLY_K1_WIN4")) : 2;
     return v;
@@ -192,11 +156,6 @@ void Win4Cache::clear() {
         (void)hipFree(e.tab);
     }
     items.clear();
-    if (twc) {
-        (void)hipEventDestroy(twc_ready);
-        (void)hipFree(twc);
-        twc = nullptr;
-    }
 }
 
 template <class G, bool PAIR = false>
@@ -234,7 +193,7 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
         constexpr int n_ = 2 * G::N;                                                           \
         const int c_ = (int)(((long long)a.ld_a + n_ / 2 + (long long)first * SEGLEN) % n_);   \
         a.ld_win4 = (w4cache && win4_enabled()) ? w4cache->get(a.ld_win, c_, a.ld_len, NS, n_, SEGLEN, s) : nullptr; \
-        a.twc = (a.ld_win4 && win4_enabled() >= 2) ? w4cache->compact_tw(tw14, s) : nullptr; \
+        a.twc = (a.ld_win4 && win4_enabled() >= 2) ? w4cache->twc : nullptr;               \
         if (a.twc)                                                                             \
             launch_band_inst<GC, PAIR, true, 1, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
         else if (a.ld_win4)                                                                    \
@@ -248,6 +207,18 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
                 SWF_TRY_SEG_PRE(24)
 #undef SWF_TRY_SEG_PRE
             } else if (a.band_len < 0 && fwd) {
+                // backward finish: compact twiddle sections when the caller owns the tables
+                using GB = RGeoC<G::LOGN, G::LOGP, G::SPLIT>;
+                a.twc = (w4cache && win4_enabled() >= 2) ? w4cache->twc : nullptr;
+#define SWF_TRY_SEG_C(NS)                                                              \
+    if (a.twc && run <= NS) {                                                          \
+        a.seg_rot = first;                                                             \
+        launch_band_inst<GB, PAIR, false, 2, NS, 0>(a, blocks, tw14, tw_full, s);      \
+        return (int)hipGetLastError();                                                 \
+    }
+                SWF_TRY_SEG_C(13)
+                SWF_TRY_SEG_C(16)
+#undef SWF_TRY_SEG_C
                 SWF_TRY_SEG(false, 2, 13, 0)
                 SWF_TRY_SEG(false, 2, 16, 0)
             }
@@ -353,6 +324,9 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 1, 24, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16, true, 0>();
+        using BandGeo5C = RGeoC<14, 5, true>;
+        if (!rcb) rcb = init_band_pair<BandGeo5C, false, 2, 13, true, 0>();
+        if (!rcb) rcb = init_band_pair<BandGeo5C, false, 2, 16, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false, 1>();
         if (!rcb) rcb = init_band_geo<BandGeo4>();
         if (!rcb) rcb = init_band_geo<BandGeo64k>();

@@ -41,16 +41,33 @@ static int upload(swiftly_hip* h, T** dst, const std::vector<T>& v) {
     return 0;
 }
 
+static std::vector<cx<float>> host_twiddles_f(int logn) {
+    const int n = 1 << logn;
+    std::vector<cx<float>> t(n);
+    for (int k = 0; k < n; k++) {
+        // exact octant symmetry is not needed; evaluate in long double
+        long double a = -2.0L * 3.14159265358979323846264338327950288L * k / n;
+        t[k] = {(float)cosl(a), (float)sinl(a)};
+    }
+    return t;
+}
+// compact copy of the float table of length 2^logn for kernels with 2^logp points per lane (swiftly_fft.h)
+static int make_compact_twiddles(swiftly_hip* h, int logn, int logp) {
+    if (logn < 2 || logp < 1 || logn > kMaxLogNFloat + 1 || h->twc_f.count({logn, logp})) return 0;
+    const std::vector<cx<float>> t = host_twiddles_f(logn);
+    std::vector<cx<float>> c((size_t)compact_tw_entries(logn, logp));
+    build_compact_twiddles(t.data(), logn, logp, c.data());
+    cx<float>* d;
+    if (int rc = upload(h, &d, c)) return rc;
+    h->twc_f[{logn, logp}] = d;
+    return 0;
+}
+
 static int make_twiddles(swiftly_hip* h, int logn) {
     if (logn < kMinLogN) return 0;
     const int n = 1 << logn;
     if (logn <= kMaxLogNFloat + 1 && !h->tw_f.count(logn)) {  // 2^16: only the band row kernel and the column passes use it
-        std::vector<cx<float>> t(n);
-        for (int k = 0; k < n; k++) {
-            // exact octant symmetry is not needed; evaluate in long double
-            long double a = -2.0L * 3.14159265358979323846264338327950288L * k / n;
-            t[k] = {(float)cosl(a), (float)sinl(a)};
-        }
+        const std::vector<cx<float>> t = host_twiddles_f(logn);
         cx<float>* d;
         if (int rc = upload(h, &d, t)) return rc;
         h->tw_f[logn] = d;
@@ -267,6 +284,16 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             if (!rc && l == 15) rc = make_twiddles(h, 13);
             if (!rc && (l == 16 || l == 14)) rc = make_twiddles(h, l - 1);  // band row kernel halves
         }
+    // compact copies for the contiguous-axis kernels whose lanes gather table values (swiftly_fft.h): the forward K1 / backward
+    // finish of 32768-point rows (2 x 16384 points, 32 per lane) and the one-wave-per-row subgrid-side kernels (64 lanes per row)
+    if (!rc && h->log_yN == 15) {
+        rc = make_compact_twiddles(h, 14, 5);
+        if (!rc) h->win4.twc = compact_twiddles(h, 14, 5);
+    }
+    if (!rc && sum_finish_supported(h->log_m, h->log_xM) && h->log_xM < 12) {
+        rc = make_compact_twiddles(h, h->log_m, h->log_m - 6);
+        if (!rc) rc = make_compact_twiddles(h, h->log_xM, h->log_xM - 6);
+    }
     for (int64_t len : {yN, xM, h->m})
         if (!rc) rc = make_bluestein(h, len);
     for (int64_t len : {yN, xM, h->m})
@@ -781,7 +808,7 @@ static bool try_row_pass(swiftly_hip* h, int logn, const RowsArgs<float>& a, con
                 *rc_out = rc;
                 return true;
             }
-            int e2 = launch_row_pass_band(r, tw14, r.tw, st);
+            int e2 = launch_row_pass_band(r, tw14, r.tw, st, &h->win4);
             if (tmp) (void)hipFreeAsync(tmp, st);
             *rc_out = e2 ? fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e2)) : 0;
             return true;

@@ -64,6 +64,8 @@ struct swiftly_hip {
     double* fn_d = nullptr;
     std::map<int, cx<float>*> tw_f;  // by log2(length)
     std::map<int, cx<double>*> tw_d;
+    // compact copies of the float tables (swiftly_fft.h, "compact twiddle sections") by (log2(length), log2(points per lane))
+    std::map<std::pair<int, int>, cx<float>*> twc_f;
     // Bluestein tables for transform lengths that are not a power of two (swiftly_bluestein.h), by length
     struct Blu {
         int logL = 0;
@@ -107,6 +109,10 @@ template <>
 inline const cx<double>* twiddles<double>(const swiftly_hip* h, int logn) {
     auto it = h->tw_d.find(logn);
     return it == h->tw_d.end() ? nullptr : it->second;
+}
+inline const cx<float>* compact_twiddles(const swiftly_hip* h, int logn, int logp) {
+    auto it = h->twc_f.find({logn, logp});
+    return it == h->twc_f.end() ? nullptr : it->second;
 }
 template <typename R>
 inline const R* invp(const swiftly_hip* h);

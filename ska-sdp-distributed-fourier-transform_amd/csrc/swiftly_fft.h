@@ -312,7 +312,7 @@ __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __
         cx<R> w[RAD];
         static_for<0, LOGR>([&](auto bI) {
             constexpr int b = decltype(bI)::value;
-            w[1 << b] = tw[(kidx << b) & (N - 1)];
+            w[1 << b] = pre ? pre[b] : tw[(kidx << b) & (N - 1)];
         });
         static_for<1, RAD>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
@@ -323,10 +323,56 @@ __device__ __forceinline__ void twiddle_inputs(cx<R> (&x)[PTOT], const cx<R>* __
     }
 }
 
+// COMPACT TWIDDLE SECTIONS (r5).  The table values a phase builds its inter-phase twiddles from are
+// tw[(k << (LOGN - LOGNS - LOGR + b)) & (N - 1)], b < LOGR, with k = (virtual thread) mod 2^LOGNS: gathers whose lanes are
+// 8 << s bytes apart -- up to one cache line per lane (K1's last phase: 124 lines per wave for 5 loads).  Geometries with
+// `static constexpr bool COMPACT_TW = true` take them from a re-ordered COPY of the table instead (host-built from the
+// same values, bit-identical): for every phase boundary ns = 1 .. LOGN - 1 a section of 2^ns entries of LOGP slots at
+// offset LOGP * (2^ns - 2), slot i of entry k = tw[(k << (LOGN - ns - 1 - i)) & (N - 1)] (0 when the shift would be
+// negative) -- independent of the schedule: a phase (LOGNS, LOGR) reads b from slot LOGR - 1 - b, and the lanes of a wave
+// read consecutive entries (20 lines for K1's last phase).  Measured (r5, same box, K1 per facet): 1.61 - 1.63 ms with the
+// table gathers, 1.53 - 1.55 ms with two 16-byte and one 8-byte load per section, 1.51 - 1.52 ms with five 8-byte loads
+// (kept): the vector-memory path charges for the lines a wave instruction touches, not for the instruction count.
+template <class G, class = void>
+struct compact_tw_of {
+    static constexpr bool value = false;
+};
+template <class G>
+struct compact_tw_of<G, std::enable_if_t<G::COMPACT_TW>> {
+    static constexpr bool value = true;
+};
+// a geometry with the compact sections switched on
+template <class G>
+struct CompactTw : G {
+    static constexpr bool COMPACT_TW = true;
+};
+constexpr int compact_tw_offset(int logp, int ns) { return logp * ((1 << ns) - 2); }
+constexpr int compact_tw_entries(int logn, int logp) { return compact_tw_offset(logp, logn); }
+// host side: the compact copy of table `tw` (length 2^logn) for geometries with 2^logp points per lane
+template <typename R>
+inline void build_compact_twiddles(const cx<R>* tw, int logn, int logp, cx<R>* out) {
+    for (int ns = 1; ns < logn; ns++)
+        for (int k = 0; k < (1 << ns); k++)
+            for (int i = 0; i < logp; i++) {
+                const int sh = logn - ns - 1 - i;
+                out[compact_tw_offset(logp, ns) + k * logp + i] = sh >= 0 ? tw[((long long)k << sh) & ((1 << logn) - 1)] : cx<R>{0, 0};
+            }
+}
+// the LOGR table values of phase (LOGNS, LOGR) for virtual thread j
+template <class G, typename R, int LOGNS, int LOGR>
+__device__ __forceinline__ void load_compact(cx<R> (&cw)[LOGR], int j, const cx<R>* __restrict__ twc) {
+    static_assert(LOGR <= G::LOGP && LOGNS >= 1, "a phase never has a larger radix than the points per lane");
+    const cx<R>* p = twc + compact_tw_offset(G::LOGP, LOGNS) + (j & ((1 << LOGNS) - 1)) * G::LOGP;
+    static_for<0, LOGR>([&](auto bI) {
+        constexpr int b = decltype(bI)::value;
+        cw[b] = p[LOGR - 1 - b];
+    });
+}
+
 // One Stockham phase, compute part: twiddle + in-register DFTs.
 template <class G, typename R, int LOGNS, int LOGR>
 __device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<R>* __restrict__ tw,
-                                              const cx<R>* pre = nullptr) {
+                                              const cx<R>* pre = nullptr, const cx<R>* __restrict__ twc = nullptr) {
     constexpr int RAD = 1 << LOGR, NB = G::P / RAD;
     static_for<0, NB>([&](auto uI) {
         constexpr int u = decltype(uI)::value;
@@ -334,8 +380,19 @@ __device__ __forceinline__ void phase_compute(cx<R> (&x)[G::P], int t, const cx<
             int j = t + u * G::T;
             int k = j & ((1 << LOGNS) - 1);
             // angle = -2 pi k r / (Ns * RAD)  ->  table index k * N/(Ns*RAD) * r
-            twiddle_inputs<R, LOGR, NB, u, G::P, G::N, lean_tw_of<G>::value>(x, tw, k << (G::LOGN - LOGNS - LOGR),
-                                                                             NB == 1 ? pre : nullptr);
+            if constexpr (compact_tw_of<G>::value) {
+                // table values from the compact section of this phase (in place unless they were preloaded)
+                if (NB == 1 && pre) {
+                    twiddle_inputs<R, LOGR, NB, u, G::P, G::N, lean_tw_of<G>::value>(x, tw, 0, pre);
+                } else {
+                    cx<R> cw[LOGR];
+                    load_compact<G, R, LOGNS, LOGR>(cw, j, twc);
+                    twiddle_inputs<R, LOGR, NB, u, G::P, G::N, lean_tw_of<G>::value>(x, tw, 0, cw);
+                }
+            } else {
+                twiddle_inputs<R, LOGR, NB, u, G::P, G::N, lean_tw_of<G>::value>(x, tw, k << (G::LOGN - LOGNS - LOGR),
+                                                                                 NB == 1 ? pre : nullptr);
+            }
         }
         fft_reg<R, LOGR, NB, u, G::P>(x);
     });
@@ -351,35 +408,6 @@ template <class G>
 struct preload_tw_of<G, std::enable_if_t<G::PRELOAD_TW>> {
     static constexpr bool value = true;
 };
-
-// Geometries with `static constexpr bool COMPACT_TW = true` (r5: RGeoPreC = the forward K1 with the re-laid-out window):
-// the table values of a radix-2^LOGP phase come from a COMPACT copy of the table -- per phase boundary NLOGNS a section of
-// 2^NLOGNS entries of LOGP values {tw[kidx << b], b < LOGP}, the lane's values in consecutive bytes -- so that the LOGP
-// 8-byte loads of a wave touch 20 cache lines together instead of being gathers with strides of 8 .. 128 bytes between
-// lanes (124 lines per wave in the last phase of K1).  The copy is made from the table itself (bit-identical values).
-// Measured (r5, same box, K1 per facet): 1.61 - 1.63 ms with the table gathers, 1.53 - 1.55 ms with two 16-byte and one
-// 8-byte load per section, 1.51 - 1.52 ms with five 8-byte loads (kept): what the vector-memory path charges for is the
-// number of lines a wave instruction touches, not the number of instructions.
-template <class G, class = void>
-struct compact_tw_of {
-    static constexpr bool value = false;
-};
-template <class G>
-struct compact_tw_of<G, std::enable_if_t<G::COMPACT_TW>> {
-    static constexpr bool value = true;
-};
-// section offsets (entries) for the phase boundaries of the pair schedule: LOGR1 = LOGN % LOGP, then + LOGP each
-constexpr int compact_tw_offset(int logn, int logp, int nlogns) {
-    int off = 0;
-    for (int ns = logn % logp; ns < nlogns; ns += logp) off += logp << ns;
-    return off;
-}
-constexpr int compact_tw_entries(int logn, int logp) { return compact_tw_offset(logn, logp, logn); }
-template <class G, typename R, int NLOGNS>
-__device__ __forceinline__ void preload_compact(cx<R> (&nxt)[G::LOGP], int t, const cx<R>* __restrict__ twc) {
-    const cx<R>* p = twc + compact_tw_offset(G::LOGN, G::LOGP, NLOGNS) + (t & ((1 << NLOGNS) - 1)) * G::LOGP;
-    static_for<0, G::LOGP>([&](auto bI) { nxt[decltype(bI)::value] = p[decltype(bI)::value]; });
-}
 
 // One Stockham phase, scatter part: f(e, value) for every output element of
 // this thread, e = natural-order index within the phase's output array.
@@ -496,7 +524,7 @@ __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool
                                            const cx<R>* __restrict__ twc = nullptr) {
     constexpr int REM = G::LOGN - LOGNS;
     constexpr int LOGR = REM < G::LOGP ? REM : G::LOGP;
-    phase_compute<G, R, LOGNS, LOGR>(x, t, tw, pre);
+    phase_compute<G, R, LOGNS, LOGR>(x, t, tw, pre, twc);
     if constexpr (LOGNS + LOGR == G::LOGN) {
         phase_scatter<G, R, LOGNS, LOGR>(x, t, fin);
     } else {
@@ -504,7 +532,7 @@ __device__ __forceinline__ void fft_phases(cx<R> (&x)[G::P], int t, int rb, bool
         if constexpr (preload_tw_of<G>::value && G::P == (1 << NLOGR) && NLOGR >= 5) {
             cx<R> nxt[NLOGR];
             if constexpr (compact_tw_of<G>::value) {
-                preload_compact<G, R, NLOGNS>(nxt, t, twc);
+                load_compact<G, R, NLOGNS, NLOGR>(nxt, t, twc);
             } else {
                 const int kidx = (t & ((1 << NLOGNS) - 1)) << (G::LOGN - NLOGNS - NLOGR);
                 static_for<0, NLOGR>([&](auto bI) {
@@ -532,7 +560,7 @@ __device__ __forceinline__ void fft_phases_pair(cx<R> (&x)[G::P], int t, void* l
     if constexpr (preload_tw_of<G>::value && G::LOGP >= 5 && G::LOGN - LOGR1 >= G::LOGP) {
         cx<R> nxt[G::LOGP];
         if constexpr (compact_tw_of<G>::value) {
-            preload_compact<G, R, LOGR1>(nxt, t, twc);
+            load_compact<G, R, LOGR1, G::LOGP>(nxt, t, twc);
         } else {
             const int kidx = (t & ((1 << LOGR1) - 1)) << (G::LOGN - LOGR1 - G::LOGP);
             static_for<0, G::LOGP>([&](auto bI) {
@@ -544,7 +572,7 @@ __device__ __forceinline__ void fft_phases_pair(cx<R> (&x)[G::P], int t, void* l
         fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin, nxt, twc);
     } else {
         phase_exchange<G, R, 0, LOGR1, true>(x, t, 0, false, lds);
-        fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin);
+        fft_phases<G, R, LOGR1>(x, t, 0, false, lds, tw, fin, nullptr, twc);
     }
 }
 

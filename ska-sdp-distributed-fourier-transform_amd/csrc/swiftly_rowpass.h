@@ -97,6 +97,11 @@ template <int LOGN_, int LOGP_, bool SPLIT_, bool PAD_ = true>
 struct RGeoPreC : RGeoPre<LOGN_, LOGP_, SPLIT_, PAD_> {
     static constexpr bool COMPACT_TW = true;
 };
+// compact sections without the preload: the backward finish instances (128 VGPRs: values fetched where they are used)
+template <int LOGN_, int LOGP_, bool SPLIT_, bool PAD_ = true>
+struct RGeoC : RGeo<LOGN_, LOGP_, SPLIT_, PAD_> {
+    static constexpr bool COMPACT_TW = true;
+};
 
 __device__ const float kRowOne = 1.f;
 
@@ -686,11 +691,9 @@ struct Win4Cache {
     };
     std::mutex mu;
     std::vector<Entry> items;
-    // compact twiddle sections (RowPassArgs::twc) of the 2 x 16384-point pair geometry, built once from the owner's tables
-    cx<float>* twc = nullptr;
-    hipEvent_t twc_ready = nullptr;
-    hipStream_t twc_built_on = nullptr;
-    const cx<float>* compact_tw(const cx<float>* tw_half, hipStream_t s);
+    // compact twiddle sections (RowPassArgs::twc; swiftly_fft.h) of the 2 x 16384-point geometry with 32 points per lane,
+    // set (and owned) by the owner of the cache: nullptr = the instances that gather from the plain table
+    const cx<float>* twc = nullptr;
     static constexpr size_t kMaxEntries = 64;  // beyond: the plain instances (nothing is ever evicted: a kernel may be reading)
     const float* get(const float* win, int c, int len, int ns, int n, int seglen, hipStream_t s);
     void clear();  // frees the tables (owner's teardown, device idle)

@@ -21,6 +21,12 @@ constexpr int kSumFinishThreads = 256;
 constexpr int kSumFinishInFlight = 3;
 constexpr int kSumFinishMaxGroups = 8;
 constexpr int kSumFinishMaxBatch = 64;
+// one-wave-per-row forms of the facet kernels with the compact twiddle sections (0: gathers from the plain tables; A/B builds)
+#ifndef SWF_SUMFINISH_COMPACT
+#define SWF_SUMFINISH_COMPACT 1
+#endif
+template <class G>
+using SFCompact = std::conditional_t<SWF_SUMFINISH_COMPACT != 0, CompactTw<G>, G>;
 
 struct SumFinishArgs {
     const cx<float>* in;   // colacc[g][b][row][m]
@@ -200,6 +206,10 @@ struct SumFinishFacetArgs {
     long long mask_bs;
     const cx<float>* tw_m;
     const cx<float>* tw_x;
+    // compact copies of the two tables (swiftly_fft.h, "compact twiddle sections") for the one-wave-per-row form, whose
+    // lanes otherwise gather their table values with strides of up to a cache line (r5); host-checked non-null there
+    const cx<float>* twc_m;
+    const cx<float>* twc_x;
     // Wave-parallel form (4096-point rows, SFWide): the groups in ROUNDS of mutually disjoint placement windows
     // (rgroup[rstart[r] .. rstart[r+1]) = the groups of round r); the waves of a workgroup transform different groups of
     // a round at the same time and add them into the shared accumulator row without conflicts
@@ -378,7 +388,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
         }
         if (!anyg) continue;
         const int sp = A.gsp1[g];
-        fft_phases<GM, float, 0>(xs, t, 0, false, ex_row, A.tw_m, [&](int e, cx<float> v, auto sI) {
+        fft_phases<SFCompact<GM>, float, 0>(xs, t, 0, false, ex_row, A.tw_m, [&](int e, cx<float> v, auto sI) {
             // slot = u * RAD + r of the last phase (radix RAD = 2^LR, NB = PM / RAD blocks): e = t + TR * (u + NB * r)
             constexpr int LR = GM::LOGN % GM::LOGP == 0 ? GM::LOGP : GM::LOGN % GM::LOGP, RAD = 1 << LR, NBL = PM / RAD;
             constexpr int slot = (decltype(sI)::value / RAD) + NBL * (decltype(sI)::value % RAD);
@@ -393,7 +403,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
                 y[slot + PM * cc].x += v.x * wc;
                 y[slot + PM * cc].y += v.y * wc;
             });
-        });
+        }, nullptr, A.twc_m);
         row_sync<GX>(false);  // the exchange buffer is reused by the next group
     }
     static_for<0, PX>([&](auto vI) { y[decltype(vI)::value].y = -y[decltype(vI)::value].y; });  // inverse = conj(FFT(conj(.)))
@@ -427,13 +437,13 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
             const bool ok = d < A.xA && live;
             mw[sl] = mask ? mask[ok ? d : 0] : 1.f;
         });
-        fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v, auto sI) {
+        fft_phases<SFCompact<GX>, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v, auto sI) {
             constexpr int sl = decltype(sI)::value;
             const int ck = e ^ (X >> 1);
             const int d = (ck + st_a) & (X - 1);
             const float w = scale * mw[sl];
             if (d < A.xA && live) out[d] = cx<float>{v.x * w, -v.y * w};
-        });
+        }, nullptr, A.twc_x);
         return;
     }
     fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
@@ -475,6 +485,8 @@ struct SplitFacetArgs {
     const float* fn;
     const cx<float>* tw_m;
     const cx<float>* tw_x;
+    const cx<float>* twc_m;  // compact copies, one-wave-per-row form (see SumFinishFacetArgs)
+    const cx<float>* twc_x;
 };
 
 template <int LOGM, int LOGX>
@@ -504,9 +516,10 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_
             const cx<float> val = in[ok ? q : 0];
             y[v] = ok ? val : cx<float>{0.f, 0.f};
         });
-        fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
+        using GXC = std::conditional_t<W::ON, GX, SFCompact<GX>>;
+        fft_phases<GXC, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
             acc[lds_pos<GX>(rb, e ^ (X >> 1), false)] = v;
-        });
+        }, nullptr, A.twc_x);
         row_sync<GX>(false);
     }
     const float scale = 1.f / (float)M;
@@ -591,13 +604,13 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_
                 const float w = A.fn[q];
                 x[v] = cx<float>{val.x * w, -val.y * w};  // inverse transform = conj(FFT(conj(.)))
             });
-            fft_phases<GM, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+            fft_phases<SFCompact<GM>, float, 0>(x, t, rb, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
                 const cx<float> o = cx<float>{v.x * scale, -v.y * scale};
                 static_for<0, NS>([&](auto sI) {
                     constexpr int sl = decltype(sI)::value;
                     if (outp[sl]) outp[sl][e ^ (M >> 1)] = o;
                 });
-            });
+            }, nullptr, A.twc_m);
             row_sync<GX>(false);  // ex_m is reused by the next transform
         }
     }
