@@ -285,14 +285,14 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             if (!rc && (l == 16 || l == 14)) rc = make_twiddles(h, l - 1);  // band row kernel halves
         }
     // compact copies for the contiguous-axis kernels whose lanes gather table values (swiftly_fft.h): the forward K1 / backward
-    // finish of 32768-point rows (2 x 16384 points, 32 per lane) and the one-wave-per-row subgrid-side kernels (64 lanes per row)
+    // finish of 32768-point rows (2 x 16384 points, 32 per lane) and the facet kernels of the subgrid side (64 lanes per transform)
     if (!rc && h->log_yN == 15) {
         rc = make_compact_twiddles(h, 14, 5);
         if (!rc) h->win4.twc = compact_twiddles(h, 14, 5);
     }
-    if (!rc && sum_finish_supported(h->log_m, h->log_xM) && h->log_xM < 12) {
+    if (!rc && sum_finish_supported(h->log_m, h->log_xM)) {
         rc = make_compact_twiddles(h, h->log_m, h->log_m - 6);
-        if (!rc) rc = make_compact_twiddles(h, h->log_xM, h->log_xM - 6);
+        if (!rc) rc = make_compact_twiddles(h, h->log_xM, h->log_xM - (h->log_xM >= 12 ? 8 : 6));
     }
     for (int64_t len : {yN, xM, h->m})
         if (!rc) rc = make_bluestein(h, len);

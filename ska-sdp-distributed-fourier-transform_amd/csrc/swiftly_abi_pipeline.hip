@@ -458,11 +458,10 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
     a.tw_m = twiddles<float>(h, h->log_m);
     a.tw_x = twiddles<float>(h, h->log_xM);
     if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    if (h->log_xM < 12) {  // one wave per row: table values from the compact copies
-        a.twc_m = compact_twiddles(h, h->log_m, h->log_m - 6);
-        a.twc_x = compact_twiddles(h, h->log_xM, h->log_xM - 6);
-        if (!a.twc_m || !a.twc_x) return fail(SWIFTLY_ERR_HIP, "internal: missing compact twiddle tables");
-    }
+    // table values from the compact copies (m-point transforms: 64 lanes each; rows: 64 lanes, 256 from 4096 points on)
+    a.twc_m = compact_twiddles(h, h->log_m, h->log_m - 6);
+    a.twc_x = compact_twiddles(h, h->log_xM, h->log_xM - (h->log_xM >= 12 ? 8 : 6));
+    if (!a.twc_m || !a.twc_x) return fail(SWIFTLY_ERR_HIP, "internal: missing compact twiddle tables");
     for (int64_t b0 = 0; b0 < nsub; b0 += kSumFinishMaxBatch) {
         const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nsub - b0);
         a.in = (const cx<float>*)in + b0 * in_sub_stride;
@@ -506,11 +505,10 @@ int swiftly_hip_split_prepare_facets(swiftly_hip_t* h, int dtype, const void* in
     a.tw_m = twiddles<float>(h, h->log_m);
     a.tw_x = twiddles<float>(h, h->log_xM);
     if (!a.tw_m || !a.tw_x) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    if (h->log_xM < 12) {  // one wave per row: table values from the compact copies
-        a.twc_m = compact_twiddles(h, h->log_m, h->log_m - 6);
-        a.twc_x = compact_twiddles(h, h->log_xM, h->log_xM - 6);
-        if (!a.twc_m || !a.twc_x) return fail(SWIFTLY_ERR_HIP, "internal: missing compact twiddle tables");
-    }
+    // table values from the compact copies (m-point transforms: 64 lanes each; rows: 64 lanes, 256 from 4096 points on)
+    a.twc_m = compact_twiddles(h, h->log_m, h->log_m - 6);
+    a.twc_x = compact_twiddles(h, h->log_xM, h->log_xM - (h->log_xM >= 12 ? 8 : 6));
+    if (!a.twc_m || !a.twc_x) return fail(SWIFTLY_ERR_HIP, "internal: missing compact twiddle tables");
     for (int64_t b0 = 0; b0 < nsub; b0 += kSumFinishMaxBatch) {
         const int nb = (int)std::min<int64_t>(kSumFinishMaxBatch, nsub - b0);
         a.in = (const cx<float>*)in + b0 * in_sub_stride;

@@ -21,7 +21,7 @@ constexpr int kSumFinishThreads = 256;
 constexpr int kSumFinishInFlight = 3;
 constexpr int kSumFinishMaxGroups = 8;
 constexpr int kSumFinishMaxBatch = 64;
-// one-wave-per-row forms of the facet kernels with the compact twiddle sections (0: gathers from the plain tables; A/B builds)
+// the facet kernels with the compact twiddle sections (0: gathers from the plain tables; A/B builds)
 #ifndef SWF_SUMFINISH_COMPACT
 #define SWF_SUMFINISH_COMPACT 1
 #endif
@@ -206,8 +206,8 @@ struct SumFinishFacetArgs {
     long long mask_bs;
     const cx<float>* tw_m;
     const cx<float>* tw_x;
-    // compact copies of the two tables (swiftly_fft.h, "compact twiddle sections") for the one-wave-per-row form, whose
-    // lanes otherwise gather their table values with strides of up to a cache line (r5); host-checked non-null there
+    // compact copies of the two tables (swiftly_fft.h, "compact twiddle sections": the lanes otherwise gather their table
+    // values with strides of up to a cache line; r5) for GM::LOGP / GX::LOGP points per lane; host-checked non-null
     const cx<float>* twc_m;
     const cx<float>* twc_x;
     // Wave-parallel form (4096-point rows, SFWide): the groups in ROUNDS of mutually disjoint placement windows
@@ -299,7 +299,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
                     }
                     if (anyg) {
                         const int sp = A.gsp1[g];
-                        fft_phases<GM, float, 0>(xs, lane, wv, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+                        fft_phases<SFCompact<GM>, float, 0>(xs, lane, wv, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
                             const int ck = e ^ (M >> 1);
                             const int kk = (ck - sp) & (M - 1);
                             const int dest = (kk + (X >> 1) - (M >> 1) + sp) & (X - 1);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
                             o.x += v.x * w;
                             o.y += v.y * w;
                             *p = o;
-                        });
+                        }, nullptr, A.twc_m);
                     }
                 }
             }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
         }, nullptr, A.twc_x);
         return;
     }
-    fft_phases<GX, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
+    fft_phases<SFCompact<GX>, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
         const int ck = e ^ (X >> 1);
         const int d = (ck + st_a) & (X - 1);
         if (d < A.xA && live) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
             if (mask) w *= mask[d];
             out[d] = cx<float>{v.x * w, -v.y * w};
         }
-    });
+    }, nullptr, A.twc_x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -516,8 +516,7 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_
             const cx<float> val = in[ok ? q : 0];
             y[v] = ok ? val : cx<float>{0.f, 0.f};
         });
-        using GXC = std::conditional_t<W::ON, GX, SFCompact<GX>>;
-        fft_phases<GXC, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
+        fft_phases<SFCompact<GX>, float, 0>(y, t, rb, false, acc, A.tw_x, [&](int e, cx<float> v) {
             acc[lds_pos<GX>(rb, e ^ (X >> 1), false)] = v;
         }, nullptr, A.twc_x);
         row_sync<GX>(false);
@@ -558,13 +557,13 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT)) void split_prepare_facets_
                     const float w = A.fn[q];
                     x[v] = cx<float>{val.x * w, -val.y * w};  // inverse transform = conj(FFT(conj(.)))
                 });
-                fft_phases<GM, float, 0>(x, lane, wv, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
+                fft_phases<SFCompact<GM>, float, 0>(x, lane, wv, false, ex_m, A.tw_m, [&](int e, cx<float> v) {
                     const cx<float> o = cx<float>{v.x * scale, -v.y * scale};
                     static_for<0, NS>([&](auto sI) {
                         constexpr int sl = decltype(sI)::value;
                         if (outp[sl]) outp[sl][e ^ (M >> 1)] = o;
                     });
-                });
+                }, nullptr, A.twc_m);
                 __builtin_amdgcn_wave_barrier();  // this wave's quarter of ex_m is reused by its next transform
             }
         }
