@@ -559,6 +559,8 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
     // rotated input: output k = 2 e + h, e = t + (last radix digit) * H / P, carries W_N^(rot k) = W_N^(rot (2 t + h))
     cx<float> rphi = {1.f, 0.f};
     // (the 32 distinct rotation phases from a compact table too: 12 bytes of scratch per lane in the NSEG = 22 instance, not kept)
+    // (the 32 distinct phases from a 256-byte table behind the exchange buffer, read by the store epilogue: 12 bytes of scratch
+    // in the NSEG = 22 instance again, K1 1.55 - 1.58 vs 1.51 - 1.53 ms per facet, r5; not kept)
     if constexpr (SEGSKIP) rphi = tw_full[(unsigned)(rot * (2 * t + h)) & (unsigned)(N - 1)];
     auto run_phases = [&](auto&& fin) {
         if constexpr (PAIR)

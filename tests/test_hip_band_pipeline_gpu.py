@@ -566,3 +566,43 @@ def test_cooperative_facets_virtual_ranks(world, whole_waves):
     for j, w in enumerate(want):
         assert done[j].shape == w.shape
         assert float((done[j] - w).abs().pow(2).mean().sqrt()) <= 3e-6 * float(w.abs().pow(2).mean().sqrt()), j
+
+
+_K1_PROBE = r"""
+import hashlib, sys
+import numpy, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from ska_sdp_exec_swiftly_amd import SwiftlyCoreHip
+core = SwiftlyCoreHip(10.875, 65536, 1024, 32768)
+rng = numpy.random.default_rng(5)
+x = torch.from_numpy((rng.standard_normal((5, 22528)) + 1j * rng.standard_normal((5, 22528))).astype(numpy.complex64)).cuda()
+band = (10736, 11472)
+h = hashlib.sha256()
+for off in (0, 64 * 352, -64 * 352, -64 * 320, 64 * 351):
+    h.update(core.prepare_facet_band(x, off, band, fold_other_axis_window=True).cpu().numpy().tobytes())
+b = torch.from_numpy((rng.standard_normal((5, band[1])) + 1j * rng.standard_normal((5, band[1]))).astype(numpy.complex64)).cuda()
+for off in (0, 64 * 352):
+    h.update(core.finish_facet_band(b, band, off, 22528).cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_k1_window_and_twiddle_tables_are_bit_identical(tmp_path):
+    """(r5) the re-laid-out load window (16-byte loads) and the compact twiddle sections of the long-row kernels are
+    copies of the plain tables: K1 and the backward finish give the same BITS with them switched off (SWIFTLY_K1_WIN4=0;
+    the switch is read once per process, hence the subprocesses)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "k1_probe.py"
+    script.write_text(_K1_PROBE)
+    digests = []
+    for mode in ("0", "1", "2"):
+        env = dict(os.environ, SWIFTLY_K1_WIN4=mode)
+        out = subprocess.run([sys.executable, str(script), root, os.path.join(root, "ska-sdp-distributed-fourier-transform_amd")],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1] == digests[2]
