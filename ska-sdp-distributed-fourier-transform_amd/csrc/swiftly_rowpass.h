@@ -14,6 +14,12 @@
 
 #include "swiftly_fft.h"
 
+// groups of three loads the W4 instances of the band row kernel request before the first one is consumed (0: the
+// compiler's own schedule)
+#ifndef SWF_K1_PIPE
+#define SWF_K1_PIPE 8
+#endif
+
 namespace swf {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -433,6 +439,62 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         constexpr int NB1 = NS - R1;
         const __amdgpu_buffer_rsrc_t rs_w4 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W4 ? A.ld_win4 : nullptr), (short)0, W4 ? (NS / 2) * T * 16 : 0, 0x00020000);
         f32x4 wcarry = {0.f, 0.f, 0.f, 0.f};
+#if SWF_K1_PIPE
+        // (r5) EXPLICIT LOAD PIPELINE of the W4 instances.  The lane's loads come in NG groups of three 16-byte loads -- the
+        // window quad of a segment pair and the pair's two data quads (segments (r, r + 16) for r < NB1, then (r, r + 1)) --
+        // and 33 loads in flight would need 132 VGPRs.  Left to itself the compiler issues 20 loads, WAITS for nine of them,
+        // and only then issues the other 13: two memory round trips per workgroup.  Here the first PIPE groups are requested
+        // at once and every group consumed (window products, first-stage sum: 12 VGPRs shrink to 4 or 8) makes room for the
+        // request of the next one, in program order pinned by scheduling barriers.
+        constexpr bool PIPED = W4 && CJ == 1;
+        if constexpr (PIPED) {
+            constexpr int NGA = NB1, NG = NB1 + (R1 - NB1) / 2, PIPE = SWF_K1_PIPE < NG ? SWF_K1_PIPE : NG;
+            f32x4 gw[NG], g0[NG], g1[NG];
+            auto issue = [&](auto gI) {
+                constexpr int g = decltype(gI)::value;
+                constexpr int r0 = g < NGA ? g : NGA + 2 * (g - NGA);           // first slot of the group
+                constexpr int s0 = r0, s1 = g < NGA ? r0 + R1 : r0 + 1;         // its two segments
+                gw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w4, (g * T + t) << 4, 0, 0));
+                const unsigned o0 = (base8 + (unsigned)((s0 * SEG) << 3)) & (unsigned)((N << 3) - 1);
+                const unsigned o1 = (base8 + (unsigned)((s1 * SEG) << 3)) & (unsigned)((N << 3) - 1);
+                g0[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)o0, 0, 0));
+                g1[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)o1, 0, 0));
+            };
+            auto wmul = [&](f32x4 val, f32x2 w, cx<float>& e0, cx<float>& e1) {  // (x w, -y w) per point: window + conjugation
+                const f32x2 p0 = {val.x, val.y}, p1 = {val.z, val.w};
+                f32x2 q0, q1;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(q0) : "v"(p0), "v"(w));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_hi:[1,0]" : "=v"(q1) : "v"(p1), "v"(w));
+                e0 = pkc(q0);
+                e1 = pkc(q1);
+            };
+            auto consume = [&](auto gI) {
+                constexpr int g = decltype(gI)::value;
+                constexpr int r0 = g < NGA ? g : NGA + 2 * (g - NGA);
+                cx<float> a0[2], a1[2];
+                wmul(g0[g], f32x2{gw[g].x, gw[g].y}, a0[0], a0[1]);
+                wmul(g1[g], f32x2{gw[g].z, gw[g].w}, a1[0], a1[1]);
+                static_for<0, 2>([&](auto uI) {
+                    constexpr int u = decltype(uI)::value;
+                    if constexpr (g < NGA) {
+                        x[u + 2 * r0] = pkc(__builtin_elementwise_fma(pkv(a1[u]), f32x2{sgn, sgn}, pkv(a0[u])));
+                    } else {
+                        x[u + 2 * r0] = a0[u];
+                        x[u + 2 * (r0 + 1)] = a1[u];
+                    }
+                });
+            };
+            static_for<0, PIPE>(issue);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NG>([&](auto gI) {
+                constexpr int g = decltype(gI)::value;
+                consume(gI);
+                if constexpr (g + PIPE < NG) issue(std::integral_constant<int, g + PIPE>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            static_for<2 * (NGA + 2 * (NG - NGA)), P>([&](auto vI) { x[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
+        } else
+#endif
         static_for<0, R1>([&](auto rI) {
             constexpr int r = decltype(rI)::value;
             cx<float> a[2][2];  // [q][u]
