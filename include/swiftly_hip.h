@@ -95,6 +95,17 @@ int64_t swiftly_hip_contribution_size(const swiftly_hip_t* h); /* xM*yN/N, core.
  * core.py:212-222.) */
 int swiftly_hip_set_column_precision(swiftly_hip_t* h, int bits);
 int swiftly_hip_get_column_precision(const swiftly_hip_t* h);
+/* Chained four-step launches (calling thread only; default 0).  A strided-axis transform whose intermediate exceeds
+ * 256 MB runs in chunks on two internal streams of the handle; each call FORKS them behind everything queued on the
+ * caller's stream and JOINS them back into it.  Between two such calls that follow each other on one stream the join /
+ * fork pair is a full pipeline drain plus two cross-stream event hops (measured on the 64k workload: 40 us with nothing
+ * running on the GPU, once per wave).  With chain = 1 the calling thread promises that the INPUTS of its next calls were
+ * already complete when an earlier (forking) call on the same handle was queued, and that nobody else still uses the
+ * output buffer: the fork is skipped, the chunk streams run on from the previous call's chunks, the join is unchanged
+ * (the caller's stream still continues behind the whole transform).  SwiftlyForward's planned-wave prefetch (K2 of
+ * consecutive waves read the same band buffers) sets it around the second and later calls of a pass.  (No reference
+ * counterpart: scheduling of this implementation.) */
+void swiftly_hip_chain_chunk_streams(int chain);
 
 /* -- facet -> subgrid ------------------------------------------------------ */
 

@@ -566,9 +566,14 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
             }
             // fork: the chunk streams start behind everything queued on `st` (a failed record / wait would let them
             // run ahead of the producer of the input: nothing has been launched yet, so just report it)
-            he = hipEventRecord(ev[0], st);
-            for (hipStream_t s2 : h->chunk_st)
-                if (he == hipSuccess) he = hipStreamWaitEvent(s2, ev[0], 0);
+            // (swiftly_hip_chain_chunk_streams: the caller vouches for the inputs; the chunk streams run on from the chunks
+            // of the previous call -- no pipeline drain and no idle event hops between consecutive waves, r5)
+            he = hipSuccess;
+            if (!g_chain_chunk_streams) {
+                he = hipEventRecord(ev[0], st);
+                for (hipStream_t s2 : h->chunk_st)
+                    if (he == hipSuccess) he = hipStreamWaitEvent(s2, ev[0], 0);
+            }
             if (he != hipSuccess) {
                 drop_events();
                 return fail(SWIFTLY_ERR_HIP, "chunked four-step, fork: %s", hipGetErrorString(he));

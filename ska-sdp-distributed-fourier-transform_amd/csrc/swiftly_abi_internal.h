@@ -98,6 +98,9 @@ struct swiftly_hip {
     Win4Cache win4;
 };
 
+// swiftly_hip_chain_chunk_streams (include/swiftly_hip.h): the calling thread's chunked four-step launches skip their fork
+extern thread_local int g_chain_chunk_streams;
+
 template <typename R>
 inline const cx<R>* twiddles(const swiftly_hip* h, int logn);
 template <>

@@ -16,9 +16,13 @@ __global__ void cu_census_kernel(int* __restrict__ out) {
 }
 
 
+thread_local int g_chain_chunk_streams = 0;
+
 extern "C" {
 
 const char* swiftly_hip_build_id(void) { return SWF_SRC_HASH; }
+
+void swiftly_hip_chain_chunk_streams(int chain) { g_chain_chunk_streams = chain ? 1 : 0; }
 
 int swiftly_hip_set_column_precision(swiftly_hip_t* h, int bits) {
     if (!h) return fail(SWIFTLY_ERR_PARAM, "null argument");

@@ -37,6 +37,8 @@ def _declare(lib):
     lib.swiftly_hip_contribution_size.argtypes = [vp]
     lib.swiftly_hip_build_id.restype = ctypes.c_char_p
     lib.swiftly_hip_build_id.argtypes = []
+    lib.swiftly_hip_chain_chunk_streams.restype = None
+    lib.swiftly_hip_chain_chunk_streams.argtypes = [ctypes.c_int]
     lib.swiftly_hip_set_column_precision.restype = ctypes.c_int
     lib.swiftly_hip_set_column_precision.argtypes = [vp, ctypes.c_int]
     lib.swiftly_hip_get_column_precision.restype = ctypes.c_int

@@ -295,6 +295,8 @@ class TaskQueue:
 _PREFETCH = os.environ.get("SWIFTLY_PREFETCH", "1") != "0"
 # how many planned waves K2 may run ahead of the wave being served (SwiftlyForward._prefetch_wave): 1 = the r4 schedule
 _PREFETCH_DEPTH = max(1, int(os.environ.get("SWIFTLY_PREFETCH_DEPTH", "2")))
+# SWIFTLY_CHAIN_K2=0: every prefetched K2 forks its chunk streams behind the side stream again (A/B runs)
+_CHAIN_K2 = os.environ.get("SWIFTLY_CHAIN_K2", "1") != "0"
 
 
 def _torch():
@@ -897,6 +899,7 @@ class SwiftlyForward:
                     timer.stop("K1_full_facet_transform", t0)
                 self._ingest.prefetch(j + 1)
             self.BF_Fs_persist = bands
+            self.__dict__["_k2_chain_forked"] = False  # new band buffers: the next prefetched K2 forks behind K1 again
             if self._plan is not None and _PREFETCH and _PREFETCH_DEPTH >= 2:
                 ready = self.__dict__["_bands_ready"] = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(core.device))
@@ -1041,13 +1044,22 @@ class SwiftlyForward:
             ev = torch.cuda.Event()
             ev.record(main)  # bands ready; every reader of a Q buffer that the allocator may hand out again has been enqueued
             side.wait_event(ev)
+        # (r5) second and later K2 of the free-running chain: the chunk streams of the four-step run on from the previous
+        # wave's chunks instead of being forked behind its join -- the band buffers were complete before the first (forking)
+        # call of this object, Q is a fresh block (swiftly_hip_chain_chunk_streams; 40 us of idle GPU per wave otherwise)
+        chain = _PREFETCH_DEPTH >= 2 and ready is not None and _CHAIN_K2 and self.__dict__.get("_k2_chain_forked", False)
         with torch.cuda.stream(side):
             Q = torch.empty((len(self.facet_configs), n_rows, core.xM_yN_size), dtype=self.dtype, device=core.device)
-            core.prepare_facet_columns(
-                self.BF_Fs_persist, [cfg.off0 for cfg in self.facet_configs], self._band, off1, rowmap, n_rows, out=Q
-            )
+            core.chain_chunk_streams(chain)
+            try:
+                core.prepare_facet_columns(
+                    self.BF_Fs_persist, [cfg.off0 for cfg in self.facet_configs], self._band, off1, rowmap, n_rows, out=Q
+                )
+            finally:
+                core.chain_chunk_streams(False)
             done = torch.cuda.Event()
             done.record(side)
+        self.__dict__["_k2_chain_forked"] = True
         pending[int(off1)] = (Q, rowmap, done)
 
     def _prefetch_waves(self, waves):

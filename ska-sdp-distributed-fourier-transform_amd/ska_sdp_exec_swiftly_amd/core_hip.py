@@ -704,6 +704,12 @@ class SwiftlyCoreHip:
             )
         )
 
+    def chain_chunk_streams(self, chain):
+        """``swiftly_hip_chain_chunk_streams`` for the calling thread: the next chunked strided-axis transforms skip the
+        fork of their two internal streams (the caller vouches that their inputs were complete before an earlier,
+        forking call; include/swiftly_hip.h)"""
+        self._lib.swiftly_hip_chain_chunk_streams(1 if chain else 0)
+
     def side_stream(self):
         """second HIP stream of this core (bandwidth-bound work issued next to an issue-bound kernel)"""
         st = self.__dict__.get("_side_stream")
