@@ -883,11 +883,17 @@ def main():
     for _ in range(args.warmup):
         one_pass()
     fence()
+    # (r5) one HIP event behind every timed pass (no synchronisation: the timed region is unchanged): the per-step times
+    # say whether a run's average hides an outlier -- the first process on a fresh box has shown single passes of + 10 ms
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_events[0].record()
+    for i in range(args.steps):
         one_pass()
+        step_events[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms_each = [round(step_events[i].elapsed_time(step_events[i + 1]), 3) for i in range(args.steps)]
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -1204,6 +1210,7 @@ def main():
         steps=args.steps,
         warmup=args.warmup,
         ms_per_step=round(ms_per_step, 3),
+        step_ms_each=step_ms_each,  # HIP events behind each timed pass on rank 0's stream (information; `value` uses the wall clock)
         higher_is_better=True,
         scaling="strong",
         vs_baseline=None,
