@@ -66,6 +66,28 @@ def test_prepare_facet_band(band):
         assert rel < 2e-6, (band, off, rel)
 
 
+def test_prepare_facet_band_16_segment_facets():
+    """K1 on facets of 16384 columns in 32768-point rows (the 4x4 / 8x8 custom covers of bench.py): exactly 16 of the 32
+    load segments hold data at aligned offsets -- the NSEG = 16 instances, whose re-laid-out window has no (r, r + 16)
+    segment pairs at all -- and 17 at an unaligned one (NSEG = 22 with empty tail segments)."""
+    import torch
+
+    core, ref = core64()
+    rng = numpy.random.default_rng(23)
+    rows, yB = 5, 16384
+    x = (rng.standard_normal((rows, yB)) + 1j * rng.standard_normal((rows, yB))).astype(numpy.complex64)
+    xt = torch.from_numpy(x).cuda()
+    band = (10736, 11472)
+    pc = band_cols(yN64, band)
+    keep = pc >= 0
+    for off in (0, 16384, -16384, 3 * 8192, 16384 + 2 * 333):
+        got = core.prepare_facet_band(xt, off, band, fold_other_axis_window=False).cpu().numpy()
+        want = ref.prepare_facet(x.astype(complex), off, 1)
+        assert got.shape == (rows, core.band_columns(band))
+        rel = relrms(got[:, pc[keep]], want[:, keep])
+        assert rel < 2e-6, (off, rel)
+
+
 def test_band_for_offsets_and_supports():
     core, _ = core64()
     offs = [i * 928 for i in list(range(0, 13)) + list(range(59, 71))]
