@@ -19,6 +19,12 @@
 #ifndef SWF_K1_PIPE
 #define SWF_K1_PIPE 8
 #endif
+// band store of the long-row kernel through a range-checked buffer store (1, r6) or the wave-uniform all-inside / masked pair
+// (0, r4b): bit-identical, K1 1.457 - 1.493 against 1.467 - 1.505 ms per facet (same box, interleaved), 484 -> ~330 scalar
+// instructions per wave
+#ifndef SWF_K1_BUFSTORE
+#define SWF_K1_BUFSTORE 1
+#endif
 
 namespace swf {
 
@@ -683,8 +689,31 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
         const int dw = ((wave << 7) + (N >> 1) - A.band_start + h) & (N - 1);  // d of lane 0, output r = 0
         const int lane2 = (t & 63) << 1;
-        const unsigned lane8 = (unsigned)(t & 63) << 3;
         const f32x2 sc = {scale, scale};
+#if SWF_K1_BUFSTORE
+        // (r6) WHICH LANES of a kept output are inside the band is left to the range check of a buffer store whose descriptor
+        // covers exactly the kept columns of this workgroup's parity region: one store path, one scalar branch per output
+        const int par = (h ^ A.band_start) & 1;
+        const int ncol = (A.band_len - par + 1) >> 1;   // columns q = d >> 1 with 2 q + par < band_len
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb + region, (short)0, ncol << 3, 0x00020000);
+        const unsigned off0 = (unsigned)(((dw + lane2) & (N - 1)) >> 1) << 3;
+        run_phases([&](int, cx<float> v, auto sI) {
+            constexpr int r = decltype(sI)::value;
+            const int base = (dw + (r << (LNS + 1))) & (N - 1);  // wave-uniform
+            const bool none_in = base >= A.band_len && base + 126 < N;
+            if (none_in) return;
+            if constexpr (SEGSKIP) v = cmul(v, rphi);
+            f32x2 val;
+            const f32x2 vv = pkv(v);
+            if constexpr (CJ == 1)
+                asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(val) : "v"(vv), "v"(sc));
+            else
+                val = vv * sc;
+            const unsigned off = (off0 + (unsigned)(r << (LNS + 3))) & (unsigned)((N << 2) - 1);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)off, 0, 0);
+        });
+#else
+        const unsigned lane8 = (unsigned)(t & 63) << 3;
         char* __restrict__ ob = outb + region;
         run_phases([&](int, cx<float> v, auto sI) {
             constexpr int r = decltype(sI)::value;
@@ -706,6 +735,7 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
                 if (d < A.band_len) *reinterpret_cast<f32x2*>(ob + ((unsigned)(d >> 1) << 3)) = val;
             }
         });
+#endif
 #if SWF_TRACE
         SWF_TRACE_POINT(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -109,6 +109,57 @@ def forward_chain(P, facet, fo, so, bits, scratch_split=None, round_stores=True)
     return rnd(out).astype(complex)
 
 
+def forward_chain_reordered(P, facet, fo, so, bits, scratch_split=None, round_stores=True):
+    """The r5 review's reordering (its item 3): axis 1 is FINISHED before the strided-axis work starts.  K1's epilogue takes
+    the wave's m-column window of the transformed row, runs the axis-1 half of add_to_subgrid on it (m-point transform x Fn,
+    core.py:255-285) and stores THAT; K2 and K3 then work on data that carries the axis-0 window only, and sum_finish loses
+    its m-point transforms (placement + xM-point inverse + crop).  Same stored intermediates otherwise.  bits as in
+    forward_chain (k1 covers the fused epilogue)."""
+    c = orc.OracleCore(P["W"], P["N"], P["xM"], P["yN"])
+    yB, yN, xA, xM, m = P["yB"], P["yN"], P["xA"], P["xM"], c.xM_yN_size
+    rnd = _c64 if round_stores else (lambda a: a)
+    w = c.facet_window(yB).astype(numpy.float32)
+    wt = {32: numpy.float32, 64: numpy.float64}
+    y = numpy.arange(yB)
+    pos = lambda off: (yN // 2 - yB // 2 + y + off) % yN  # noqa: E731
+    sp = [c._sp(fo[0]), c._sp(fo[1])]
+    k = numpy.arange(m)
+    # K1 + epilogue: both windows, axis-1 inverse transform (row stays in registers), window gather, m-point transform, Fn
+    t = bits["k1"]
+    x = facet.astype(numpy.complex64 if t == 32 else numpy.complex128)
+    x = x * w.astype(wt[t])[None, :] * w.astype(wt[t])[:, None]
+    k1 = numpy.zeros((yB, yN), dtype=x.dtype)
+    k1[:, pos(fo[1])] = x
+    k1 = _centred(k1, 1, t, True)
+    col = c.extract_from_facet(k1, so[1], 1)                      # [yB, m], gather
+    fn = c.Fn.astype(numpy.float32).astype(wt[t])
+    h = _centred(col, 1, t, False)
+    h = rnd(h[:, (k + sp[1]) % m] * fn[None, :])                  # stored: [yB, m] per (facet, wave)
+    # K2: pad + shift + inverse transform along axis 0 on data that carries the axis-0 window only
+    t = bits["k2"]
+    k2 = numpy.zeros((yN, m), dtype=h.dtype)
+    k2[pos(fo[0]), :] = h
+    k2 = _centred(k2, 0, t, True, mid_round=scratch_split)
+    q = rnd(c.extract_from_facet(k2, so[0], 0))                   # [m, m]
+    # K3: axis-0 m-point transform, Fn
+    t = bits["k3"]
+    fn = c.Fn.astype(numpy.float32).astype(wt[t])
+    g = _centred(q, 0, t, False)
+    g = rnd(g[(k + sp[0]) % m, :] * fn[:, None])
+    # sum_finish without its m-point transform: placement along axis 1, xM-point inverse, crop
+    t = bits["sf"]
+    acc = numpy.zeros((m, xM), dtype=numpy.complex64 if t == 32 else numpy.complex128)
+    acc[:, (k + xM // 2 - m // 2 + sp[1]) % xM] = g
+    i = numpy.arange(xA)
+    acc = rnd(_centred(acc, 1, t, True)[:, (xM // 2 - xA // 2 + i + so[1]) % xM])
+    # K5b
+    t = bits["k5"]
+    full = numpy.zeros((xM, xA), dtype=acc.dtype)
+    full[(k + xM // 2 - m // 2 + sp[0]) % xM, :] = acc
+    out = _centred(full, 0, t, True)[(xM // 2 - xA // 2 + i + so[0]) % xM, :]
+    return rnd(out).astype(complex)
+
+
 def reference_chain(P, facet, fo, so):
     """the same facet -> subgrid contribution through the oracle primitives in complex128 (reference order)"""
     c = orc.OracleCore(P["W"], P["N"], P["xM"], P["yN"])
@@ -149,14 +200,29 @@ def budget(P=PROBE, fo=PROBE_FO, so=PROBE_SO, seed=5, split=(32, 64)):
     return rows
 
 
-def chain_error(bits, P=PROBE, fo=PROBE_FO, so=PROBE_SO, seed=5, split=(32, 64)):
+def chain_error(bits, P=PROBE, fo=PROBE_FO, so=PROBE_SO, seed=5, split=(32, 64), chain=None):
     """end-to-end relative RMSE of the emulated chain with the given per-stage arithmetic"""
     rng = numpy.random.default_rng(seed)
     yB = P["yB"]
     facet = _c64(rng.standard_normal((yB, yB)) + 1j * rng.standard_normal((yB, yB)))
-    return rel_rmse(forward_chain(P, facet, fo, so, bits, split), reference_chain(P, facet, fo, so))
+    return rel_rmse((chain or forward_chain)(P, facet, fo, so, bits, split), reference_chain(P, facet, fo, so))
+
+
+def reordered_budget():
+    """the reordered dataflow's figures: all-float32, storage floor, and single-stage float32"""
+    all64 = dict(k1=64, k2=64, k3=64, sf=64, k5=64)
+    all32 = dict(k1=32, k2=32, k3=32, sf=32, k5=32)
+    rows = {"reordered: float32 arithmetic everywhere": chain_error(all32, chain=forward_chain_reordered),
+            "reordered: storage floor (float64 arithmetic, complex64 intermediates + scratch)": chain_error(all64, chain=forward_chain_reordered)}
+    for st in ("k1", "k2", "k3", "sf", "k5"):
+        b = dict(all64)
+        b[st] = 32
+        rows[f"reordered: float32 arithmetic in {st} only"] = chain_error(b, chain=forward_chain_reordered)
+    return rows
 
 
 if __name__ == "__main__":
     for name, v in budget().items():
+        print(f"{v:.3e}  {name}")
+    for name, v in reordered_budget().items():
         print(f"{v:.3e}  {name}")

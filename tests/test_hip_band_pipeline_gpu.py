@@ -605,6 +605,12 @@ for off in (0, 64 * 352, -64 * 352, -64 * 320, 64 * 351):
 b = torch.from_numpy((rng.standard_normal((5, band[1])) + 1j * rng.standard_normal((5, band[1]))).astype(numpy.complex64)).cuda()
 for off in (0, 64 * 352):
     h.update(core.finish_facet_band(b, band, off, 22528).cpu().numpy().tobytes())
+# many rows, other bands and the 16-segment instance (r6)
+xl = torch.from_numpy((rng.standard_normal((700, 22528)) + 1j * rng.standard_normal((700, 22528))).astype(numpy.complex64)).cuda()
+for off, bnd in ((0, band), (64 * 352, band), (-64 * 320, (32001, 2049)), (64 * 352, (0, 32768))):
+    h.update(core.prepare_facet_band(xl, off, bnd, fold_other_axis_window=False).cpu().numpy().tobytes())
+xs = torch.from_numpy((rng.standard_normal((300, 16384)) + 1j * rng.standard_normal((300, 16384))).astype(numpy.complex64)).cuda()
+h.update(core.prepare_facet_band(xs, 0, band).cpu().numpy().tobytes())   # 16 data segments
 print("DIGEST", h.hexdigest())
 """
 
