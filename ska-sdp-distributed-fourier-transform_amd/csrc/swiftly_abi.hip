@@ -569,7 +569,10 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
             // (swiftly_hip_chain_chunk_streams: the caller vouches for the inputs; the chunk streams run on from the chunks
             // of the previous call -- no pipeline drain and no idle event hops between consecutive waves, r5)
             he = hipSuccess;
-            if (!g_chain_chunk_streams) {
+            // (a chained call still forks when the un-chunked path has used THIS workspace since the last fork)
+            void* plain_ws = scratch;
+            const bool plain_pending = h->ws_plain_pending.compare_exchange_strong(plain_ws, nullptr);
+            if (!g_chain_chunk_streams || plain_pending) {
                 he = hipEventRecord(ev[0], st);
                 for (hipStream_t s2 : h->chunk_st)
                     if (he == hipSuccess) he = hipStreamWaitEvent(s2, ev[0], 0);
@@ -636,6 +639,7 @@ int col_transform(swiftly_hip* h, int logn, const ColPassArgs& c, const ColZ& cz
     // Cache (measured: the 160 MB of a K5b wave, K3-5 12.5 -> 11.6 ms per pass); a large one is streamed
     // non-temporally (measured: K2, 1.2 GB per wave, 18.5 ms vs 19.6 ms cacheable).
     const int scratch_nt = scratch_bytes > (size_t(192) << 20) ? 1 : 0;
+    if (!own) h->ws_plain_pending.store(scratch);  // `ws` is written on `st` below: a later chained chunked call has to wait for it
     for (long long c0 = 0; c0 < (long long)W && !rc; c0 += Ws) {
         const int wc = (int)std::min<long long>(Ws, (long long)W - c0);
         // pass A: length n1 over y1 (input index y1*n2 + y2), outer = y2; scratch row k1*n2 + y2

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -94,6 +95,10 @@ struct swiftly_hip {
     // join events are per call: two host threads may drive one handle on different streams)
     hipStream_t chunk_st[2] = {nullptr, nullptr};
     std::mutex chunk_mu;
+    // the caller's four-step workspace was last used by the UN-chunked path (on the caller's stream): the next chunked call
+    // must fork its chunk streams behind that stream even when swiftly_hip_chain_chunk_streams is set (r5 advisor: a trailing
+    // facet group below the chunk threshold, > 32 facets)
+    std::atomic<void*> ws_plain_pending{nullptr};  // that workspace
     // re-laid-out load windows of the forward K1 (swiftly_rowpass.h), built on first use per facet offset
     Win4Cache win4;
 };

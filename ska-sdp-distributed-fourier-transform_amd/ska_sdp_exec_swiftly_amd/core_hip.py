@@ -21,6 +21,7 @@ complex64, complex128 stays complex128, real input is promoted to the
 matching complex type (core.py:581-585).
 """
 import ctypes
+import functools
 
 import numpy
 import scipy.special
@@ -50,8 +51,15 @@ def calculate_pswf(W, yN_size):
 def band_range(N, yN, m, subgrid_offs, align=32):
     """Smallest cyclic range ``(start, length)`` of padded-facet columns that contains the ``m`` window
     (core.py:243-253) of every subgrid offset; ``(0, yN)`` when that is everything (pure numpy, unit-tested)."""
+    return _band_range_cached(int(N), int(yN), int(m), tuple(sorted(set(int(o) for o in subgrid_offs))), int(align))
+
+
+@functools.lru_cache(maxsize=256)
+def _band_range_cached(N, yN, m, subgrid_offs, align):
+    # (memoised, r6: the streaming classes are rebuilt every pass and ask for the same few bands -- 30 us of numpy each,
+    # on the enqueue path of a multi-GPU rank)
     keep = numpy.zeros(yN, dtype=bool)
-    for off in set(int(o) for o in subgrid_offs):
+    for off in subgrid_offs:
         s = off * yN // N
         keep[(yN // 2 - m // 2 + numpy.arange(m) + s) % yN] = True
     if keep.all() or not keep.any():
@@ -255,8 +263,17 @@ class SwiftlyCoreHip:
         torch = _torch()
         return _lib.C64 if ten.dtype == torch.complex64 else _lib.C128
 
+    def _raw_stream(self):
+        """raw handle (integer) of the calling thread's current stream on this core's device.  (``torch.cuda.current_stream``
+        builds a Stream object on every call -- 5 us, ~200 calls per pass of a multi-GPU rank; the private accessor is
+        what torch's own kernel launchers use.)"""
+        fast = getattr(_torch()._C, "_cuda_getCurrentRawStream", None)  # pylint: disable=protected-access
+        if fast is not None:
+            return int(fast(self._device_index))
+        return int(_torch().cuda.current_stream(self._device).cuda_stream)
+
     def _stream(self):
-        return ctypes.c_void_p(_torch().cuda.current_stream(self._device).cuda_stream)
+        return ctypes.c_void_p(self._raw_stream())
 
     def _real_vec(self, vec, cdtype, size):
         """Optional real window (mask) as a device vector of the precision that
@@ -654,9 +671,19 @@ class SwiftlyCoreHip:
         )
         return out
 
-    @staticmethod
-    def _i64(values):
-        return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+    _I64_CACHE = {}
+
+    @classmethod
+    def _i64(cls, values):
+        """ctypes int64 array of ``values`` (memoised by content: the per-wave offset lists repeat every pass; the native
+        side only reads them)"""
+        key = tuple(values)
+        arr = cls._I64_CACHE.get(key)
+        if arr is None:
+            if len(cls._I64_CACHE) >= 8192:
+                cls._I64_CACHE.clear()
+            arr = cls._I64_CACHE[key] = (ctypes.c_int64 * len(key))(*[int(v) for v in key])
+        return arr
 
     def _k2_scratch_bytes(self, F):
         """four-step scratch of K2 for F facets; yN = Q * 2^k also holds the output of the radix-Q pass"""
@@ -672,7 +699,7 @@ class SwiftlyCoreHip:
         pool = self.__dict__.setdefault("_scratch_pool", {})
         # one buffer per HIP stream: calls on one stream are ordered, calls on different streams (other host
         # threads, side streams) must not share a scratch
-        key = (name, torch.cuda.current_stream(self._device).cuda_stream)
+        key = (name, self._raw_stream())
         # + room for the arrival counters of the fused four-step launches (one word per batch item and column tile)
         nbytes = int(nbytes) + self.SCRATCH_TAIL_BYTES
         buf = pool.get(key)

@@ -419,6 +419,20 @@ class DistributedForward:
                                          wave_axis=1)
                     fwd.dtype = self.dtype
                     self._coop[j] = fwd
+        self._announce_wave_order()
+
+    def _announce_wave_order(self):
+        """With whole-wave ownership the waves are packed group by group, inside a group in the order of their owners
+        (pack_group) -- not in the plan's order: tell the planned-wave predictors of the local objects, so that K2 of the
+        next waves runs ahead on the side stream as it does in the single-GPU pass (r6)."""
+        sh = self.sharding
+        if self.wave_axis != 1 or not self._plan or getattr(sh, "wave_rank", None) is None or not getattr(sh, "wave_groups", None):
+            return
+        order = [k for group in sh.wave_groups for k in sorted(group, key=lambda k: sh.wave_rank[k])]
+        if self.local is not None:
+            self.local.set_wave_order(order)
+        for fwd in self._coop.values():
+            fwd.set_wave_order(order)
 
     # -- cooperative facets: K1 on this rank's rows + the band-row exchange ----------------------------------------
     def pack_coop(self, j):

@@ -356,6 +356,48 @@ def test_forward_planned_wave_prefetch_is_bit_identical(order):
     assert relrms(ahead[keys[1]][1], so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))) < 2e-5
 
 
+def test_chained_k2_with_a_trailing_unchunked_facet_group():
+    """(r5 advisor) More than 32 facets: K2 of a wave runs as one four-step per group of 32 facets, and only groups whose
+    intermediate exceeds 256 MiB take the chunk-stream path.  36 facets at yN = 8192, m = 1024: the first group (2 GiB) is
+    chunked, the trailing group of 4 facets (exactly 256 MiB) runs un-chunked on the side stream through slot 0 of the same
+    workspace.  The chained K2 of the next prefetched wave (no fork behind the previous call) must still wait for it: the
+    planned, prefetching pass gives the same BITS as the pass without prefetch."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+
+    P = dict(W=11.0, fov=1.0, N=32768, yB_size=4096, yN_size=8192, xA_size=2048, xM_size=4096)
+    cfg = sw.SwiftlyConfig(backend="hip", **P)
+    facet_cfgs = sw.api.make_full_cover_config(P["N"], P["yB_size"], sw.FacetConfig)[:36]
+    cover = sw.api.make_full_cover_config(P["N"], P["xA_size"], sw.SubgridConfig)
+    plan = [c for c in cover if c.off1 in (2048, 3 * 2048, 5 * 2048, 7 * 2048) and c.off0 in (0, 4 * 2048)]
+    assert len(plan) == 8
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    facets = [torch.view_as_complex(torch.randn((4096, 4096, 2), device="cuda", generator=gen)) for _ in facet_cfgs]
+    waves = {}
+    for c in plan:
+        waves.setdefault(c.off1, []).append(c)
+
+    def run(prefetch):
+        old = sw.api._PREFETCH
+        sw.api._PREFETCH = prefetch
+        try:
+            fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=plan, wave_axis=1)
+            out = [fwd.get_wave(waves[k]).cpu().numpy() for k in sorted(waves)]
+            used = fwd.__dict__.get("_prefetched", "never") != "never"
+        finally:
+            sw.api._PREFETCH = old
+        torch.cuda.synchronize()
+        return out, used
+
+    plain, used0 = run(False)
+    for _ in range(3):  # a race does not lose every time
+        ahead, used1 = run(True)
+        assert not used0 and used1
+        for a, b in zip(plain, ahead):
+            assert numpy.array_equal(a, b)
+
+
 @pytest.mark.parametrize("lru_backward", [1, 2])
 def test_backward_default_axis_with_plan_stages_single_adds(lru_backward):
     """SwiftlyBackward(subgrid_configs=plan) without wave_axis picks the band schedule for complex64 subgrids;

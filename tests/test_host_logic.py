@@ -273,21 +273,44 @@ def test_planned_wave_prediction_follows_the_walk_direction():
 
 def test_mispredicted_prefetch_is_dropped_and_switches_the_prefetch_off():
     """SwiftlyForward._take_prefetched: a prefetched wave that is not the one asked for (and the one asked for is not
-    cached) is a misprediction -- the buffer is dropped; after two of them the predictor stops predicting."""
+    cached) is a misprediction -- the buffer is dropped (parked until its K2 has finished); after two of them IN A ROW the
+    predictor stops predicting, and a caller that follows the plan again for a few requests gets it back (r6)."""
     fwd = object.__new__(api.SwiftlyForward)
-    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (10, 20, 30, 40)]
-    fwd._planned_keys = {10, 20, 30, 40}
+    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (10, 20, 30, 40, 50, 60, 70)]
+    fwd._planned_keys = {10, 20, 30, 40, 50, 60, 70}
     fwd.lru = api.LRUCache(1)
     fwd.__dict__["_prefetched"] = {20: ("Q20", None, None)}
     fwd._take_prefetched(40)                       # asked for 40, 20 was prefetched
     assert not fwd.__dict__["_prefetched"] and fwd.__dict__["_prefetch_missed"] == 1
+    assert fwd.__dict__["_prefetch_parked"] == [("Q20", None, None)]
     assert fwd._predict_next_wave(10) == 20        # one miss: still predicting
     fwd.__dict__["_prefetched"] = {20: ("Q20", None, None), 30: ("Q30", None, None)}
     fwd.lru.set(("b", 30), ("Q30", None))
-    fwd._take_prefetched(30)                       # 30 is cached: not a miss, the other prefetched wave stays
-    assert list(fwd.__dict__["_prefetched"]) == [20] and fwd.__dict__["_prefetch_missed"] == 1
+    fwd._take_prefetched(30)                       # a hit: the other prefetched wave stays, the miss count starts again
+    assert list(fwd.__dict__["_prefetched"]) == [20] and fwd.__dict__["_prefetch_missed"] == 0
     fwd._take_prefetched(40)
+    assert fwd.__dict__["_prefetch_missed"] == 1 and not fwd.__dict__.get("_prefetch_off")
+    fwd.__dict__["_prefetched"] = {20: ("Q20", None, None)}
+    fwd._take_prefetched(50)
     assert fwd.__dict__.get("_prefetch_off") and fwd._predict_next_wave(10) is None
+    # four requests in plan order switch it on again
+    assert [fwd._predict_next_wave(k) for k in (20, 30, 40)] == [None, None, None]
+    assert fwd._predict_next_wave(50) == 60 and not fwd.__dict__["_prefetch_off"]
+
+
+def test_announced_wave_order_and_the_next_pass_of_a_reused_object():
+    """set_wave_order: the predictor follows the order the caller announces (the multi-GPU pass packs its waves group
+    by group); a jump from the last wave of the order back to the first is the next pass of the same walk, not a turn."""
+    fwd = object.__new__(api.SwiftlyForward)
+    fwd._plan = [api.SubgridConfig(0, k, 8) for k in (10, 20, 30, 40)]
+    fwd._planned_keys = {10, 20, 30, 40}
+    fwd.set_wave_order([30, 10, 99, 40, 20, 10])   # 99 is not planned, the second 10 is a repeat
+    assert fwd._wave_order == [30, 10, 40, 20]
+    assert fwd._predict_next_waves(30, 2) == [10, 40]
+    assert fwd._predict_next_waves(10, 2) == [40, 20]
+    assert fwd._predict_next_waves(20, 2) == []
+    assert fwd._predict_next_waves(30, 2) == [10, 40]   # wrapped round: still walking forwards
+    assert fwd._predict_next_waves(10, 1) == [40]
 
 
 def test_planned_wave_prediction_depth():

@@ -31,8 +31,12 @@ for c in sgs:
 waves = list(waves.values())
 
 
+WHOLE = os.environ.get("VR_WHOLE_WAVES") == "1"
+
+
 def one_pass():
-    dfw = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64, rank_world=(rank, world))
+    dfw = DistributedForward(cfg, fcs, data, subgrid_configs=sgs, wave_axis=axis, dtype=torch.complex64, rank_world=(rank, world),
+                             whole_waves=WHOLE)
     t0 = time.perf_counter()
     dfw.prepare_all_facets()
     for j in dfw.sharding.coop:  # cooperative facets: K1 on this rank's rows + (dummy) band-row exchange
@@ -69,4 +73,8 @@ if os.environ.get("VR_PROFILE") == "1":
     pr.enable()
     one_pass()
     pr.disable()
-    pstats.Stats(pr).strip_dirs().sort_stats("tottime").print_stats(28)
+    st = pstats.Stats(pr).strip_dirs()
+    rows = sorted(((v[2], v[3], v[0], k) for k, v in st.stats.items()), reverse=True)  # tottime, cumtime, calls, (file, line, name)
+    print("tottime_us cumtime_us calls function")
+    for tt, ct, nc, k in rows[:45]:
+        print(f"{tt * 1e6:9.0f} {ct * 1e6:9.0f} {nc:6d} {k[0]}:{k[1]}({k[2]})")

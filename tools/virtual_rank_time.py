@@ -37,6 +37,32 @@ def main():
     xA = p["xA_size"]
     res = dict(workload=wl["name"], subgrid_ownership="whole waves" if WHOLE else "round-robin within a wave", worlds={})
     one = bench.separable_facet(torch, sep.facet_vectors(1234, p["yB_size"]), all_fcs[0])
+
+    def single_path_ms():
+        """the pass bench.py --gpus 1 times (SwiftlyForward, planned waves): what a scaling series divides by"""
+        fcs = all_fcs if wl.get("max_facets_per_rank") is None else all_fcs[: wl["max_facets_per_rank"]]
+        axis = sw.api.preferred_wave_axis(cfg, torch.complex64, n_facets=len(fcs))
+        key = (lambda c: c.off1) if axis == 1 else (lambda c: c.off0)
+        wv = {}
+        for c in sgs:
+            wv.setdefault(key(c), []).append(c)
+
+        def one_pass():
+            fwd = sw.SwiftlyForward(cfg, [(f, one) for f in fcs], lru_forward=1, subgrid_configs=sgs, wave_axis=axis)
+            fwd.prepare_all_facets()
+            for w in wv.values():
+                fwd.get_wave(w)
+
+        one_pass()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one_pass()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3 * 1e3
+
+    res["single_path_forward_ms"] = round(single_path_ms(), 2)
+    print(f"{name}: single path (SwiftlyForward) {res['single_path_forward_ms']} ms", flush=True)
     for world in (1, 2, 4, 8):
         cap = wl.get("max_facets_per_rank")
         n_active = len(all_fcs) if cap is None else min(len(all_fcs), cap * world)
@@ -68,6 +94,24 @@ def main():
                     send, inc, outc = dfw.pack_coop(j)
                     sent[0] += 8 * (sum(inc) - inc[rank])
                     dfw.unpack_coop(j, torch.empty(sum(outc), dtype=torch.complex64, device="cuda"))
+                if WHOLE and dfw.sharding.wave_groups:
+                    # bench.py's grouped loop: the waves group by group (distinct owners), one (dummy) exchange per group,
+                    # the finish of group g behind the packing of group g + 1
+                    by_key = {dfw.wave_key(w): w for w in waves}
+                    pend = None
+                    for group in dfw.sharding.wave_groups:
+                        gw = [by_key[k] for k in group if k in by_key]
+                        if not gw:
+                            continue
+                        send, inc, outc = dfw.pack_group(gw)
+                        sent[0] += 8 * (sum(inc) - inc[rank])
+                        recv = send if world == 1 else torch.empty(sum(outc), dtype=torch.complex64, device="cuda")
+                        if pend is not None:
+                            dfw.unpack_group(*pend)
+                        pend = (gw, recv)
+                    if pend is not None:
+                        dfw.unpack_group(*pend)
+                    return
                 for wave in waves:
                     send, inc, outc = dfw.pack_wave(wave)
                     sent[0] += 8 * (sum(inc) - inc[rank])
@@ -123,6 +167,7 @@ def main():
             torch.cuda.empty_cache()
         ent["critical_path_forward_ms"] = max(r["forward_ms"] for r in ent["ranks"].values())
         ent["critical_path_backward_ms"] = max(r["backward_ms"] for r in ent["ranks"].values())
+        ent["speedup_vs_single_path_forward"] = round(res["single_path_forward_ms"] / ent["critical_path_forward_ms"], 2)
         res["worlds"][str(world)] = ent
     if out_path:
         with open(out_path, "w", encoding="utf-8") as fh:
