@@ -315,6 +315,18 @@ def _import_reference():
 
 
 _CPU_CORE = {}
+CPU_BASELINE_PROCS = int(os.environ.get("SWIFTLY_BENCH_CPU_PROCS", "32"))
+
+
+def _cpu_pin(slot, pins):
+    """worker initialiser: pin this process to one CPU of the spread (numpy's pocketfft is single-threaded)"""
+    with slot.get_lock():
+        i = slot.value
+        slot.value += 1
+    try:
+        os.sched_setaffinity(0, {pins[i % len(pins)]})
+    except (AttributeError, OSError):  # pragma: no cover
+        pass
 
 
 def _cpu_warm(args):
@@ -391,19 +403,29 @@ def cpu_baseline(p, F, S, C):
     import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
 
-    cores = os.cpu_count() or 1
+    # (r6, method 5) at most CPU_BASELINE_PROCS worker processes, each pinned to its own CPU, spread evenly over the CPUs
+    # this process may use.  Methods 1-4 ran one process per CPU (256 on the GPU box): the repeats of one run spread
+    # 1.6 - 2x, the value halved between rounds (24 / 189 / 192 / 145 / 90 contributions/s) and the leg took 84 s of the
+    # driver's 130 -- 256 numpy processes contend for memory bandwidth and last-level cache in a different way every time.
+    # `cores` in the line is the number of processes (= threads) actually used.
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = list(range(os.cpu_count() or 1))
+    cores = max(1, min(CPU_BASELINE_PROCS, len(avail)))
+    pins = [avail[(i * len(avail)) // cores] for i in range(cores)]
     repeats = 3
     t0 = time.perf_counter()
     per_repeat = []
-    # spawn: the parent holds an initialised HIP runtime, which must not be forked
-    with ProcessPoolExecutor(cores, mp_context=multiprocessing.get_context("spawn")) as pool:
+    ctx = multiprocessing.get_context("spawn")  # the parent holds an initialised HIP runtime, which must not be forked
+    slot = ctx.Value("i", 0)
+    with ProcessPoolExecutor(cores, mp_context=ctx, initializer=_cpu_pin, initargs=(slot, pins)) as pool:
         # (r5) untimed warm-up: in r4 the first repeat ran while the workers were still being spawned -- staggered, i.e.
         # under less contention -- and came out 1.7-2.2x faster than the others (247 / 145 / 111 contributions/s)
         list(pool.map(_cpu_warm, [(p, F, i) for i in range(cores)]))
-        # ... and one untimed repeat of the sample itself: with the workers merely started, the first timed repeat still came
-        # out 1.1 - 1.9x faster than the following ones (187 / 97 / 92): the host reaches its sustained clocks only under load
+        # ... and one untimed repeat of the sample itself: the host reaches its sustained clocks only under load
         list(pool.map(_cpu_sample, [(p, F, 500 + i) for i in range(cores)]))
-        for rep in range(repeats):  # every repeat keeps all cores busy at once; the pool (and each worker's core) is reused
+        for rep in range(repeats):  # every repeat keeps all workers busy at once; the pool (and each worker's core) is reused
             per_repeat.append(list(pool.map(_cpu_sample, [(p, F, 1000 + rep * cores + i) for i in range(cores)])))
     wall = time.perf_counter() - t0
     m = p["xM_size"] * p["yN_size"] // p["N"]
@@ -422,7 +444,7 @@ def cpu_baseline(p, F, S, C):
         if kind == "reference" else "oracle port of the reference's numpy path"
     )
     order = sorted(range(repeats), key=lambda i: values[i])
-    mid = order[repeats // 2]  # median of the repeats (256 concurrent numpy processes: single samples spread 2.7x, r3)
+    mid = order[repeats // 2]  # median of the repeats
     total, s1, s2, s3 = splits[mid]
     return dict(
         value=values[mid],
@@ -430,8 +452,10 @@ def cpu_baseline(p, F, S, C):
         cores=cores,
         kind=kind,
         samples=[round(v, 1) for v in values],
+        spread=round(max(values) / min(values), 3),
+        host_cpus=len(avail),
         sample=(
-            f"{what}, complex128, {cores} processes concurrently, each: K1 on a {p['yB_size']}x{ncol} "
+            f"{what}, complex128, {cores} processes concurrently (each pinned to its own CPU, of {len(avail)} CPUs), each: K1 on a {p['yB_size']}x{ncol} "
             f"column slab of one facet, K2 on {nrow} of {m} rows of one (facet, column), K3-K5 for one subgrid "
             f"with {F} contributions; per-unit times averaged over processes and extrapolated linearly to {F} facets "
             f"x {C} columns x {S} subgrids spread over {cores} cores "
@@ -439,21 +463,23 @@ def cpu_baseline(p, F, S, C):
             f"({', '.join(f'{v:.0f}' for v in values)} contributions/s); wall time of all repeats {wall:.1f} s"
         ),
         extrapolated_seconds=total,
-        # (r4 advice) what the sample was, so that values stay comparable across rounds: method 4 (r5) = method 2 + an
+        # (r4 advice) what the sample was, so that values stay comparable across rounds: method 5 (r6) = method 4 on at most 32
+        # pinned processes; method 4 (r5) = method 2 + an
         # untimed warm-up task per worker + one untimed repeat of the sample; method 2 (r4) = slabs of 2e6 / 4e6 elements and the median of three repeats;
         # method 1 (r1-r3) = 4e6 / 8e6 elements, one repeat
-        method=dict(version=4, warmup="per worker: process start + PSWF tables + first padded-length transform, then ONE "
+        method=dict(version=5, processes="min(32, CPUs), one per CPU, pinned, spread evenly over the CPUs of the host "
+                                         "(methods 1-4: one process per CPU, 256 on the GPU box)", warmup="per worker: process start + PSWF tables + first padded-length transform, then ONE "
                                       "untimed repeat of the whole sample under full contention, before the timed repeats", k1_slab_elements=int(p["yB_size"]) * int(ncol), k2_slab_elements=int(nrow) * int(p["yB_size"]),
                     k1_slab_columns=int(ncol), k2_slab_rows=int(nrow), repeats=repeats, statistic="median"),
     )
 
 
 # --------------------------------------------------------------------------- measured traffic (PMC passes)
-PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc_kernels.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r6_pmc_kernels.json")
 
 
 def _pmc_record(workload):
-    """Per-kernel counter summary of THIS round's build for the workload (profiles/r5_pmc_kernels.json, written by
+    """Per-kernel counter summary of THIS round's build for the workload (profiles/r6_pmc_kernels.json, written by
     tools/pmc_kernels.py from a rocprofv3 kernel trace and separate --pmc FETCH_SIZE / WRITE_SIZE passes), or None."""
     try:
         with open(PMC_FILE, encoding="utf-8") as fh:
@@ -525,7 +551,7 @@ def kernel_table(workload, F, C, parts):
         return None
     tot_us = sum(r["us_per_pass"] for r in rows)
     return dict(
-        source="profiles/r5_pmc_kernels.json: " + rec.get("note", ""),
+        source="profiles/r6_pmc_kernels.json: " + rec.get("note", ""),
         rows=rows,
         sum_us_per_pass=round(tot_us, 1),
         counter_bytes_per_pass=int(sum(r["counter_bytes_per_pass"] for r in rows)),
@@ -537,7 +563,7 @@ def backward_kernel_table(workload, F, C, parts):
     """The same table for the subgrid -> facet direction (band schedule): every stage is the mirror
     of a forward stage and moves the mirrored bytes, so the algorithmic figures are the forward model's
     (B8 finish_facet <-> K1, B5 gather-sum four-step <-> K2, B4 m-point column pass <-> K3, B2 split_prepare_facets <-> K4,
-    B1 prepare_subgrid axis 0 <-> K5).  Counter bytes and durations: profiles/r5_pmc_kernels.json["<workload>:backward"]."""
+    B1 prepare_subgrid axis 0 <-> K5).  Counter bytes and durations: profiles/r6_pmc_kernels.json["<workload>:backward"]."""
     rec = _pmc_record(workload + ":backward")
     if not rec:
         return None
@@ -568,7 +594,7 @@ def backward_kernel_table(workload, F, C, parts):
     tot_us = sum(r["us_per_pass"] for r in rows)
     running = traffic_build_state(workload + ":backward")
     return dict(
-        source="profiles/r5_pmc_kernels.json: " + rec.get("note", ""),
+        source="profiles/r6_pmc_kernels.json: " + rec.get("note", ""),
         build_state=running["state"],
         rows=rows,
         sum_us_per_pass=round(tot_us, 1),
@@ -577,11 +603,13 @@ def backward_kernel_table(workload, F, C, parts):
     )
 
 
-def quick_forward(torch, sw, sw_api, name, passes=3):
+def quick_forward(torch, sw, sw_api, name, passes=5, warmups=2):
     """Forward pass of another BASELINE configuration beside the headline line (`other_workloads`, r4 review): the same
     objects as the default workload's timed region -- fresh planned SwiftlyForward per pass, K1 of every facet, every
-    wave -- `passes` timed passes after one warm-up, parity of the subgrids those objects produce against the oracle.
-    Never part of `value`."""
+    wave -- `passes` passes, each timed on its own, after `warmups` untimed ones (r6: the MEDIAN is reported with every
+    pass in `step_ms_each`; r5 timed three passes behind one warm-up as a block and one configuration ranged 151 - 203 ms
+    between boxes -- first passes of a workload pay the caching allocator's block splitting and the first-use tables),
+    parity of the subgrids those objects produce against the oracle.  Never part of `value`."""
     from oracle import separable as sep  # data recipe shared with the checker
 
     wl = WORKLOADS[name]
@@ -612,13 +640,14 @@ def quick_forward(torch, sw, sw_api, name, passes=3):
                     if i in picks:
                         keep[i] = res[k].cpu().numpy()
 
-    one_pass()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(passes):
+    warm_each, each = [], []
+    for rep in range(warmups + passes):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         one_pass()
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / passes
+        torch.cuda.synchronize()
+        (warm_each if rep < warmups else each).append(1e3 * (time.perf_counter() - t0))
+    ms = sorted(each)[len(each) // 2]
     kept = {}
     one_pass(kept)
     torch.cuda.synchronize()
@@ -658,7 +687,8 @@ def quick_forward(torch, sw, sw_api, name, passes=3):
     return dict(
         roundtrip=roundtrip,
         workload=wl["name"], facets=F, subgrids=S, subgrid_columns=C, wave_axis=wave_axis, passes=passes,
-        ms_per_step=round(ms, 3), contributions_per_s=round(F * S / (ms * 1e-3), 1),
+        ms_per_step=round(ms, 3), statistic="median", step_ms_each=[round(t, 2) for t in each],
+        warmup_ms=[round(t, 2) for t in warm_each], contributions_per_s=round(F * S / (ms * 1e-3), 1),
         hbm_algorithmic_frac_of_peak=round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         parity={k: par[k] for k in ("rel_rmse", "subgrids", "tol_rel_rmse", "ok")},
     )
@@ -704,6 +734,8 @@ def main():
                          "created and the pass runs through DistributedForward with the REAL all_to_all_single calls (split "
                          "sizes of one rank, the real send / receive buffers, RCCL's stream against the compute stream); "
                          "the line says so in `config.parallelism` and is not a scaling measurement")
+    ap.add_argument("--strict-others", action="store_true",
+                    help="exit non-zero when one of the secondary workloads of the default run errors or fails its parity")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short forward runs of BASELINE configs 2, 3 and 5 (`other_workloads`) that follow the default "
                          "workload's measurement")
@@ -1239,11 +1271,32 @@ def main():
         roundtrip=roundtrip,
     )
     if line["roofline"] is not None:
-        # the whole pass beside its dominant kernel (r4 review: `roofline` alone shows the most flattering stage)
-        line["roofline"]["whole_pass"] = dict(
-            frac=line["hbm_algorithmic_frac_of_peak"], achieved=line["hbm_algorithmic_gbs"], ms_per_step=line["ms_per_step"],
-            sustained_frac=(line["kernels"] or {}).get("frac_sustained_whole_pass"),
-            what="algorithmic bytes of ALL stages / ms_per_step; sustained = counter bytes / sum of the kernels' own durations",
+        # (r5 review) the object LEADS with the whole pass -- all stages' algorithmic bytes over the timed step, and what
+        # the counters say the pass moved over the kernels' own durations -- and carries the dominant kernel (K1, 52 % of
+        # the algorithmic bytes) inside: K1's own `frac` credits 3.8 GB per launch of band-pruned output it never writes
+        # (`pruned_bytes`), so it is not the state of the pass.
+        k1r = line["roofline"]
+        ktab = line["kernels"] or {}
+        k1r["frac_algorithmic"] = k1r.get("frac")
+        k1r["frac_sustained"] = k1r.pop("sustained_frac", None)
+        if k1r.get("traffic") and k1r.get("algorithmic_bytes_per_launch"):
+            k1r["pruned_bytes"] = int(k1r["algorithmic_bytes_per_launch"] - k1r["traffic"])
+        line["roofline"] = dict(
+            scope="whole forward pass (all stages); the dominant kernel is inside",
+            bound="hbm",
+            achieved=line["hbm_algorithmic_gbs"],
+            peak=HBM_PEAK_GBS,
+            unit="GB/s",
+            frac=line["hbm_algorithmic_frac_of_peak"],
+            sustained_frac=ktab.get("frac_sustained_whole_pass"),
+            traffic=ktab.get("counter_bytes_per_pass"),
+            algorithmic_bytes=total_bytes,
+            ms_per_step=line["ms_per_step"],
+            what="achieved = algorithmic bytes of ALL stages (SURVEY section 8d) / ms_per_step; traffic = FETCH_SIZE x 2 + "
+                 "WRITE_SIZE of every kernel of a pass (committed counter summary of this build); sustained_frac = traffic / "
+                 "sum of the kernels' own durations / peak",
+            traffic_build=k1r.get("traffic_build"),
+            dominant_kernel=k1r,
         )
     if len(facet_cfgs) < len(all_facet_cfgs):
         line["scaling"] = "weak (a rank holds at most %d facets: the facet subset grows with the ranks)" % cap
@@ -1258,6 +1311,8 @@ def main():
                 line["other_workloads"][other] = quick_forward(torch, sw, sw_api, other)
             except Exception as err:  # pylint: disable=broad-except
                 line["other_workloads"][other] = dict(error=f"{type(err).__name__}: {err}")
+        line["other_workloads_ok"] = all(not r.get("error") and r.get("parity", {}).get("ok", False)
+                                         for r in line["other_workloads"].values())
     if world > 1 or args.rccl_dry:
         torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
@@ -1271,9 +1326,13 @@ def main():
         print(json.dumps(line), flush=True)
     if parity is not None and not parity["ok"]:
         raise SystemExit(f"bench.py: PARITY FAILURE rel_rmse={parity['rel_rmse']:.3e} >= {parity['tol_rel_rmse']}")
-    for other, rec in (line.get("other_workloads") or {}).items():
-        if rec.get("error") or not rec.get("parity", {}).get("ok", False):
-            raise SystemExit(f"bench.py: other_workloads[{other}] failed: {rec.get('error') or rec['parity']}")
+    # (r5 advisor) the secondary workloads report their failures INSIDE the line (`other_workloads[..].error` / `.parity.ok`,
+    # `other_workloads_ok`); the exit status of the default run belongs to the headline measurement.  --strict-others turns
+    # them into a failure again (the builder's own sessions).
+    if args.strict_others:
+        for other, rec in (line.get("other_workloads") or {}).items():
+            if rec.get("error") or not rec.get("parity", {}).get("ok", False):
+                raise SystemExit(f"bench.py: other_workloads[{other}] failed: {rec.get('error') or rec['parity']}")
     bpar = (backward or {}).get("parity") or (roundtrip or {}).get("backward_parity")
     if bpar is not None and not bpar["ok"]:
         raise SystemExit(f"bench.py: BACKWARD PARITY FAILURE rel_rmse={bpar['rel_rmse']:.3e} >= {bpar['tol_rel_rmse']}")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel HBM traffic of the forward pass (three rocprofv3 runs of the same command; counters in their own runs):
-#   tools/gpu_pmc.sh OUTDIR [workload] [forward|backward]   ->  OUTDIR/pmc_kernels.json (merge into profiles/r5_pmc_kernels.json;
+#   tools/gpu_pmc.sh OUTDIR [workload] [forward|backward]   ->  OUTDIR/pmc_kernels.json (merge into profiles/r6_pmc_kernels.json;
 #   carries the build identity: source hash, .so hash, git commit); `backward` traces tools/run_backward.py (band schedule)
 out=$1; wl=${2:-64k-sparse}; dir=${3:-forward}
 mkdir -p "$out"
@@ -12,7 +12,7 @@ here=$(pwd)
 export SWIFTLY_PREFETCH=0 SWIFTLY_K2_CHUNK=0
 cmd="python $here/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-backward"
 [ "$dir" = backward ] && cmd="python $here/tools/run_backward.py $wl 2"
-[ -f "$here/profiles/r5_pmc_kernels.json" ] && cp "$here/profiles/r5_pmc_kernels.json" "$out/pmc_kernels.json"
+[ -f "$here/profiles/r6_pmc_kernels.json" ] && cp "$here/profiles/r6_pmc_kernels.json" "$out/pmc_kernels.json"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$here/$out/kt" -o kt -- $cmd > "$here/$out/kt.log" 2>&1 )
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$here/$out/pf" -o pf -- $cmd > "$here/$out/pf.log" 2>&1 )
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$here/$out/pw" -o pw -- $cmd > "$here/$out/pw.log" 2>&1 )

@@ -15,7 +15,7 @@
 #   trace[:WORKLOAD]     rocprofv3 --kernel-trace of a 2-step forward bench -> kernel_stats_WORKLOAD.txt, timeline_WORKLOAD.csv,
 #                        idle-gap accounting (tools/trace_timeline.py)
 #   pmc:forward|backward per-kernel FETCH_SIZE / WRITE_SIZE + durations of this build (tools/gpu_pmc.sh) merged into
-#                        pmc_kernels.json (copy it to profiles/r5_pmc_kernels.json)
+#                        pmc_kernels.json (copy it to profiles/r6_pmc_kernels.json)
 #   others               bench lines of the other workloads (8k 12k 24k 32k-8x8 64k-sparse-4x4 128k 128k-8x8)
 #   f64                  bench with --column-precision 64                  -> bench_64k_sparse_f64.json
 #   vranks               tools/virtual_rank_time.py in both ownership modes
@@ -71,7 +71,7 @@ for step in "$@"; do
       rm -rf "$out/kt" ;;
     pmc)
       tools/gpu_pmc.sh "$out/pmc" 64k-sparse "${arg:-forward}" > "$out/pmc_${arg:-forward}.log" 2>&1
-      cp "$out/pmc/pmc_kernels.json" "$out/pmc_kernels.json"; cp "$out/pmc/pmc_kernels.json" profiles/r5_pmc_kernels.json
+      cp "$out/pmc/pmc_kernels.json" "$out/pmc_kernels.json"; cp "$out/pmc/pmc_kernels.json" profiles/r6_pmc_kernels.json
       cp "$out/pmc/kernel_stats_${arg:-forward}.txt" "$out/kernel_stats_serial_${arg:-forward}.txt"
       cat "$out/pmc/pmc_kernels_${arg:-forward}.txt" ;;
     others)

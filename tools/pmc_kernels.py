@@ -8,7 +8,7 @@
   pmc_write.db    : rocprofv3 --kernel-trace --pmc WRITE_SIZE     -> bytes written per launch
 
 (FETCH_SIZE / WRITE_SIZE need separate passes on gfx950; FETCH_SIZE tallies 64 B per 128 B request and is doubled;
-MI355X_MICROARCH.md, section HBM.)  Writes profiles/r5_pmc_kernels.json, which bench.py reads for `roofline.traffic`,
+MI355X_MICROARCH.md, section HBM.)  Writes profiles/r6_pmc_kernels.json, which bench.py reads for `roofline.traffic`,
 `roofline.sustained` and the `kernels` table of the JSON line.  A sixth argument `backward` selects the stage table of
 the subgrid -> facet direction (trace of tools/run_backward.py; key "<workload>:backward", `backward.kernels`)."""
 import collections
@@ -81,7 +81,7 @@ def per_kernel(path, counter=None):
 def main():
     global _ACTIVE  # pylint: disable=global-statement
     kt, pf, pw = sys.argv[1:4]
-    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r5_pmc_kernels.json")
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r6_pmc_kernels.json")
     workload = sys.argv[5] if len(sys.argv) > 5 else "64k-sparse"
     direction = sys.argv[6] if len(sys.argv) > 6 else "forward"
     _ACTIVE = STAGES_BACKWARD if direction == "backward" else STAGES
