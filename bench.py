@@ -640,14 +640,14 @@ def quick_forward(torch, sw, sw_api, name, passes=5, warmups=2):
                     if i in picks:
                         keep[i] = res[k].cpu().numpy()
 
-    warm_each, each = [], []
+    warm_each, fwd_each = [], []
     for rep in range(warmups + passes):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         one_pass()
         torch.cuda.synchronize()
-        (warm_each if rep < warmups else each).append(1e3 * (time.perf_counter() - t0))
-    ms = sorted(each)[len(each) // 2]
+        (warm_each if rep < warmups else fwd_each).append(1e3 * (time.perf_counter() - t0))
+    ms = sorted(fwd_each)[len(fwd_each) // 2]
     kept = {}
     one_pass(kept)
     torch.cuda.synchronize()
@@ -687,7 +687,7 @@ def quick_forward(torch, sw, sw_api, name, passes=5, warmups=2):
     return dict(
         roundtrip=roundtrip,
         workload=wl["name"], facets=F, subgrids=S, subgrid_columns=C, wave_axis=wave_axis, passes=passes,
-        ms_per_step=round(ms, 3), statistic="median", step_ms_each=[round(t, 2) for t in each],
+        ms_per_step=round(ms, 3), statistic="median", step_ms_each=[round(t, 2) for t in fwd_each],
         warmup_ms=[round(t, 2) for t in warm_each], contributions_per_s=round(F * S / (ms * 1e-3), 1),
         hbm_algorithmic_frac_of_peak=round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         parity={k: par[k] for k in ("rel_rmse", "subgrids", "tol_rel_rmse", "ok")},
