@@ -126,13 +126,23 @@ static int win4_enabled() {  // SWIFTLY_K1_WIN4: 0 = the plain window loads, 1 =
 }
 const float* Win4Cache::get(const float* win, int c, int len, int ns, int n, int seglen, hipStream_t s) {
     std::lock_guard<std::mutex> lock(mu);
-    for (const Entry& e : items)
-        if (e.win == win && e.c == c && e.len == len && e.ns == ns) {
-            if (e.built_on != s && hipStreamWaitEvent(s, e.ready, 0) != hipSuccess) return nullptr;
+    for (Entry& e : items)
+        if (e.win == win && e.c == c && e.len == len && e.ns == ns && e.n == n && e.seglen == seglen) {
+            // (r5 advisor) a launch on another stream than the one the table was built on waits for the build -- until the
+            // build has been seen complete once; after that the table is a constant like the twiddle tables
+            if (!e.complete && e.built_on != s) {
+                const hipError_t q = hipEventQuery(e.ready);
+                if (q == hipSuccess) {
+                    e.complete = true;
+                } else {
+                    (void)hipGetLastError();  // hipErrorNotReady must not be mistaken for a failed launch later
+                    if (hipStreamWaitEvent(s, e.ready, 0) != hipSuccess) return nullptr;
+                }
+            }
             return e.tab;
         }
     if (items.size() >= kMaxEntries) return nullptr;
-    Entry e{win, c, len, ns, nullptr, nullptr, s};
+    Entry e{win, c, len, ns, n, seglen, nullptr, nullptr, s, false};
     const int count = (ns >> 1) * (seglen >> 1);
     if (hipMalloc(&e.tab, (size_t)count * 16) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess) {

@@ -778,10 +778,11 @@ int launch_row_pass_split(const RowPassArgs& a, const cx<float>* tw14, const cx<
 struct Win4Cache {
     struct Entry {
         const float* win;
-        int c, len, ns;
+        int c, len, ns, n, seglen;
         float* tab;
         hipEvent_t ready;
         hipStream_t built_on;
+        bool complete;  // the build kernel has finished (seen by hipEventQuery): later launches on other streams need no wait
     };
     std::mutex mu;
     std::vector<Entry> items;
