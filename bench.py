@@ -56,6 +56,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PARITY_TOL = 1.5e-5
 BACKWARD_PARITY_TOL = 3.5e-5
 HIGH_PRECISION_PARITY_TOL = 5e-6
+# forward relRMSE bound of the axis-1-first pipeline (float32 arithmetic, SwiftlyConfig(axis1_first=True); model: 2.1e-6)
+AXIS1_FIRST_PARITY_TOL = 4e-6
 HIGH_PRECISION_BACKWARD_PARITY_TOL = 1e-5
 
 WORKLOADS = {
@@ -722,6 +724,9 @@ def main():
                     help="multi-GPU: 'group' (default) = every wave's subgrids are finished by ONE rank and the waves are "
                          "exchanged in groups of n_gpus waves with distinct owners (one balanced all-to-all per group); "
                          "'wave' = the subgrids of every wave dealt out round-robin, one all-to-all per wave")
+    ap.add_argument("--axis1-first", action="store_true",
+                    help="time the axis-1-first forward pipeline (SwiftlyConfig(axis1_first=True): the contiguous axis is "
+                         "finished before the strided-axis transforms; float32 arithmetic at ~5x smaller error)")
     ap.add_argument("--column-precision", type=int, default=32, choices=[32, 64],
                     help="arithmetic of the column passes K2 / K3 (complex64 data): 32 = float32 (default, the timed "
                          "configuration of every round), 64 = float64 butterflies (3.7x smaller error, 1.5x the time)")
@@ -789,7 +794,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     p = wl["params"]
-    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, **p)
+    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, axis1_first=args.axis1_first, **p)
     all_facet_cfgs = sw.make_full_facet_cover(cfg)
     # a rank holds at most `max_facets_per_rank` facets (HBM capacity): with too few ranks only the first cap * world
     # facets of the cover take part -- a stated subset; contributions are counted for those only
@@ -942,7 +947,39 @@ def main():
             torch.distributed.all_gather_object(gathered, kept)
             kept = {k: v for d in gathered for k, v in d.items()}
         if rank == 0:
-            parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept, tol=wl.get("parity_tol"))
+            parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept,
+                                     tol=AXIS1_FIRST_PARITY_TOL if args.axis1_first else wl.get("parity_tol"))
+
+    # (r6) the axis-1-first pipeline beside the timed default order: same objects, same facets, float32 arithmetic -- the
+    # contiguous axis finished (m-point transform x Fn per wave window) BEFORE K2 / K3, which then see ONE facet window
+    accurate = None
+    if single and picks and args.column_precision == 32 and not args.axis1_first and rank == 0:
+        cfg.core.axis1_first = True
+        try:
+            one_pass()
+            fence()
+            each = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                one_pass()
+                fence()
+                each.append(1e3 * (time.perf_counter() - t0))
+            kept_a = {}
+            one_pass(keep=kept_a)
+            fence()
+            a_par = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept_a, tol=AXIS1_FIRST_PARITY_TOL)
+            accurate = dict(
+                mode="axis1_first", ms_per_step=round(sorted(each)[1], 3), each_ms=[round(t, 2) for t in each],
+                what="SwiftlyConfig(axis1_first=True): per wave, the rows of the K1 output go through the contiguous-axis half "
+                     "of add_to_subgrid (window gather, m-point transform, Fn; swiftly_hip_finish_axis1_rows) before K2; K2 / "
+                     "K3 unchanged, sum_finish_facets without its m-point transforms; float32 arithmetic throughout; not "
+                     "part of `value`",
+                parity={k: a_par[k] for k in ("rel_rmse", "rel_rmse_each", "max_abs_over_rms", "tol_rel_rmse", "ok")},
+            )
+        except NotImplementedError as err:
+            accurate = dict(mode="axis1_first", error=str(err))
+        finally:
+            cfg.core.axis1_first = False
 
     # the float64-arithmetic column passes (column_precision = 64) beside the timed float32 configuration: same objects,
     # same facets, three passes + the same parity check, outside the timed region (1 GPU, default precision only)
@@ -1246,7 +1283,7 @@ def main():
         higher_is_better=True,
         scaling="strong",
         vs_baseline=None,
-        dtype="complex64 (f32 arithmetic)" if args.column_precision == 32 else "complex64 (f64 arithmetic in the column passes K2/K3, f32 elsewhere)",
+        dtype="complex64 (f32 arithmetic, axis-1-first order)" if args.axis1_first else "complex64 (f32 arithmetic)" if args.column_precision == 32 else "complex64 (f64 arithmetic in the column passes K2/K3, f32 elsewhere)",
         data="synthetic",
         config=dict(
             workload=wl["name"], facets=F, facets_total=len(all_facet_cfgs), subgrids=S, subgrid_columns=C,
@@ -1266,6 +1303,7 @@ def main():
         roofline=roofline,
         kernels=kernel_table(args.workload, F, C, parts) if world == 1 else None,
         parity=parity,
+        accurate=accurate,
         high_precision=high_precision,
         backward=backward,
         roundtrip=roundtrip,

@@ -403,6 +403,33 @@ int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, in
                                   const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
                                   void* tmp_work, void* out, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* AXIS-1-FIRST forward pipeline (r6; opt-in: the accuracy mode that replaces float64 column passes).  The transforms of
+ * the two axes commute (api_helper.py:81-99, 200-210), so the contiguous-axis half of add_to_subgrid (core.py:255-285:
+ * m-point transform x Fn, the step that takes the axis-1 facet window out again) can run on the K1 output BEFORE the
+ * strided-axis transforms K2 / K3, which then work on data that carries ONE facet window instead of two: their float32
+ * rounding reaches the subgrid an order of magnitude weaker.
+ *
+ * finish_axis1_rows: for every facet f and row r of its K1 band buffer (bands + f*band_facet_stride, [rows, band columns],
+ *   parity-split) and the wave `wave_off1` (s = wave_off1 * yN / N):
+ *       x[(i + s) mod m] = P_f[r, (yN/2 - m/2 + i + s) mod yN]            extract_from_facet(axis 1), core.py:243-253
+ *       Z[k] = Fn[k] * cfft_m(x)[(k + s'1_f) mod m]                        add_to_subgrid(axis 1) without its placement
+ *   out + f*out_facet_stride = [rows, m] in the parity-split layout of a band that is exactly the wave's window
+ *   (band_start' = (yN/2 - m/2 + s) mod yN, band_len' = m; logical column i holds Z[(i + s) mod m]): pass it to
+ *   prepare_facet_columns / wave_facet_side as `bands` with that band, and the contributions come out with Z along their
+ *   contiguous axis.  facet_off1s: host array.  yN_size 16384 .. 65536, m 128 .. 1024, complex64.
+ * wave_subgrid_side_placed: wave_subgrid_side for blocks produced that way -- sum_finish_facets places and sums the rows
+ *   without its m-point transforms (xM <= 2048). */
+int swiftly_hip_finish_axis1_rows(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
+                                  int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off1s,
+                                  int64_t band_start, int64_t band_len, int64_t wave_off1, void* out,
+                                  int64_t out_row_stride, int64_t out_facet_stride, void* stream);
+int swiftly_hip_wave_subgrid_side_placed(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
+                                         int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
+                                         int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s,
+                                         int64_t subgrid_size, const void* mask0, int64_t mask0_bs, const void* mask1,
+                                         int64_t mask1_bs, void* tmp_work, void* out, void* scratch, int64_t scratch_bytes,
+                                         void* stream);
+
 /* Backward subgrid side for all facets at once (mirror of sum_finish_facets): in[b] = [xM, subgrid_size] =
  * prepare_subgrid of subgrid b along axis 0 ONLY (core.py:328-368); out[f][b] = [m, m] contiguous = the contribution
  * of subgrid b to facet f, i.e. api_helper.prepare_and_split_subgrid (api_helper.py:115-139): prepare_subgrid along

@@ -45,6 +45,23 @@ static int init_one_s() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sum_finish_facets_lds<LOGM, LOGX>()));
 }
 
+template <int LOGM>
+static int launch_axis1(const Axis1RowsArgs& a, int nfacets, hipStream_t s) {
+    using GM = typename Axis1Geo<LOGM>::GM;
+    dim3 grid((unsigned)((a.nrows + GM::RB - 1) / GM::RB), (unsigned)nfacets);
+    hipLaunchKernelGGL((axis1_rows_kernel<LOGM>), grid, dim3(kAxis1Threads), Axis1Geo<LOGM>::LDS_BYTES, s, a);
+    return (int)hipGetLastError();
+}
+int launch_axis1_rows(int logm, const Axis1RowsArgs& a, int nfacets, hipStream_t s) {
+    switch (logm) {
+        case 7: return launch_axis1<7>(a, nfacets, s);
+        case 8: return launch_axis1<8>(a, nfacets, s);
+        case 9: return launch_axis1<9>(a, nfacets, s);
+        case 10: return launch_axis1<10>(a, nfacets, s);
+        default: return -1;
+    }
+}
+
 #define SF_PAIRS(X) X(7, 8) X(7, 10) X(8, 9) X(8, 10) X(9, 10) X(9, 11) X(10, 11) X(10, 12)
 
 int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s) {

@@ -428,11 +428,11 @@ int swiftly_hip_transform_contributions(swiftly_hip_t* h, int dtype, const void*
                                         out_facet_stride, out_sub_stride, nullptr, nullptr, stream);
 }
 
-int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t nfacets, int64_t in_facet_stride,
+static int sum_finish_facets_impl(swiftly_hip_t* h, int dtype, const void* in, int64_t nfacets, int64_t in_facet_stride,
                                   int64_t in_sub_stride, int64_t in_row_stride, const int64_t* facet_off0s,
                                   const int64_t* facet_off1s, void* out, int64_t out_sub_stride, int64_t out_row_stride,
                                   const int64_t* subgrid_off1s, int64_t subgrid_size, const void* mask,
-                                  int64_t mask_batch_stride, int64_t nsub, void* stream) {
+                                  int64_t mask_batch_stride, int64_t nsub, int placed, void* stream) {
     if (!h || !in || !out || !facet_off0s || !facet_off1s || !subgrid_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     DeviceGuard device_guard_(h->device);
     CHECK_SUBGRID_SIZE();
@@ -453,6 +453,10 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
     a.xA = xA;
     fill_facet_groups(a, h, nfacets, facet_off0s, facet_off1s);
     fill_group_rounds(a, h);
+    a.placed = placed ? 1 : 0;
+    if (placed && h->log_xM >= 12)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "axis-1-first pipeline: rows of %lld points run the wave-parallel sum_finish form, "
+                    "which has no placed mode", (long long)h->xM);
     a.fn = h->fn_f;
     a.mask_bs = mask ? mask_batch_stride : 0;
     a.tw_m = twiddles<float>(h, h->log_m);
@@ -471,6 +475,58 @@ int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, i
         int e = launch_sum_finish_facets(h->log_m, h->log_xM, a, nb, (hipStream_t)stream);
         if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
+    return 0;
+}
+
+int swiftly_hip_sum_finish_facets(swiftly_hip_t* h, int dtype, const void* in, int64_t nfacets, int64_t in_facet_stride,
+                                  int64_t in_sub_stride, int64_t in_row_stride, const int64_t* facet_off0s,
+                                  const int64_t* facet_off1s, void* out, int64_t out_sub_stride, int64_t out_row_stride,
+                                  const int64_t* subgrid_off1s, int64_t subgrid_size, const void* mask,
+                                  int64_t mask_batch_stride, int64_t nsub, void* stream) {
+    return sum_finish_facets_impl(h, dtype, in, nfacets, in_facet_stride, in_sub_stride, in_row_stride, facet_off0s, facet_off1s,
+                                  out, out_sub_stride, out_row_stride, subgrid_off1s, subgrid_size, mask, mask_batch_stride, nsub,
+                                  0, stream);
+}
+
+/* AXIS-1-FIRST pipeline (r6), step R: the contiguous-axis half of add_to_subgrid (core.py:255-285) on the rows of the K1
+ * band buffers of all facets, for the wave `wave_off1`, BEFORE the strided-axis transforms (swiftly_sumfinish.h,
+ * axis1_rows_kernel).  out[f] = [rows, m] in the parity-split layout of a band that is exactly the wave's window
+ * (start (yN/2 - m/2 + s) mod yN, length m): hand it to prepare_facet_columns / wave_facet_side with that band. */
+int swiftly_hip_finish_axis1_rows(swiftly_hip_t* h, int dtype, const void* bands, int64_t rows, int64_t band_row_stride,
+                                  int64_t band_facet_stride, int64_t nfacets, const int64_t* facet_off1s,
+                                  int64_t band_start, int64_t band_len, int64_t wave_off1, void* out,
+                                  int64_t out_row_stride, int64_t out_facet_stride, void* stream) {
+    if (!h || !bands || !out || !facet_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
+    DeviceGuard device_guard_(h->device);
+    if (dtype != SWIFTLY_C64) return fail(SWIFTLY_ERR_UNSUPPORTED, "finish_axis1_rows: complex64 only");
+    if (!band_is_split(h) || h->log_m < 7 || h->log_m > 10)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "finish_axis1_rows: needs the parity-split band layout (yN_size 16384 .. 65536) and "
+                    "m = 128 .. 1024");
+    if (nfacets <= 0 || nfacets > kSumFinishMaxFacets)
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "finish_axis1_rows: 1..%d facets supported", kSumFinishMaxFacets);
+    const int yN = (int)h->yN, m = (int)h->m;
+    if (band_len <= 0 || band_len > yN || band_start < 0 || band_start >= yN)
+        return fail(SWIFTLY_ERR_PARAM, "band [%lld, +%lld) is not a cyclic range of [0, %d)", (long long)band_start, (long long)band_len, yN);
+    if (rows <= 0) return 0;
+    Axis1RowsArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = (const cx<float>*)bands; a.out = (cx<float>*)out;
+    a.in_fs = band_facet_stride; a.in_rs = band_row_stride; a.out_fs = out_facet_stride; a.out_rs = out_row_stride;
+    a.nrows = (int)rows; a.yN = yN;
+    a.band_start = (int)band_start; a.band_len = (int)band_len; a.band_half = (int)band_half_columns(band_len);
+    const int64_t s = floordiv(wave_off1 * h->yN, h->N);
+    a.c0 = (int)pmod(yN / 2 - m / 2 + s, yN);
+    a.s = (int)pmod(s, m);
+    // every column of the window must lie inside the band
+    if (pmod(a.c0 - band_start, yN) + m > band_len)
+        return fail(SWIFTLY_ERR_PARAM, "finish_axis1_rows: the window of off1 = %lld is not inside the band", (long long)wave_off1);
+    for (int64_t f = 0; f < nfacets; f++) a.sp[f] = (int)pmod(floordiv(facet_off1s[f] * h->xM, h->N), m);
+    a.fn = h->fn_f;
+    a.tw_m = twiddles<float>(h, h->log_m);
+    a.twc_m = compact_twiddles(h, h->log_m, h->log_m - 6);
+    if (!a.tw_m || !a.twc_m) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
+    int e = launch_axis1_rows(h->log_m, a, (int)nfacets, (hipStream_t)stream);
+    if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "no instance");
     return 0;
 }
 
@@ -623,22 +679,46 @@ int swiftly_hip_wave_facet_side(swiftly_hip_t* h, int dtype, const void* bands, 
                                         sub_off0s, g_out, g_facet_stride, g_sub_stride, g_offsets, g_facet_strides, stream);
 }
 
-int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
+static int wave_subgrid_side_impl(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
                                   int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
                                   int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
                                   const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
-                                  void* tmp_work, void* out, void* scratch, int64_t scratch_bytes, void* stream) {
+                                  void* tmp_work, void* out, void* scratch, int64_t scratch_bytes, int placed, void* stream) {
     if (!h || !g || !tmp_work || !out || !sub_off0s || !sub_off1s) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (nsub <= 0) return 0;
     const int64_t m = h->m, xM = h->xM, xA = subgrid_size;
     // K4b + K5a: tmp[b] = [xM, xA]
-    int rc = swiftly_hip_sum_finish_facets(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, m, facet_off0s, facet_off1s,
-                                           tmp_work, xM * xA, xA, sub_off1s, subgrid_size, mask1, mask1_bs, nsub, stream);
+    int rc = sum_finish_facets_impl(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, m, facet_off0s, facet_off1s,
+                                    tmp_work, xM * xA, xA, sub_off1s, subgrid_size, mask1, mask1_bs, nsub, placed, stream);
     if (rc) return rc;
     // K5b: finish_subgrid along axis 0 (strided): rows of the op = xA columns
     CallWorkspace call_ws(scratch, scratch ? (size_t)scratch_bytes : 0);
     return swiftly_hip_finish_subgrid_batch(h, dtype, tmp_work, xA, 1, xA, out, 1, xA, 0, subgrid_size, mask0, nsub,
                                             xM * xA, xA * xA, sub_off0s, mask0 ? mask0_bs : 0, stream);
+}
+
+int swiftly_hip_wave_subgrid_side(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
+                                  int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
+                                  int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s, int64_t subgrid_size,
+                                  const void* mask0, int64_t mask0_bs, const void* mask1, int64_t mask1_bs,
+                                  void* tmp_work, void* out, void* scratch, int64_t scratch_bytes, void* stream) {
+    return wave_subgrid_side_impl(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, facet_off0s, facet_off1s, nsub, sub_off0s,
+                                  sub_off1s, subgrid_size, mask0, mask0_bs, mask1, mask1_bs, tmp_work, out, scratch, scratch_bytes,
+                                  0, stream);
+}
+
+/* wave_subgrid_side of the AXIS-1-FIRST pipeline: the blocks g[f][b] come from band buffers that went through
+ * swiftly_hip_finish_axis1_rows, i.e. their rows already are Fn * cfft_m along the contiguous axis: sum_finish_facets
+ * places and sums them without its m-point transforms. */
+int swiftly_hip_wave_subgrid_side_placed(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
+                                         int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
+                                         int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s,
+                                         int64_t subgrid_size, const void* mask0, int64_t mask0_bs, const void* mask1,
+                                         int64_t mask1_bs, void* tmp_work, void* out, void* scratch, int64_t scratch_bytes,
+                                         void* stream) {
+    return wave_subgrid_side_impl(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, facet_off0s, facet_off1s, nsub, sub_off0s,
+                                  sub_off1s, subgrid_size, mask0, mask0_bs, mask1, mask1_bs, tmp_work, out, scratch, scratch_bytes,
+                                  1, stream);
 }
 
 

@@ -216,6 +216,10 @@ struct SumFinishFacetArgs {
     int nrounds;
     int rstart[kSumFinishMaxFacets + 1];
     int rgroup[kSumFinishMaxFacets];
+    // (r6, axis-1-first pipeline) 1 = the rows of `in` already ARE  Fn[k] * cfft_m(contribution)[(k + s'1) mod m]  along the
+    // contiguous axis (axis1_rows_kernel ran before the strided-axis transforms): no m-point transform here, the rows of
+    // a group are summed and placed.  Register form only.
+    int placed;
 };
 
 // (register form, 1024-point rows: 4 waves per SIMD = 16 rows per CU, which the 8.7 KB of LDS per row now allow)
@@ -369,9 +373,11 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
                     const cx<float>* __restrict__ in =
                         A.in + (long long)A.fidx[nn] * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
                     wgt[sl] = on ? 1.f : 0.f;
+                    // placed rows are indexed by kk = (centred output index - s'1) mod m of the slot the value lands in
+                    const int rot = A.placed ? A.gsp1[g] : 0;
                     static_for<0, PM>([&](auto vI) {
                         constexpr int v = decltype(vI)::value;
-                        x[sl][v] = in[(t + v * TR) ^ (M >> 1)];  // plain index -> centred element
+                        x[sl][v] = in[(((t + v * TR) ^ (M >> 1)) - rot) & (M - 1)];  // plain index -> centred element
                     });
                 }
             });
@@ -388,6 +394,22 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
         }
         if (!anyg) continue;
         const int sp = A.gsp1[g];
+        if (A.placed) {  // workgroup-uniform: xs[v] = sum of the group's rows at element kk_v (loaded below in that order)
+            static_for<0, PM>([&](auto vI) {
+                constexpr int v = decltype(vI)::value;
+                const int ck = (t + v * TR) ^ (M >> 1);
+                const int kk = (ck - sp) & (M - 1);
+                const int p = (kk - (M >> 1) + sp) & (X - 1);
+                const int c = p >> LOGM;
+                static_for<0, RATIO>([&](auto cI) {
+                    constexpr int cc = decltype(cI)::value;
+                    const float wc = c == cc ? 1.f : 0.f;
+                    y[v + PM * cc].x += xs[v].x * wc;
+                    y[v + PM * cc].y += xs[v].y * wc;
+                });
+            });
+            continue;
+        }
         fft_phases<SFCompact<GM>, float, 0>(xs, t, 0, false, ex_row, A.tw_m, [&](int e, cx<float> v, auto sI) {
             // slot = u * RAD + r of the last phase (radix RAD = 2^LR, NB = PM / RAD blocks): e = t + TR * (u + NB * r)
             constexpr int LR = GM::LOGN % GM::LOGP == 0 ? GM::LOGP : GM::LOGN % GM::LOGP, RAD = 1 << LR, NBL = PM / RAD;
@@ -455,6 +477,71 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
             out[d] = cx<float>{v.x * w, -v.y * w};
         }
     }, nullptr, A.twc_x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AXIS-1-FIRST pipeline (r6; SwiftlyConfig(axis1_first=True)): the contiguous-axis half of add_to_subgrid (core.py:255-285)
+// applied to the rows of the K1 output BEFORE the strided-axis transforms K2 / K3 -- the transforms commute
+// (api_helper.py:81-99, 200-210) -- so that K2 and K3 work on data that carries ONE facet window instead of two: their
+// float32 rounding then reaches the subgrid 10x weaker (tests/accuracy_model.py: 1.30e-5 -> 2.1e-6 end to end).
+// Per facet f, facet row r and wave (subgrid off1, s = off1 yN / N):
+//     x[(i + s) mod m] = P_f[r, (yN/2 - m/2 + i + s) mod yN]          extract_from_facet(axis 1), core.py:243-253
+//     Z[k]             = Fn[k] * cfft_m(x)[(k + s'1_f) mod m]          add_to_subgrid(axis 1) without its placement
+//     W_f[r, band column of window element i] = Z[(i + s) mod m]       parity-split band of exactly the window's m columns
+// The output is laid out as a K1 band buffer whose band IS the window (start (yN/2 - m/2 + s) mod yN, length m), so the
+// unchanged K2 gathers Z[j] as "window element" j; sum_finish_facets then runs with SumFinishFacetArgs::placed.
+struct Axis1RowsArgs {
+    const cx<float>* in;   // bands[f][row][band columns], parity-split
+    cx<float>* out;        // W[f][row][m], parity-split band of the window
+    long long in_fs, in_rs, out_fs, out_rs;
+    int nrows, yN;
+    int band_start, band_len, band_half;
+    int c0;                // logical column of window element 0: (yN/2 - m/2 + s) mod yN
+    int s;                 // s mod m
+    int sp[kSumFinishMaxFacets];  // s'1 = floor(facet_off1 * xM / N) mod m per facet
+    const float* fn;
+    const cx<float>* tw_m;
+    const cx<float>* twc_m;
+};
+constexpr int kAxis1Threads = 256;  // four rows per workgroup, one wave per row (wave-private exchange buffers)
+template <int LOGM>
+struct Axis1Geo {
+    using GM = Geo<float, LOGM, LOGM - 6, kAxis1Threads, false>;
+    static constexpr size_t LDS_BYTES = GM::LDS_BYTES;
+};
+template <int LOGM>
+__global__ __launch_bounds__(kAxis1Threads) void axis1_rows_kernel(const Axis1RowsArgs A) {
+    using GM = typename Axis1Geo<LOGM>::GM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cx<float>* ex = reinterpret_cast<cx<float>*>(smem);
+    constexpr int M = GM::N, PM = GM::P, TR = 64;
+    const int t = threadIdx.x & 63, rb = threadIdx.x >> 6;
+    const int f = blockIdx.y;
+    const int row = blockIdx.x * GM::RB + rb;
+    const bool live = row < A.nrows;
+    const cx<float>* __restrict__ in = A.in + (long long)f * A.in_fs + (long long)(live ? row : 0) * A.in_rs;
+    cx<float>* __restrict__ out = A.out + (long long)f * A.out_fs + (long long)(live ? row : 0) * A.out_rs;
+    const int sp = A.sp[f];
+    cx<float> x[PM];
+    static_for<0, PM>([&](auto vI) {
+        constexpr int v = decltype(vI)::value;
+        const int ci = (t + v * TR) ^ (M >> 1);          // centred element of x (plain index t + v TR)
+        const int i = (ci - A.s) & (M - 1);              // window element that lands there
+        int col = A.c0 + i;
+        if (col >= A.yN) col -= A.yN;
+        int d = col - A.band_start;
+        if (d < 0) d += A.yN;
+        const bool ok = d < A.band_len;                  // (a window always lies inside the band of its plan)
+        x[v] = in[ok ? (d & 1) * A.band_half + (d >> 1) : 0];
+        if (!ok) x[v] = cx<float>{0.f, 0.f};
+    });
+    fft_phases<SFCompact<GM>, float, 0>(x, t, rb, false, ex, A.tw_m, [&](int e, cx<float> v) {
+        const int ck = e ^ (M >> 1);
+        const int kk = (ck - sp) & (M - 1);
+        const float w = A.fn[kk];
+        const int i2 = (kk - A.s) & (M - 1);
+        if (live) out[(i2 & 1) * (M >> 1) + (i2 >> 1)] = cx<float>{v.x * w, v.y * w};
+    }, nullptr, A.twc_m);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -620,5 +707,6 @@ int launch_sum_finish_facets(int logm, int logx, const SumFinishFacetArgs& a, in
 int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatch, hipStream_t s);
 int init_sum_finish_rows();
 bool sum_finish_supported(int logm, int logx);
+int launch_axis1_rows(int logm, const Axis1RowsArgs& a, int nfacets, hipStream_t s);
 
 }  // namespace swf

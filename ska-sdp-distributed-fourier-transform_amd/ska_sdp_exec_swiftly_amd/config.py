@@ -89,7 +89,7 @@ class SwiftlyConfig:
     # pylint: disable=too-many-arguments,too-many-instance-attributes
     def __init__(
         self, W, fov, N, yB_size, yN_size, xA_size, xM_size, dask_client=None, backend="hip", column_precision=None,
-        **_other_args
+        axis1_first=False, **_other_args
     ):
         self._W = W
         self._fov = fov
@@ -100,7 +100,9 @@ class SwiftlyConfig:
         self._xM_size = xM_size
         self.dask_client = dask_client  # unused: there is no Dask in this backend
         if backend == "hip":
-            self._core = SwiftlyCoreHip(W, N, xM_size, yN_size, column_precision=column_precision)
+            # column_precision=64 / axis1_first=True: the two opt-in accuracy modes of the complex64 band pipeline
+            # (float64 arithmetic in the column passes; the contiguous axis finished before the strided one)
+            self._core = SwiftlyCoreHip(W, N, xM_size, yN_size, column_precision=column_precision, axis1_first=axis1_first)
         elif backend in ("numpy", "ska_sdp_func"):
             # reference api.py:137-141 -- those cores live in the reference package; this one is GPU only
             raise ValueError(

@@ -140,7 +140,9 @@ class SwiftlyCoreHip:
 
     # pylint: disable=too-many-public-methods,too-many-arguments
 
-    def __init__(self, W, N, xM_size, yN_size, device=None, column_precision=None):
+    def __init__(self, W, N, xM_size, yN_size, device=None, column_precision=None, axis1_first=False):
+        # (r6) axis-1-first forward band pipeline (finish_axis1_rows): the streaming classes read this switch
+        self.axis1_first = bool(axis1_first)
         self.W = W
         self.N = N
         self.xM_size = xM_size
@@ -198,7 +200,7 @@ class SwiftlyCoreHip:
     def __getstate__(self):
         # no device pointers, no caches
         return {"W": self.W, "N": self.N, "xM_size": self.xM_size, "yN_size": self.yN_size,
-                "column_precision": self.column_precision}
+                "column_precision": self.column_precision, "axis1_first": self.axis1_first}
 
     def __setstate__(self, state):
         self.__init__(**state)
@@ -773,14 +775,18 @@ class SwiftlyCoreHip:
         )
         return out
 
-    def wave_subgrid_side(self, G, facet_off0s, facet_off1s, sub_off0s, sub_off1s, subgrid_size, mask0, mask1, tmp, out):
+    def wave_subgrid_side(self, G, facet_off0s, facet_off1s, sub_off0s, sub_off1s, subgrid_size, mask0, mask1, tmp, out,
+                          placed=False):
         """K4b + K5 of one wave natively (``swiftly_hip_wave_subgrid_side``): ``G[F, S, m, m]`` -> ``out[S, xA, xA]``
-        through the workspace ``tmp[S, xM, xA]``."""
+        through the workspace ``tmp[S, xM, xA]``.  ``placed``: the blocks come from the axis-1-first pipeline
+        (``finish_axis1_rows`` ran before K2): their rows already are ``Fn * cfft_m`` along the contiguous axis."""
         F, S = G.shape[0], G.shape[1]
         cvp = ctypes.c_void_p
         scr = self.scratch("k5b", min(S, 64) * self.xM_size * int(subgrid_size) * 8)
+        # axis-1-first pipeline: the rows of G already are Fn * cfft_m along the contiguous axis (finish_axis1_rows)
+        entry = self._lib.swiftly_hip_wave_subgrid_side_placed if placed else self._lib.swiftly_hip_wave_subgrid_side
         _lib.check(
-            self._lib.swiftly_hip_wave_subgrid_side(
+            entry(
                 self._handle, self._code(G), cvp(G.data_ptr()), F, G.stride(0), G.stride(1), self._i64(facet_off0s),
                 self._i64(facet_off1s), S, self._i64(sub_off0s), self._i64(sub_off1s), int(subgrid_size),
                 cvp(mask0.data_ptr()) if mask0 is not None else None, mask0.stride(0) if mask0 is not None else 0,
@@ -789,6 +795,27 @@ class SwiftlyCoreHip:
             )
         )
         return out
+
+    def finish_axis1_rows(self, bands, facet_off1s, band, wave_off1, out=None):
+        """Step R of the axis-1-first pipeline (``swiftly_hip_finish_axis1_rows``): the contiguous-axis half of
+        ``add_to_subgrid`` (reference core.py:255-285) on every row of the K1 band buffers ``bands[F, yB, band columns]``
+        for the wave ``wave_off1``, BEFORE the strided-axis transforms.  Returns ``(W[F, yB, m], window band)``: hand both
+        to ``prepare_facet_columns`` / ``wave_facet_side`` in place of the band buffers and their band."""
+        torch = _torch()
+        F, rows = bands.shape[0], bands.shape[1]
+        m, yN = self.xM_yN_size, self.yN_size
+        if out is None:
+            out = torch.empty((F, rows, m), dtype=bands.dtype, device=bands.device)
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_finish_axis1_rows(
+                self._handle, self._code(bands), cvp(bands.data_ptr()), rows, bands.stride(1), bands.stride(0), F,
+                self._i64(facet_off1s), int(band[0]), int(band[1]), int(wave_off1), cvp(out.data_ptr()), out.stride(1),
+                out.stride(0), self._stream(),
+            )
+        )
+        s = int(wave_off1) * yN // self.N
+        return out, ((yN // 2 - m // 2 + s) % yN, m)
 
     def sum_finish_facets(self, G, facet_off0s, facet_off1s, out, subgrid_off1s, subgrid_size, mask=None):
         """K4b + K5a: sum over facets + axis-1 finish of ``G[F, S, m, m]`` (transform_contributions) ->

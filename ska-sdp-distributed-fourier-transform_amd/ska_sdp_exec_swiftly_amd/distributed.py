@@ -562,7 +562,8 @@ class DistributedForward:
         m = self.core.xM_yN_size
         cfgs = self._arrival_cfgs(key)
         blocks = recv.view(len(cfgs), len(mine), m, m)  # facets in arrival order
-        res = finish_from_blocks(self.core, blocks, cfgs, [sgs[i] for i in mine], transformed=self.fused)
+        res = finish_from_blocks(self.core, blocks, cfgs, [sgs[i] for i in mine], transformed=self.fused,
+                                 placed=self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False)))
         return mine, res
 
     def start_wave(self, sgs):

@@ -364,8 +364,11 @@ class SwiftlyForward(WavePrefetch):
         nxt = self._predict_next_waves(sgs[0].off1, _knobs()._PREFETCH_DEPTH)
         if not compute:
             self._prefetch_waves(nxt)
+        band = self._band
+        if compute:
+            bands, band = self._k2_source(sgs[0].off1)
         try:
-            self.core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,
+            self.core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], band, sgs[0].off1, rowmap,
                                       n_rows, Q, compute, [sg.off0 for sg in sgs], flat, g_layout=layout)
         except Exception:
             if compute:  # Q was registered before it was computed: a later request must not find garbage
@@ -446,6 +449,19 @@ class SwiftlyForward(WavePrefetch):
             self._wave_rowmaps[key] = self.core.subgrid_column_rows(by_key.get(key, []))
         return self._wave_rowmaps[key]
 
+    def _axis1(self):
+        """is this object running the axis-1-first band pipeline (``SwiftlyConfig(axis1_first=True)``, wave_axis = 1)?"""
+        return self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False))
+
+    def _k2_source(self, off1):
+        """``(bands, band)`` that K2 of wave ``off1`` reads: the K1 band buffers and the plan's band -- or, in the
+        axis-1-first pipeline (``SwiftlyConfig(axis1_first=True)``), the rows finished along the contiguous axis for this
+        wave (core.finish_axis1_rows, on the current stream) with the band that is exactly the wave's window."""
+        bands = self.BF_Fs_persist
+        if not self._axis1():
+            return bands, self._band
+        return self.core.finish_axis1_rows(bands, [cfg.off1 for cfg in self.facet_configs], self._band, off1)
+
     def _get_wave_columns(self, off1):
         """K2: ``Q[F, rows, m]`` for the subgrid wave ``off1`` (LRU cached like the reference's per-off0 columns)."""
         self._take_prefetched(off1)
@@ -453,10 +469,11 @@ class SwiftlyForward(WavePrefetch):
         if hit is None:
             if self._plan is not None and int(off1) not in self._planned_keys:
                 raise ValueError(f"subgrid wave off1={off1} was not in the subgrid_configs plan")
-            bands = self.prepare_all_facets()
+            self.prepare_all_facets()
             rowmap, n_rows = self._wave_rows(off1)
+            bands, band = self._k2_source(off1)
             Q = self.core.prepare_facet_columns(
-                bands, [cfg.off0 for cfg in self.facet_configs], self._band, off1, rowmap, n_rows
+                bands, [cfg.off0 for cfg in self.facet_configs], band, off1, rowmap, n_rows
             )
             hit = (Q, rowmap)
             self.lru.set(("b", off1), hit)
@@ -474,7 +491,8 @@ class SwiftlyForward(WavePrefetch):
         """stage-by-stage form (one ABI call per kernel group; used when the stages are timed separately)"""
         Q, rowmap = self._get_wave_columns(sgs[0].off1)
         self._check_planned(sgs)
-        return _finish_from_columns(self.core, Q, 1, self.facet_configs, sgs, [sg.off0 for sg in sgs], rowmap=rowmap)
+        return _finish_from_columns(self.core, Q, 1, self.facet_configs, sgs, [sg.off0 for sg in sgs], rowmap=rowmap,
+                                    placed=self._axis1())
 
     def _wave_Q(self, off1):
         """(Q workspace, rowmap, n_rows, needs computing) of wave ``off1`` (LRU cached like _get_wave_columns)"""
@@ -505,8 +523,11 @@ class SwiftlyForward(WavePrefetch):
             self._prefetch_waves(nxt)
         m = core.xM_yN_size
         G = torch.empty((len(self.facet_configs), len(sgs), m, m), dtype=self.dtype, device=core.device)
+        band = self._band
+        if compute:
+            bands, band = self._k2_source(sgs[0].off1)
         try:
-            core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], self._band, sgs[0].off1, rowmap,
+            core.wave_facet_side(bands, [cfg.off0 for cfg in self.facet_configs], band, sgs[0].off1, rowmap,
                                  n_rows, Q, compute, [sg.off0 for sg in sgs], G)
         except Exception:
             if compute:
@@ -514,9 +535,10 @@ class SwiftlyForward(WavePrefetch):
             raise
         if compute:  # (this wave's own K2 was enqueued on the current stream just now: the next one goes behind it)
             self._prefetch_waves(nxt)
-        return _finish_from_G(core, G, self.facet_configs, sgs)
+        return _finish_from_G(core, G, self.facet_configs, sgs, placed=self._axis1())
 
-def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, rowmap=None, band=None):
+
+def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, rowmap=None, band=None, placed=False):
     """K3..K5 without any HBM accumulator: per-(facet, subgrid) axis-0 transforms gathered straight from the
     wave's facet buffers (``src``), facet sum + axis-1 finish on chip, axis-0 finish."""
     torch = _torch()
@@ -527,11 +549,12 @@ def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, row
     off0s = [cfg.off0 for cfg in facet_configs]
     off1s = [cfg.off1 for cfg in facet_configs]
     G = core.transform_contributions(src, layout, off0s, window_offs, rowmap=rowmap, band=band)
-    return _finish_from_G(core, G, facet_configs, sgs)
+    return _finish_from_G(core, G, facet_configs, sgs, placed=placed)
 
 
-def _finish_from_G(core, G, facet_configs, sgs):
-    """facet sum + axis-1 finish on chip (sum_finish_facets), then the axis-0 finish, for ``G[F, S, m, m]``."""
+def _finish_from_G(core, G, facet_configs, sgs, placed=False):
+    """facet sum + axis-1 finish on chip (sum_finish_facets), then the axis-0 finish, for ``G[F, S, m, m]``.  ``placed``:
+    blocks of the axis-1-first pipeline (their contiguous axis is already finished up to the placement)."""
     torch = _torch()
     xM, xA, S = core.xM_size, sgs[0].size, len(sgs)
     dt, dev = G.dtype, core.device
@@ -542,15 +565,15 @@ def _finish_from_G(core, G, facet_configs, sgs):
     tmp = torch.empty((S, xM, xA), dtype=dt, device=dev)
     res = torch.empty((S, xA, xA), dtype=dt, device=dev)
     return core.wave_subgrid_side(G, off0s, off1s, [sg.off0 for sg in sgs], [sg.off1 for sg in sgs], xA, mask0, mask1,
-                                  tmp, res)
+                                  tmp, res, placed=placed)
 
 
-def finish_from_blocks(core, blocks, facet_configs, sgs, transformed=True):
+def finish_from_blocks(core, blocks, facet_configs, sgs, transformed=True, placed=False):
     """Finished, masked subgrids ``[S, xA, xA]`` from the per-(facet, subgrid) blocks ``[F, S, m, m]`` of ALL
     facets (``facet_configs`` in the blocks' facet order): the receiving side of the multi-GPU exchange.
-    ``transformed`` as in :py:meth:`SwiftlyForward.wave_blocks`."""
+    ``transformed`` as in :py:meth:`SwiftlyForward.wave_blocks`; ``placed``: the senders ran the axis-1-first pipeline."""
     if transformed:
-        return _finish_from_G(core, blocks, facet_configs, sgs)
+        return _finish_from_G(core, blocks, facet_configs, sgs, placed=placed)
     return sum_and_finish_wave(core, blocks, facet_configs, sgs)
 
 

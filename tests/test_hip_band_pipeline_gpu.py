@@ -356,6 +356,127 @@ def test_forward_planned_wave_prefetch_is_bit_identical(order):
     assert relrms(ahead[keys[1]][1], so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))) < 2e-5
 
 
+def test_finish_axis1_rows_matches_oracle():
+    """(r6) step R of the axis-1-first pipeline against the oracle primitives: for rows of a K1 band buffer, the window
+    gather of extract_from_facet(axis 1) followed by add_to_subgrid(axis 1) (core.py:243-285) -- the latter read back
+    from its placement in the padded subgrid -- laid out as a parity-split band that is exactly the wave's window."""
+    import torch
+
+    core, ref = core64()
+    rng = numpy.random.default_rng(7)
+    rows, m, xM = 6, 512, xM64
+    band = (10736, 11472)
+    pc = band_cols(yN64, band)
+    full = (rng.standard_normal((rows, yN64)) + 1j * rng.standard_normal((rows, yN64))).astype(numpy.complex64)
+    phys = numpy.zeros((2, rows, core.band_columns(band)), dtype=numpy.complex64)
+    keep = pc >= 0
+    phys[:, :, pc[keep]] = full[None][:, :, keep]
+    bands = torch.from_numpy(phys).cuda()
+    facet_off1s = [0, 64 * 352]
+    for sub_off1 in (0, 3 * 928, -5 * 928):
+        W, wband = core.finish_axis1_rows(bands, facet_off1s, band, sub_off1)
+        s = sub_off1 * yN64 // N64
+        assert wband == ((yN64 // 2 - m // 2 + s) % yN64, m) and tuple(W.shape) == (2, rows, m)
+        got = W.cpu().numpy()
+        wpc = band_cols(yN64, wband)
+        for f, foff in enumerate(facet_off1s):
+            contrib = ref.extract_from_facet(full.astype(complex), sub_off1, 1)          # [rows, m]
+            placed = ref.add_to_subgrid(contrib, foff, 1)                                  # [rows, xM]
+            sp = foff * xM // N64
+            k = numpy.arange(m)
+            Z = placed[:, (k + xM // 2 - m // 2 + sp) % xM]                                # Z[k], core.py:274-285
+            # logical window element i holds Z[(i + s) mod m], at the parity-split position of logical column c0 + i
+            i = numpy.arange(m)
+            want_logical = Z[:, (i + s) % m]
+            got_logical = got[f][:, wpc[(wband[0] + i) % yN64]]
+            rel = relrms(got_logical, want_logical)
+            assert rel < 2e-6, (sub_off1, f, rel)
+
+
+def test_axis1_first_pipeline_matches_oracle_and_default_order():
+    """(r6) SwiftlyConfig(axis1_first=True): the forward band pipeline with the contiguous axis finished before K2 / K3
+    gives the oracle's subgrids (tighter than the default order: its float32 rounding acts on singly windowed data) in
+    any request order, with and without the planned-wave prefetch."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+
+    torch_, sw_, cfg0, facet_cfgs, facets, sg_cfgs = _small_rows_problem(seed=91)
+    if not cfg0.core.supports_band_pipeline(torch.complex64):
+        pytest.skip("band pipeline not available")
+    P = dict(W=W64, fov=1.0, N=N64, yB_size=352, yN_size=yN64, xA_size=928, xM_size=xM64)
+    cfg = sw.SwiftlyConfig(backend="hip", axis1_first=True, **P)
+    assert cfg.core.axis1_first and not cfg0.core.axis1_first
+    so = sep.SeparableOracle(core64()[1], [orc.CoverItem(c.off0, c.off1, c.size) for c in facet_cfgs],
+                             [sep.facet_vectors(91 + j, 352, rank=2) for j in range(3)])
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off1, []).append(c)
+    ref = sw.SwiftlyForward(cfg0, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
+    for prefetch in (True, False):
+        old = sw.api._PREFETCH
+        sw.api._PREFETCH = prefetch
+        try:
+            fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
+            for key in (sorted(waves) if prefetch else sorted(waves)[::-1]):
+                got = fwd.get_wave(waves[key]).cpu().numpy()
+                base = ref.get_wave(waves[key]).cpu().numpy()
+                for k, c in enumerate(waves[key]):
+                    want = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))
+                    assert relrms(got[k], want) < 4e-6, (prefetch, key, k, relrms(got[k], want))
+                    assert relrms(got[k], base[k]) < 3e-5
+        finally:
+            sw.api._PREFETCH = old
+    # pickling carries the switch (core.py:512-525: only parameters travel)
+    import pickle
+
+    assert pickle.loads(pickle.dumps(cfg.core)).axis1_first
+
+
+def test_axis1_first_through_the_multi_gpu_classes():
+    """(r6) the axis-1-first order on the facet-sharded path: two virtual ranks (whole facets, in-process shuffle in place of
+    the all-to-all) pack their blocks with finish_axis1_rows in front of K2 and the owners finish them in placed mode --
+    the same subgrids as the single-process object in that mode."""
+    import torch
+
+    import ska_sdp_exec_swiftly_amd as sw
+    from ska_sdp_exec_swiftly_amd.distributed import DistributedForward
+
+    _, _, cfg0, facet_cfgs, facets, sg_cfgs = _small_rows_problem(seed=93)
+    if not cfg0.core.supports_band_pipeline(torch.complex64):
+        pytest.skip("band pipeline not available")
+    P = dict(W=W64, fov=1.0, N=N64, yB_size=352, yN_size=yN64, xA_size=928, xM_size=xM64)
+    cfg = sw.SwiftlyConfig(backend="hip", axis1_first=True, **P)
+    world = 2
+    ref = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
+    fwds = [DistributedForward(cfg, facet_cfgs, facets, dtype=torch.complex64, wave_axis=1, subgrid_configs=sg_cfgs,
+                               rank_world=(r, world), cooperative=False) for r in range(world)]
+    waves = {}
+    for c in sg_cfgs:
+        waves.setdefault(c.off1, []).append(c)
+    for wave in waves.values():
+        want = ref.get_wave(wave)
+        packed = [f.pack_wave(wave) for f in fwds]
+        # in-process all-to-all: rank r receives chunk r of every sender, in sender order
+        recvs = []
+        for r in range(world):
+            parts = []
+            for snd, (send, in_counts, _) in enumerate(packed):
+                pos = sum(in_counts[:r])
+                parts.append(send[pos : pos + in_counts[r]])
+            recvs.append(torch.cat(parts))
+        got = {}
+        for r, f in enumerate(fwds):
+            assert recvs[r].numel() == sum(packed[r][2])
+            mine, res = f.unpack_wave(wave, recvs[r])
+            for k, i in enumerate(mine):
+                got[i] = res[k]
+        assert sorted(got) == list(range(len(wave)))
+        scale = float(want.abs().max())
+        for i in range(len(wave)):
+            assert float((got[i] - want[i]).abs().max()) <= 5e-6 * scale
+
+
 def test_chained_k2_with_a_trailing_unchunked_facet_group():
     """(r5 advisor) More than 32 facets: K2 of a wave runs as one four-step per group of 32 facets, and only groups whose
     intermediate exceeds 256 MiB take the chunk-stream path.  36 facets at yN = 8192, m = 1024: the first group (2 GiB) is

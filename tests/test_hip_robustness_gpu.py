@@ -44,7 +44,7 @@ def test_pickle_roundtrip():
     b = _chain(clone, facet, 8, 6, P["xA_size"])
     assert numpy.array_equal(a, b)
     # the state carries no device pointers
-    assert set(core.__getstate__()) == {"W", "N", "xM_size", "yN_size", "column_precision"}
+    assert set(core.__getstate__()) == {"W", "N", "xM_size", "yN_size", "column_precision", "axis1_first"}
     core.column_precision = 64  # the precision setting travels with the pickle
     assert pickle.loads(pickle.dumps(core)).column_precision == 64
     core.column_precision = 32
