@@ -29,3 +29,21 @@ def test_storage_floor_and_the_stages_that_set_the_float32_error():
     both = am.chain_error(dict(k1=32, k2=64, k3=64, sf=32, k5=32))
     print(f"{both:.3e}  float64 arithmetic in k2 and k3 (column_precision = 64)")
     assert both < 1.15 * floor_scratch      # 3.5e-6
+
+
+def test_axis1_first_order_removes_the_double_window_from_the_column_passes():
+    """(r6; r5 review item 3) The transforms of the two axes commute (api_helper.py:81-99, 200-210).  With the contiguous
+    axis finished per wave BEFORE the strided-axis transforms (K1 output -> window gather -> m-point transform x Fn, stored in
+    complex64; tests/accuracy_model.py: forward_chain_reordered) K2 and K3 work on data that carries ONE facet window: the
+    all-float32 error of the probe configuration falls from 1.3e-5 to 2.1e-6, the storage floor from 3.3e-6 to 3.7e-7, and
+    no single stage's float32 arithmetic costs more than 1.5e-6.  This is the dataflow of SwiftlyConfig(axis1_first=True)
+    (HIP kernels on the N = 65536 workload: 2.04e-6 against 1.03e-5)."""
+    rows = am.reordered_budget()
+    for name, v in rows.items():
+        print(f"{v:.3e}  {name}")
+    all32 = rows["reordered: float32 arithmetic everywhere"]
+    floor = rows["reordered: storage floor (float64 arithmetic, complex64 intermediates + scratch)"]
+    assert 1.5e-6 < all32 < 3e-6          # 2.07e-6
+    assert 2e-7 < floor < 6e-7            # 3.7e-7
+    for st in ("k1", "k2", "k3", "sf", "k5"):
+        assert rows[f"reordered: float32 arithmetic in {st} only"] < 2e-6
