@@ -58,6 +58,8 @@ BACKWARD_PARITY_TOL = 3.5e-5
 HIGH_PRECISION_PARITY_TOL = 5e-6
 # forward relRMSE bound of the axis-1-first pipeline (float32 arithmetic, SwiftlyConfig(axis1_first=True); model: 2.1e-6)
 AXIS1_FIRST_PARITY_TOL = 4e-6
+# ... and of its form with the contiguous-axis finish fused into K1 (axis1_first="fused"; measured 5.8e-6 on the 64k workload)
+AXIS1_FUSED_PARITY_TOL = 7.5e-6
 HIGH_PRECISION_BACKWARD_PARITY_TOL = 1e-5
 
 WORKLOADS = {
@@ -724,9 +726,11 @@ def main():
                     help="multi-GPU: 'group' (default) = every wave's subgrids are finished by ONE rank and the waves are "
                          "exchanged in groups of n_gpus waves with distinct owners (one balanced all-to-all per group); "
                          "'wave' = the subgrids of every wave dealt out round-robin, one all-to-all per wave")
-    ap.add_argument("--axis1-first", action="store_true",
-                    help="time the axis-1-first forward pipeline (SwiftlyConfig(axis1_first=True): the contiguous axis is "
-                         "finished before the strided-axis transforms; float32 arithmetic at ~5x smaller error)")
+    ap.add_argument("--axis1-first", nargs="?", const="rows", default=None, choices=["rows", "fused"],
+                    help="time the axis-1-first forward pipeline: 'rows' = SwiftlyConfig(axis1_first=True), the contiguous axis "
+                         "finished by a row pass per wave before the strided-axis transforms (float32 arithmetic at ~5x "
+                         "smaller error); 'fused' = axis1_first='fused', that finish inside K1 (window half spectra; cheaper, "
+                         "~1.8x smaller error than the default order)")
     ap.add_argument("--column-precision", type=int, default=32, choices=[32, 64],
                     help="arithmetic of the column passes K2 / K3 (complex64 data): 32 = float32 (default, the timed "
                          "configuration of every round), 64 = float64 butterflies (3.7x smaller error, 1.5x the time)")
@@ -794,7 +798,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     p = wl["params"]
-    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, axis1_first=args.axis1_first, **p)
+    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, axis1_first={None: False, "rows": True, "fused": "fused"}[args.axis1_first], **p)
     all_facet_cfgs = sw.make_full_facet_cover(cfg)
     # a rank holds at most `max_facets_per_rank` facets (HBM capacity): with too few ranks only the first cap * world
     # facets of the cover take part -- a stated subset; contributions are counted for those only
@@ -948,38 +952,52 @@ def main():
             kept = {k: v for d in gathered for k, v in d.items()}
         if rank == 0:
             parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept,
-                                     tol=AXIS1_FIRST_PARITY_TOL if args.axis1_first else wl.get("parity_tol"))
+                                     tol={None: wl.get("parity_tol"), "rows": AXIS1_FIRST_PARITY_TOL,
+                                          "fused": AXIS1_FUSED_PARITY_TOL}[args.axis1_first])
 
     # (r6) the axis-1-first pipeline beside the timed default order: same objects, same facets, float32 arithmetic -- the
     # contiguous axis finished (m-point transform x Fn per wave window) BEFORE K2 / K3, which then see ONE facet window
     accurate = None
     if single and picks and args.column_precision == 32 and not args.axis1_first and rank == 0:
-        cfg.core.axis1_first = True
-        try:
-            one_pass()
-            fence()
-            each = []
-            for _ in range(3):
-                t0 = time.perf_counter()
+        def axis1_leg(mode, tol):
+            cfg.core.axis1_first = mode
+            try:
                 one_pass()
                 fence()
-                each.append(1e3 * (time.perf_counter() - t0))
-            kept_a = {}
-            one_pass(keep=kept_a)
-            fence()
-            a_par = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept_a, tol=AXIS1_FIRST_PARITY_TOL)
-            accurate = dict(
-                mode="axis1_first", ms_per_step=round(sorted(each)[1], 3), each_ms=[round(t, 2) for t in each],
-                what="SwiftlyConfig(axis1_first=True): per wave, the rows of the K1 output go through the contiguous-axis half "
-                     "of add_to_subgrid (window gather, m-point transform, Fn; swiftly_hip_finish_axis1_rows) before K2; K2 / "
-                     "K3 unchanged, sum_finish_facets without its m-point transforms; float32 arithmetic throughout; not "
-                     "part of `value`",
-                parity={k: a_par[k] for k in ("rel_rmse", "rel_rmse_each", "max_abs_over_rms", "tol_rel_rmse", "ok")},
-            )
-        except NotImplementedError as err:
-            accurate = dict(mode="axis1_first", error=str(err))
-        finally:
-            cfg.core.axis1_first = False
+                each = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    one_pass()
+                    fence()
+                    each.append(1e3 * (time.perf_counter() - t0))
+                kept_a = {}
+                one_pass(keep=kept_a)
+                fence()
+                a_par = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept_a, tol=tol)
+                return dict(ms_per_step=round(sorted(each)[1], 3), each_ms=[round(t, 2) for t in each],
+                            parity={k: a_par[k] for k in ("rel_rmse", "rel_rmse_each", "max_abs_over_rms", "tol_rel_rmse", "ok")})
+            except NotImplementedError as err:
+                return dict(error=str(err))
+            finally:
+                cfg.core.axis1_first = False
+
+        accurate = dict(
+            mode="axis1_first",
+            what="SwiftlyConfig(axis1_first=True): per wave, the rows of the K1 output go through the contiguous-axis half "
+                 "of add_to_subgrid (window gather, m-point transform, Fn; swiftly_hip_finish_axis1_rows) before K2; K2 / "
+                 "K3 unchanged, sum_finish_facets without its m-point transforms; float32 arithmetic throughout; not "
+                 "part of `value`",
+            **axis1_leg(True, AXIS1_FIRST_PARITY_TOL),
+        )
+        accurate["fused_into_k1"] = dict(
+            what="SwiftlyConfig(axis1_first='fused'): the same order with the contiguous-axis finish inside K1 -- each of a "
+                 "row's two workgroups stores the half spectrum (m/2-point transform) of its output parity for every planned "
+                 "window instead of the band; K2 / K3 unchanged on the halves, sum_finish_facets joins them (radix-2 step, "
+                 "window phase, Fn).  No band buffer, no row pass per wave; the column passes work on ALIASED spectra "
+                 "(frequency u folded onto u + m/2, where Fn has not yet suppressed the window's leakage), which costs "
+                 "part of the accuracy gain",
+            **axis1_leg("fused", AXIS1_FUSED_PARITY_TOL),
+        )
 
     # the float64-arithmetic column passes (column_precision = 64) beside the timed float32 configuration: same objects,
     # same facets, three passes + the same parity check, outside the timed region (1 GPU, default precision only)
@@ -1283,7 +1301,7 @@ def main():
         higher_is_better=True,
         scaling="strong",
         vs_baseline=None,
-        dtype="complex64 (f32 arithmetic, axis-1-first order)" if args.axis1_first else "complex64 (f32 arithmetic)" if args.column_precision == 32 else "complex64 (f64 arithmetic in the column passes K2/K3, f32 elsewhere)",
+        dtype=f"complex64 (f32 arithmetic, axis-1-first order: {args.axis1_first})" if args.axis1_first else "complex64 (f32 arithmetic)" if args.column_precision == 32 else "complex64 (f64 arithmetic in the column passes K2/K3, f32 elsewhere)",
         data="synthetic",
         config=dict(
             workload=wl["name"], facets=F, facets_total=len(all_facet_cfgs), subgrids=S, subgrid_columns=C,

@@ -402,6 +402,7 @@ class DistributedForward:
             if local and self.local.dtype != self.dtype:
                 raise ValueError(f"local facets are {self.local.dtype}, the pass was declared {self.dtype}")
             self.local.dtype = self.dtype
+            self.local.axis1_fused = False  # the receivers place blocks of the per-wave axis-1-first form (unpack_wave)
         self.arrival_cfgs = [self.facet_configs[j] for j in self.sharding.arrival_order]
         # cooperative facets: one single-facet SwiftlyForward per facet over the waves this rank owns; its band buffer
         # is assembled by the band-row exchange of prepare_all_facets instead of its own K1
@@ -418,6 +419,7 @@ class DistributedForward:
                     fwd = SwiftlyForward(swiftly_config, [(cfg, ghost)], lru_forward=lru_forward, subgrid_configs=my_plan,
                                          wave_axis=1)
                     fwd.dtype = self.dtype
+                    fwd.axis1_fused = False  # (its band buffer comes from the band-row exchange)
                     self._coop[j] = fwd
         self._announce_wave_order()
 
@@ -563,7 +565,7 @@ class DistributedForward:
         cfgs = self._arrival_cfgs(key)
         blocks = recv.view(len(cfgs), len(mine), m, m)  # facets in arrival order
         res = finish_from_blocks(self.core, blocks, cfgs, [sgs[i] for i in mine], transformed=self.fused,
-                                 placed=self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False)))
+                                 placed=int(self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False))))
         return mine, res
 
     def start_wave(self, sgs):

@@ -420,11 +420,23 @@ class SwiftlyForward(WavePrefetch):
                 core.band_for_offsets([sg.off1 for sg in self._plan]) if self._plan is not None else (0, core.yN_size)
             )
             F, yB = len(self._facet_info), self._facet_info[0][1][0]
-            bands = torch.empty((F, yB, core.band_columns(self._band)), dtype=self.dtype, device=core.device)
+            mode = self.__dict__["_axis1_mode"] = self._choose_axis1_mode()
+            if mode == 2:
+                # axis-1-first pipeline, contiguous-axis finish fused into K1: per facet row the two half spectra of every
+                # planned window instead of the band (core.prepare_facet_window_spectra)
+                keys = sorted(self._planned_keys)
+                self.__dict__["_window_of"] = {k: w for w, k in enumerate(keys)}
+                starts = torch.tensor(core.window_starts(self._band, keys), dtype=torch.int32, device=core.device)
+                bands = torch.empty((F, yB, len(keys) * core.xM_yN_size), dtype=self.dtype, device=core.device)
+            else:
+                bands = torch.empty((F, yB, core.band_columns(self._band)), dtype=self.dtype, device=core.device)
             for j, cfg in enumerate(self.facet_configs):
                 data = self._ingest.ready(j)
                 t0 = timer.start() if timer is not None else None
-                core.prepare_facet_band(data, cfg.off1, self._band, out=bands[j])
+                if mode == 2:
+                    core.prepare_facet_window_spectra(data, cfg.off1, self._band, starts, bands[j])
+                else:
+                    core.prepare_facet_band(data, cfg.off1, self._band, out=bands[j])
                 if timer is not None:
                     timer.stop("K1_full_facet_transform", t0)
                 self._ingest.prefetch(j + 1)
@@ -449,17 +461,44 @@ class SwiftlyForward(WavePrefetch):
             self._wave_rowmaps[key] = self.core.subgrid_column_rows(by_key.get(key, []))
         return self._wave_rowmaps[key]
 
+    #: may ``axis1_first="fused"`` fuse the contiguous-axis finish into K1 (window half spectra)?  The multi-GPU classes
+    #: exchange band rows / blocks of the per-wave form and switch this off for their local objects.
+    axis1_fused = True
+
+    def _choose_axis1_mode(self):
+        """0: default order; 1: axis-1-first with a row pass per wave (core.finish_axis1_rows; ``axis1_first=True``);
+        2: axis-1-first with the finish fused into K1 (``axis1_first="fused"``; needs a plan -- the windows are the plan's
+        waves -- and a configuration with core.supports_window_spectra, else 1)."""
+        if not (self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False))):
+            return 0
+        if (self.core.axis1_first == "fused" and self.axis1_fused and self._plan is not None and self._band is not None and
+                self.core.supports_window_spectra(self._band, self._facet_info[0][1][1],
+                                                  [cfg.off1 for cfg in self.facet_configs])):
+            return 2
+        return 1
+
     def _axis1(self):
-        """is this object running the axis-1-first band pipeline (``SwiftlyConfig(axis1_first=True)``, wave_axis = 1)?"""
-        return self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False))
+        """the axis-1-first mode of this object (``SwiftlyConfig(axis1_first=True)``, wave_axis = 1): 0 = off, 1 = row pass
+        per wave, 2 = fused into K1 (decided when the facets are prepared); doubles as the ``placed`` argument of the
+        subgrid side"""
+        mode = self.__dict__.get("_axis1_mode")
+        if mode is None:
+            mode = self._choose_axis1_mode() if self.BF_Fs_persist is None else 0
+        return mode
 
     def _k2_source(self, off1):
         """``(bands, band)`` that K2 of wave ``off1`` reads: the K1 band buffers and the plan's band -- or, in the
         axis-1-first pipeline (``SwiftlyConfig(axis1_first=True)``), the rows finished along the contiguous axis for this
         wave (core.finish_axis1_rows, on the current stream) with the band that is exactly the wave's window."""
         bands = self.BF_Fs_persist
-        if not self._axis1():
+        mode = self._axis1()
+        if not mode:
             return bands, self._band
+        if mode == 2:  # the window's half spectra: m columns of the K1 output, read as a band that is exactly the window
+            core = self.core
+            m, w = core.xM_yN_size, self._window_of[int(off1)]
+            start = (core.window_starts(self._band, [off1])[0] + self._band[0]) % core.yN_size
+            return bands[:, :, w * m:(w + 1) * m], (start, m)
         return self.core.finish_axis1_rows(bands, [cfg.off1 for cfg in self.facet_configs], self._band, off1)
 
     def _get_wave_columns(self, off1):

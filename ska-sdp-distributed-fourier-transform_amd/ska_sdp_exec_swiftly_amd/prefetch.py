@@ -169,10 +169,10 @@ class WavePrefetch:
         # (r5) second and later K2 of the free-running chain: the chunk streams of the four-step run on from the previous
         # wave's chunks instead of being forked behind its join -- the band buffers were complete before the first (forking)
         # call of this object, Q is a fresh block (swiftly_hip_chain_chunk_streams; 40 us of idle GPU per wave otherwise)
-        # (axis-1-first pipeline: K2 reads rows that finish_axis1_rows has just written on the side stream -- its chunk
-        # streams must fork behind them every time)
+        # (axis-1-first pipeline with a row pass per wave: K2 reads rows that finish_axis1_rows has just written on the side
+        # stream -- its chunk streams must fork behind them every time)
         chain = (_knobs()._PREFETCH_DEPTH >= 2 and ready is not None and _knobs()._CHAIN_K2
-                 and self.__dict__.get("_k2_chain_forked", False) and not getattr(core, "axis1_first", False))
+                 and self.__dict__.get("_k2_chain_forked", False) and self._axis1() != 1)
         with torch.cuda.stream(side):
             Q = torch.empty((len(self.facet_configs), n_rows, core.xM_yN_size), dtype=self.dtype, device=core.device)
             src, band = self._k2_source(off1)

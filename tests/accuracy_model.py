@@ -109,12 +109,18 @@ def forward_chain(P, facet, fo, so, bits, scratch_split=None, round_stores=True)
     return rnd(out).astype(complex)
 
 
-def forward_chain_reordered(P, facet, fo, so, bits, scratch_split=None, round_stores=True):
+def forward_chain_reordered(P, facet, fo, so, bits, scratch_split=None, round_stores=True, halves=False):
     """The r5 review's reordering (its item 3): axis 1 is FINISHED before the strided-axis work starts.  K1's epilogue takes
     the wave's m-column window of the transformed row, runs the axis-1 half of add_to_subgrid on it (m-point transform x Fn,
     core.py:255-285) and stores THAT; K2 and K3 then work on data that carries the axis-0 window only, and sum_finish loses
     its m-point transforms (placement + xM-point inverse + crop).  Same stored intermediates otherwise.  bits as in
-    forward_chain (k1 covers the fused epilogue)."""
+    forward_chain (k1 covers the fused epilogue).
+
+    halves=True: the form that CAN live in the K1 epilogue of the HIP kernels (SwiftlyConfig(axis1_first="fused")) -- each of
+    a row's two workgroups holds the outputs of one parity, so K1 stores the two decimation-in-time half spectra of the window
+    (m/2-point transforms of the even / odd window samples); K2 and K3 run on those, and the radix-2 step that joins them,
+    the phase of the window rotation and Fn follow K3.  The halves are ALIASED (frequency u folded onto u + m/2): the column
+    passes round at the level of the window's leakage that Fn would have suppressed."""
     c = orc.OracleCore(P["W"], P["N"], P["xM"], P["yN"])
     yB, yN, xA, xM, m = P["yB"], P["yN"], P["xA"], P["xM"], c.xM_yN_size
     rnd = _c64 if round_stores else (lambda a: a)
@@ -133,8 +139,16 @@ def forward_chain_reordered(P, facet, fo, so, bits, scratch_split=None, round_st
     k1 = _centred(k1, 1, t, True)
     col = c.extract_from_facet(k1, so[1], 1)                      # [yB, m], gather
     fn = c.Fn.astype(numpy.float32).astype(wt[t])
-    h = _centred(col, 1, t, False)
-    h = rnd(h[:, (k + sp[1]) % m] * fn[None, :])                  # stored: [yB, m] per (facet, wave)
+    if halves:
+        s1 = (so[1] * yN // P["N"]) % m
+        b = col[:, (k + s1) % m]                                  # window samples b[i]: col[(i + s) mod m] = b[i]
+        ct = numpy.complex64 if t == 32 else numpy.complex128
+        g0 = scipy.fft.fft(b[:, 0::2].astype(ct), axis=1)
+        g1 = scipy.fft.fft(b[:, 1::2].astype(ct), axis=1)
+        h = rnd(numpy.concatenate([g0, g1], axis=1))              # stored: [yB, m] = the two half spectra
+    else:
+        h = _centred(col, 1, t, False)
+        h = rnd(h[:, (k + sp[1]) % m] * fn[None, :])              # stored: [yB, m] per (facet, wave)
     # K2: pad + shift + inverse transform along axis 0 on data that carries the axis-0 window only
     t = bits["k2"]
     k2 = numpy.zeros((yN, m), dtype=h.dtype)
@@ -148,6 +162,15 @@ def forward_chain_reordered(P, facet, fo, so, bits, scratch_split=None, round_st
     g = rnd(g[(k + sp[0]) % m, :] * fn[:, None])
     # sum_finish without its m-point transform: placement along axis 1, xM-point inverse, crop
     t = bits["sf"]
+    if halves:  # join the halves: Fk[ck] = W^((s - m/2) u) (G0[u'] + W^u G1[u']), u = ck - m/2; Z[k] = Fn[k] Fk[(k + s'1) mod m]
+        ct = numpy.complex64 if t == 32 else numpy.complex128
+        ck = (k + sp[1]) % m
+        u = ck - m // 2
+        W = lambda e: numpy.exp(-2j * numpy.pi * ((e % m) / m)).astype(ct)  # noqa: E731
+        fnt = c.Fn.astype(numpy.float32).astype(wt[t])
+        gc = g.astype(ct)
+        z = gc[:, u % (m // 2)] + W(u)[None, :] * gc[:, m // 2 + u % (m // 2)]
+        g = z * (W((s1 - m // 2) * u) * fnt)[None, :]
     acc = numpy.zeros((m, xM), dtype=numpy.complex64 if t == 32 else numpy.complex128)
     acc[:, (k + xM // 2 - m // 2 + sp[1]) % xM] = g
     i = numpy.arange(xA)
@@ -206,6 +229,19 @@ def chain_error(bits, P=PROBE, fo=PROBE_FO, so=PROBE_SO, seed=5, split=(32, 64),
     yB = P["yB"]
     facet = _c64(rng.standard_normal((yB, yB)) + 1j * rng.standard_normal((yB, yB)))
     return rel_rmse((chain or forward_chain)(P, facet, fo, so, bits, split), reference_chain(P, facet, fo, so))
+
+
+def halves_error(P=None, fo=None, so=None, seed=5, bits=None):
+    """end-to-end error of the axis-1-first chain with the contiguous-axis finish split into half spectra (float32 everywhere
+    unless ``bits`` says otherwise) on the probe configuration"""
+    P, fo, so = P or PROBE, fo or PROBE_FO, so or PROBE_SO
+    rng = numpy.random.default_rng(seed)
+    yB = P["yB"]
+    facet = _c64(rng.standard_normal((yB, yB)) + 1j * rng.standard_normal((yB, yB)))
+    want = reference_chain(P, facet, fo, so)
+    got = forward_chain_reordered(P, facet, fo, so, bits or dict(k1=32, k2=32, k3=32, sf=32, k5=32), scratch_split=(32, 64),
+                                  halves=True)
+    return rel_rmse(got, want)
 
 
 def reordered_budget():

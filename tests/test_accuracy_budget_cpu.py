@@ -47,3 +47,18 @@ def test_axis1_first_order_removes_the_double_window_from_the_column_passes():
     assert 2e-7 < floor < 6e-7            # 3.7e-7
     for st in ("k1", "k2", "k3", "sf", "k5"):
         assert rows[f"reordered: float32 arithmetic in {st} only"] < 2e-6
+
+
+def test_fusing_the_axis1_finish_into_k1_costs_part_of_the_gain():
+    """(r6) The form of the axis-1-first order that fits the K1 epilogue of the HIP kernels (axis1_first="fused"): each of a
+    row's two workgroups holds one output parity, so what K1 can store per window are the two decimation-in-time HALF spectra;
+    K2 / K3 run on those and the radix-2 join + Fn follow.  The halves are aliased (u folded onto u + m/2), so the column
+    passes -- and even the complex64 STORES -- round at the level of the window leakage that Fn has not yet suppressed:
+    7.4e-6 all-float32 on the probe configuration (default order 1.3e-5, row pass per wave 2.1e-6), 1.8e-6 with float64
+    arithmetic everywhere (3.7e-7 for the row pass).  HIP kernels on the N = 65536 workload: 5.8e-6 against 1.03e-5 / 2.04e-6."""
+    all32 = am.halves_error()
+    stores_only = am.halves_error(bits=dict(k1=64, k2=64, k3=64, sf=64, k5=64))
+    print(f"{all32:.3e}  halves: float32 arithmetic everywhere")
+    print(f"{stores_only:.3e}  halves: float64 arithmetic, complex64 intermediates")
+    assert 5e-6 < all32 < 9.5e-6
+    assert 1.2e-6 < stores_only < 2.6e-6

@@ -393,10 +393,52 @@ def test_finish_axis1_rows_matches_oracle():
             assert rel < 2e-6, (sub_off1, f, rel)
 
 
+def test_window_spectra_store_of_k1_matches_the_band_store():
+    """(r6) the forward K1 with the contiguous-axis finish fused in (swiftly_hip_prepare_facet_window_spectra): for every
+    planned window w the two decimation-in-time half spectra of the window samples, computed by the workgroup that holds
+    the outputs of that parity.  Checked against numpy transforms of the SAME kernel's band store (which the oracle pins:
+    test_prepare_facet_band_*), including a window at the very start / end of the band, odd and even window starts and a
+    band that wraps around the padded axis."""
+    import torch
+
+    core, _ = core64()
+    rng = numpy.random.default_rng(17)
+    rows, size, m = 10, 352, 512
+    facet = (rng.standard_normal((rows, size)) + 1j * rng.standard_normal((rows, size))).astype(numpy.complex64)
+    dev = torch.from_numpy(facet).cuda()
+    for foff, wave_off1s in ((0, [0, 928, 3 * 928, -2 * 928]), (64 * 352, [-928, 5 * 928, 7 * 928 + 2, 12 * 928 + 6]),
+                             (-32 * 352, [30 * 928, 33 * 928, 35 * 928 + 4])):
+        band = core.band_for_offsets(wave_off1s)
+        assert core.supports_window_spectra(band, size, [foff])
+        starts = core.window_starts(band, wave_off1s)
+        assert min(starts) >= 0 and max(starts) + m <= band[1]
+        plain = core.prepare_facet_band(dev, foff, band).cpu().numpy()
+        pc = band_cols(yN64, band)
+        sd = torch.tensor(starts, dtype=torch.int32, device="cuda")
+        out = torch.full((rows, len(starts) * m), float("nan"), dtype=torch.complex64, device="cuda")
+        core.prepare_facet_window_spectra(dev, foff, band, sd, out)
+        got = out.cpu().numpy()
+        assert numpy.isfinite(got.view(numpy.float32)).all()
+        for w, d in enumerate(starts):
+            i = numpy.arange(m)
+            b = plain[:, pc[(band[0] + d + i) % yN64]].astype(complex)          # logical window samples
+            for p in (0, 1):
+                want = numpy.fft.fft(b[:, p::2], axis=1)
+                rel = relrms(got[:, w * m + p * (m // 2):w * m + (p + 1) * (m // 2)], want)
+                assert rel < 5e-7, (foff, w, p, rel)
+    # unsupported shapes are refused, not approximated: a band with more kept columns per parity than the LDS stage holds
+    wide = (0, 2 * core.WINDOW_SPECTRA_STAGE_COLUMNS + 2)
+    assert not core.supports_window_spectra(wide, size, [0])
+    with pytest.raises(Exception):
+        core.prepare_facet_window_spectra(dev, 0, wide, torch.zeros(1, dtype=torch.int32, device="cuda"),
+                                          torch.empty((rows, m), dtype=torch.complex64, device="cuda"))
+
+
 def test_axis1_first_pipeline_matches_oracle_and_default_order():
     """(r6) SwiftlyConfig(axis1_first=True): the forward band pipeline with the contiguous axis finished before K2 / K3
     gives the oracle's subgrids (tighter than the default order: its float32 rounding acts on singly windowed data) in
-    any request order, with and without the planned-wave prefetch."""
+    any request order, with and without the planned-wave prefetch -- in both of its forms: the finish fused into K1 (window
+    half spectra, joined by sum_finish_facets; what a planned pass on this configuration runs) and a row pass per wave."""
     import torch
 
     import ska_sdp_exec_swiftly_amd as sw
@@ -413,24 +455,35 @@ def test_axis1_first_pipeline_matches_oracle_and_default_order():
     for c in sg_cfgs:
         waves.setdefault(c.off1, []).append(c)
     ref = sw.SwiftlyForward(cfg0, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
-    for prefetch in (True, False):
+    for prefetch, fused in ((True, True), (False, True), (True, False), (False, False)):
         old = sw.api._PREFETCH
         sw.api._PREFETCH = prefetch
         try:
+            cfg.core.axis1_first = "fused" if fused else True
             fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
             for key in (sorted(waves) if prefetch else sorted(waves)[::-1]):
                 got = fwd.get_wave(waves[key]).cpu().numpy()
                 base = ref.get_wave(waves[key]).cpu().numpy()
                 for k, c in enumerate(waves[key]):
                     want = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))
-                    assert relrms(got[k], want) < 4e-6, (prefetch, key, k, relrms(got[k], want))
+                    assert relrms(got[k], want) < 4e-6, (prefetch, fused, key, k, relrms(got[k], want))
                     assert relrms(got[k], base[k]) < 3e-5
+            assert fwd._axis1() == (2 if fused else 1)  # pylint: disable=protected-access
         finally:
             sw.api._PREFETCH = old
+    # without a plan there are no windows to fuse: the row pass per wave
+    cfg.core.axis1_first = "fused"
+    fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), wave_axis=1)
+    key = sorted(waves)[1]
+    got = fwd.get_wave(waves[key]).cpu().numpy()
+    assert fwd._axis1() == 1  # pylint: disable=protected-access
+    for k, c in enumerate(waves[key]):
+        assert relrms(got[k], so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))) < 4e-6
     # pickling carries the switch (core.py:512-525: only parameters travel)
     import pickle
 
-    assert pickle.loads(pickle.dumps(cfg.core)).axis1_first
+    assert pickle.loads(pickle.dumps(cfg.core)).axis1_first == "fused"
+    assert sw.SwiftlyConfig(backend="hip", axis1_first=True, **P).core.axis1_first is True
 
 
 def test_axis1_first_through_the_multi_gpu_classes():
