@@ -726,7 +726,7 @@ def main():
                     help="multi-GPU: 'group' (default) = every wave's subgrids are finished by ONE rank and the waves are "
                          "exchanged in groups of n_gpus waves with distinct owners (one balanced all-to-all per group); "
                          "'wave' = the subgrids of every wave dealt out round-robin, one all-to-all per wave")
-    ap.add_argument("--axis1-first", nargs="?", const="rows", default=None, choices=["rows", "fused"],
+    ap.add_argument("--axis1-first", nargs="?", const="rows", default=None, choices=["rows", "fused", "halves"],
                     help="time the axis-1-first forward pipeline: 'rows' = SwiftlyConfig(axis1_first=True), the contiguous axis "
                          "finished by a row pass per wave before the strided-axis transforms (float32 arithmetic at ~5x "
                          "smaller error); 'fused' = axis1_first='fused', that finish inside K1 (window half spectra; cheaper, "
@@ -798,7 +798,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     p = wl["params"]
-    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, axis1_first={None: False, "rows": True, "fused": "fused"}[args.axis1_first], **p)
+    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, axis1_first={None: False, "rows": True, "fused": "fused", "halves": "halves"}[args.axis1_first], **p)
     all_facet_cfgs = sw.make_full_facet_cover(cfg)
     # a rank holds at most `max_facets_per_rank` facets (HBM capacity): with too few ranks only the first cap * world
     # facets of the cover take part -- a stated subset; contributions are counted for those only
@@ -952,8 +952,8 @@ def main():
             kept = {k: v for d in gathered for k, v in d.items()}
         if rank == 0:
             parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept,
-                                     tol={None: wl.get("parity_tol"), "rows": AXIS1_FIRST_PARITY_TOL,
-                                          "fused": AXIS1_FUSED_PARITY_TOL}[args.axis1_first])
+                                     tol={None: wl.get("parity_tol"), "rows": AXIS1_FIRST_PARITY_TOL, "fused": AXIS1_FIRST_PARITY_TOL,
+                                          "halves": AXIS1_FUSED_PARITY_TOL}[args.axis1_first])
 
     # (r6) the axis-1-first pipeline beside the timed default order: same objects, same facets, float32 arithmetic -- the
     # contiguous axis finished (m-point transform x Fn per wave window) BEFORE K2 / K3, which then see ONE facet window
@@ -990,13 +990,20 @@ def main():
             **axis1_leg(True, AXIS1_FIRST_PARITY_TOL),
         )
         accurate["fused_into_k1"] = dict(
-            what="SwiftlyConfig(axis1_first='fused'): the same order with the contiguous-axis finish inside K1 -- each of a "
+            what="SwiftlyConfig(axis1_first='fused'): the same order with the contiguous-axis finish in the epilogue of K1 -- "
+                 "one persistent workgroup per CU owns whole rows (both output parities), parks the band of a row in an "
+                 "L2-resident scratch slot and stores the finished window rows of every planned wave; no band buffer in HBM, "
+                 "no row pass per wave; K2 / K3 / placed sum_finish as above",
+            **axis1_leg("fused", AXIS1_FIRST_PARITY_TOL),
+        )
+        accurate["halves_from_k1"] = dict(
+            what="SwiftlyConfig(axis1_first='halves'): the same order with the contiguous-axis finish inside the TWO-workgroup K1 -- each of a "
                  "row's two workgroups stores the half spectrum (m/2-point transform) of its output parity for every planned "
                  "window instead of the band; K2 / K3 unchanged on the halves, sum_finish_facets joins them (radix-2 step, "
                  "window phase, Fn).  No band buffer, no row pass per wave; the column passes work on ALIASED spectra "
                  "(frequency u folded onto u + m/2, where Fn has not yet suppressed the window's leakage), which costs "
                  "part of the accuracy gain",
-            **axis1_leg("fused", AXIS1_FUSED_PARITY_TOL),
+            **axis1_leg("halves", AXIS1_FUSED_PARITY_TOL),
         )
 
     # the float64-arithmetic column passes (column_precision = 64) beside the timed float32 configuration: same objects,

@@ -450,6 +450,18 @@ int swiftly_hip_prepare_facet_window_spectra(swiftly_hip_t* h, int dtype, const 
                                              int64_t band_start, int64_t band_len, int64_t other_axis_size,
                                              int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
                                              void* stream);
+/* ... and the form that finishes the contiguous axis COMPLETELY inside K1 (r6): one persistent workgroup per CU owns whole
+ * rows -- both output parities -- stages the band of a row in LDS (it never reaches memory) and stores for every window w
+ * exactly what finish_axis1_rows produces for wave w from that band:
+ *     out[row][w*m ..] = parity-split window band of  Fn[k] cfft_m(window w)[(k + s'1) mod m]
+ * so the columns [w*m, (w+1)*m) go to prepare_facet_columns / wave_facet_side with the band (window start, m) and the
+ * blocks to wave_subgrid_side_placed.  Same shape limits as prepare_facet_window_spectra, with a band of at most ~13000
+ * columns (LDS stage) instead of the per-parity limit. */
+int swiftly_hip_prepare_facet_window_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
+                                          int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
+                                          int64_t band_start, int64_t band_len, int64_t other_axis_size,
+                                          int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
+                                          void* stream);
 int swiftly_hip_wave_subgrid_side_halves(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
                                          int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
                                          int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s,

@@ -205,6 +205,10 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
         a.ld_win4 = (w4cache && win4_enabled()) ? w4cache->get(a.ld_win, c_, a.ld_len, NS, n_, SEGLEN, s) : nullptr; \
         a.twc = (a.ld_win4 && win4_enabled() >= 2) ? w4cache->twc : nullptr;               \
         if (a.win_d && !a.twc) return -2;                                                      \
+        if (a.win_full || !a.win_d) {                                                          \
+            const int ew_ = launch_row_pass_whole(a, NS, tw14, tw_full, s);                    \
+            if (ew_ != -2 || a.win_full) return ew_;                                           \
+        }                                                                                      \
         if (a.win_d)                                                                           \
             launch_band_inst<GC, PAIR, true, 3, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
         else if (a.twc)                                                                        \
@@ -269,8 +273,8 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
         // window-spectra store (ST = 3): 32768-point rows, 512-column windows, the kept columns of one parity staged in the
         // LDS the 256-point window transforms leave free
         const int ncol = (a.band_len + 1) >> 1;
-        if (logn != 15 || a.win_logm != 9 || a.nwin <= 0 || !a.tw_win || a.band_len <= 0 || ncol > row_pass_window_stage_columns())
-            return -2;
+        if (logn != 15 || a.win_logm != 9 || a.nwin <= 0 || a.band_len <= 0) return -2;
+        if (!a.win_full && (!a.tw_win || ncol > row_pass_window_stage_columns())) return -2;
         const bool pair_ok_w = !(a.ld_a & 1) && !(a.ld_len & 1) && !(a.in_pitch & 1) && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
         if (!pair_ok_w || !a.ld_win || !(a.conj_ld && a.conj_st)) return -2;
         return launch_band_geo<BandGeo5, true>(a, tw_half, tw_full, s, w4);
@@ -359,6 +363,7 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5C, false, 2, 13, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5C, false, 2, 16, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo64k, true, 1, 44, false, 1>();
+        if (!rcb) rcb = init_row_pass_whole();
         if (!rcb) rcb = init_band_geo<BandGeo4>();
         if (!rcb) rcb = init_band_geo<BandGeo64k>();
         if (!rcb) rcb = init_band_geo<BandGeo16k>();

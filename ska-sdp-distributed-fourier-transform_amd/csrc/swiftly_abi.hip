@@ -1492,7 +1492,8 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
 static int prepare_facet_band_rows_impl(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                         int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                         int64_t band_start, int64_t band_len, int64_t other_axis_size,
-                                        int64_t other_axis_row0, const int32_t* win_d, int64_t nwin, void* stream) {
+                                        int64_t other_axis_row0, const int32_t* win_d, int64_t nwin, int win_full,
+                                        void* stream) {
     const int fold_other_axis_window = other_axis_size > 0;
     if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");
     if (fold_other_axis_window && (other_axis_row0 < 0 || other_axis_row0 + rows > other_axis_size))
@@ -1540,10 +1541,18 @@ static int prepare_facet_band_rows_impl(swiftly_hip_t* h, int dtype, const void*
         r.win_d = win_d; r.nwin = (int)nwin; r.win_logm = h->log_m;
         r.tw_win = h->log_m > 1 ? twiddles<float>(h, h->log_m - 1) : nullptr;
     }
+    if (win_d && win_full) {  // complete window rows (whole-row kernel)
+        r.win_full = 1;
+        r.win_sp = pmod(floordiv(facet_off * h->xM, h->N), (int)h->m);
+        r.win_fn = h->fn_f;
+        r.win_tw_m = twiddles<float>(h, h->log_m);
+        r.win_twc_m = h->log_m >= 6 ? compact_twiddles(h, h->log_m, h->log_m - 6) : nullptr;
+    }
     int e = launch_row_pass_band_n(h->log_yN, r, twh, twf, (hipStream_t)stream, &h->win4);
     if (e == -2)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_window_spectra: needs yN_size 32768, contribution size 512, even facet "
-                    "size / offset / row stride and at most %d kept columns per output parity", row_pass_window_stage_columns());
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_window_%s: needs yN_size 32768, contribution size 512, even facet "
+                    "size / offset / row stride%s", r.win_full ? "rows" : "spectra",
+                    r.win_full ? " and a band of at most 12800 physical columns" : " and at most 5888 kept columns per output parity");
     if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -1553,7 +1562,7 @@ int swiftly_hip_prepare_facet_band_rows(swiftly_hip_t* h, int dtype, const void*
                                         int64_t band_start, int64_t band_len, int64_t other_axis_size,
                                         int64_t other_axis_row0, void* stream) {
     return prepare_facet_band_rows_impl(h, dtype, in, rows, facet_size, in_row_stride, out, out_row_stride, facet_off, band_start,
-                                        band_len, other_axis_size, other_axis_row0, nullptr, 0, stream);
+                                        band_len, other_axis_size, other_axis_row0, nullptr, 0, 0, stream);
 }
 
 // (r6, axis-1-first pipeline) prepare_facet_band_rows whose kernel, instead of storing the band, stores for each of the
@@ -1568,7 +1577,22 @@ int swiftly_hip_prepare_facet_window_spectra(swiftly_hip_t* h, int dtype, const 
     if (!window_starts || nwindows <= 0) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_spectra: no windows");
     if (h && out_row_stride < nwindows * h->m) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_spectra: output rows hold nwindows * m columns");
     return prepare_facet_band_rows_impl(h, dtype, in, rows, facet_size, in_row_stride, out, out_row_stride, facet_off, band_start,
-                                        band_len, other_axis_size, other_axis_row0, window_starts, nwindows, stream);
+                                        band_len, other_axis_size, other_axis_row0, window_starts, nwindows, 0, stream);
+}
+
+// (r6, axis-1-first pipeline) ... and the form that finishes the contiguous axis COMPLETELY inside K1: one persistent workgroup
+// per CU owns whole rows (both output parities; swiftly_rowwhole.h), stages the band of a row in LDS and stores, for every
+// window w, what swiftly_hip_finish_axis1_rows would produce for wave w from that band:
+// out[row][w*m ..] = parity-split window band of  Fn[k] cfft_m(window w)[(k + s'1) mod m].
+int swiftly_hip_prepare_facet_window_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
+                                          int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
+                                          int64_t band_start, int64_t band_len, int64_t other_axis_size,
+                                          int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
+                                          void* stream) {
+    if (!window_starts || nwindows <= 0) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_rows: no windows");
+    if (h && out_row_stride < nwindows * h->m) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_rows: output rows hold nwindows * m columns");
+    return prepare_facet_band_rows_impl(h, dtype, in, rows, facet_size, in_row_stride, out, out_row_stride, facet_off, band_start,
+                                        band_len, other_axis_size, other_axis_row0, window_starts, nwindows, 1, stream);
 }
 
 int swiftly_hip_finish_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,

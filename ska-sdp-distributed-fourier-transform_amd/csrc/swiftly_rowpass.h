@@ -83,6 +83,16 @@ struct RowPassArgs {
     const int* win_d;     // device table, nwin entries: (first logical column of window w - band_start) mod N
     int nwin, win_logm;
     const cx<float>* tw_win;  // twiddle table of length m / 2
+    // WINDOW-ROWS store (r6, whole-row kernel swiftly_rowwhole.h, WIN instances): one workgroup owns BOTH output parities of a
+    // row, so the complete contiguous-axis half of add_to_subgrid runs in its epilogue (what swiftly_hip_finish_axis1_rows does
+    // per wave in a pass of its own): the band of the row is staged in LDS (the exchange buffer, free after the last gather),
+    // and for every window w   out[row][w * m + parity-split position of (kk - s_w) mod m] =
+    // Fn[kk] cfft_m(window w)[(kk + win_sp) mod m]   -- the layout finish_axis1_rows produces for wave w.
+    int win_full;                 // 1: this form (needs win_d / nwin / win_logm above)
+    int win_sp;                   // s'1 = floor(facet_off1 * xM / N) mod m of this facet
+    const float* win_fn;          // Fn[m]
+    const cx<float>* win_tw_m;    // twiddle table of length m and its compact sections for m / 64 points per lane
+    const cx<float>* win_twc_m;
 };
 
 // physical column of logical (centred) column ck in a parity-split band buffer, or -1
@@ -854,6 +864,10 @@ int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<f
 int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s,
                            Win4Cache* w4 = nullptr);
 int row_pass_band_occupancy();
+int launch_row_pass_whole(const RowPassArgs& a, int nseg, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s);
+int init_row_pass_whole();
+int row_pass_whole_grid();  // workgroups of a whole-row launch (one per CU)
+int row_pass_whole_stage_columns();  // physical band columns (both parities) the window-rows epilogue can stage
 int row_pass_window_stage_columns();  // kept columns per output parity the window-spectra store (RowPassArgs::win_d) can stage
 
 }  // namespace swf

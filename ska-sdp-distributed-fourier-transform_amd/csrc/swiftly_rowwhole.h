@@ -20,6 +20,7 @@
 // (same products, same tables): the outputs are bit-identical (tests/test_hip_band_pipeline_gpu.py).
 #pragma once
 #include "swiftly_rowpass.h"
+#include "swiftly_sumfinish.h"  // SFCompact: the m-point engine of the window epilogue
 
 // timing-only ablations of the whole-row kernel (tools/build_variant.sh ... -DSWF_WHOLE_ABL=mask; results are wrong):
 // 1 = no memory behind the loads (empty descriptors), 2 = no stores, 4 = no LDS traffic (barriers stay), 8 = no butterflies
@@ -106,7 +107,9 @@ __device__ __forceinline__ void opaque_values(cx<float> (&v)[K]) {
     });
 }
 
-template <int NSEG>
+// WIN (RowPassArgs::win_full): the band of a row is staged in the exchange buffer (free once the last gather is done) and the
+// epilogue finishes the contiguous axis for every planned window (see RowPassArgs) -- the K1 of the axis-1-first pipeline.
+template <int NSEG, bool WIN = false>
 __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                 cx<float>* __restrict__ gout,
                                                                 const cx<float>* __restrict__ tw,
@@ -300,8 +303,16 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
                 f32x2 val;
                 const f32x2 vv = pkv(v);
                 asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(val) : "v"(vv), "v"(sc));
-                const unsigned off = (off0 + (unsigned)(r << (LNS + 3))) & (unsigned)((N << 2) - 1);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)off, 0, 0);
+                if constexpr (WIN) {
+                    // the band of the row is STAGED in the exchange buffer (free by now), laid out like a band buffer row
+                    const int d = (base + lane2) & (N - 1);
+                    f32x2* __restrict__ st = reinterpret_cast<f32x2*>(buf) + par * A.band_half + (d >> 1);
+                    if (base + 126 < A.band_len) *st = val;          // wave-uniform: every lane inside
+                    else if (d < A.band_len) *st = val;
+                } else {
+                    const unsigned off = (off0 + (unsigned)(r << (LNS + 3))) & (unsigned)((N << 2) - 1);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val), rs_out, (int)off, 0, 0);
+                }
             });
         };
         auto scatter1 = [&](cx<float> (&x)[P]) {  // output of the radix-16 phase (adjacent virtual threads per lane)
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
         // up the CU's address path for 3000 cycles (21 requests x 8 waves x 16 cycles), into the next row's first phase.
         constexpr int NLATE = 2 * (NG - E3) + NG, SLOT0 = 32 - NLATE;
         static_assert(SLOT0 >= 8, "the late requests need registers the band store has already freed");
+        if constexpr (WIN) wg_sync();   // every wave has gathered B: the exchange buffer becomes the band stage
         store_half(xa, 0, rphi0, region0, [&](auto sI) {
 #ifndef SWF_WHOLE_NOPF
             constexpr int i = decltype(sI)::value - SLOT0;
@@ -425,6 +437,40 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
         part(IL2{}, IP{}, P0_{}, xb, nx);
         part(IL2{}, IP{}, P1_{}, xb, nx);
         store_half(xb, 1, rphi1, region1, [](auto) {});
+        if constexpr (WIN) {
+            // -- window epilogue: the row's band is staged once every wave has passed the barrier ----------------------------
+            using GM = Geo<float, 9, 3, G::NT, false>;   // m = 512 (host-checked): one wave per transform, 8 points per lane
+            static_assert(GM::T == 64 && GM::WAVE_ROWS && GM::LDS_BYTES <= G::LDS_BYTES, "window transform geometry");
+            constexpr int M = GM::N;
+            wg_sync();
+            const int lane = tt & 63;
+            const int wv = __builtin_amdgcn_readfirstlane(tt >> 6);
+            const cx<float>* __restrict__ stage = buf;
+            cx<float>* ex = buf + 2 * A.band_half;       // the m-point exchanges behind the stage (host-checked: it fits)
+            cx<float>* __restrict__ orow = gout + (long long)urow * A.out_pitch;
+            const int sp = A.win_sp;
+            for (int w = wv; w < A.nwin; w += G::NT / 64) {   // wave-uniform
+                const int D = __builtin_amdgcn_readfirstlane(A.win_d[w]);
+                const int s = (A.band_start + D - (N / 2 - M / 2)) & (M - 1);   // off1 yN / N of the wave, mod m
+                cx<float> xw[GM::P];
+                static_for<0, GM::P>([&](auto vI) {
+                    constexpr int v = decltype(vI)::value;
+                    const int ci = (lane + v * 64) ^ (M >> 1);   // centred element of x (plain index lane + 64 v)
+                    const int i = (ci - s) & (M - 1);            // window element that lands there
+                    const int d = D + i;                         // its band distance (windows lie inside the band)
+                    xw[v] = stage[(d & 1) * A.band_half + (d >> 1)];
+                });
+                cx<float>* __restrict__ ow = orow + (long long)w * M;
+                fft_phases<SFCompact<GM>, float, 0>(xw, lane, wv, false, ex, A.win_tw_m, [&](int e, cx<float> v) {
+                    const int ck = e ^ (M >> 1);
+                    const int kk = (ck - sp) & (M - 1);
+                    const float wgt = A.win_fn[kk];
+                    const int i2 = (kk - s) & (M - 1);
+                    ow[(i2 & 1) * (M >> 1) + (i2 >> 1)] = cx<float>{v.x * wgt, v.y * wgt};
+                }, nullptr, A.win_twc_m);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         SWF_WTRACE(11);
         if (!more) break;
         row = next;

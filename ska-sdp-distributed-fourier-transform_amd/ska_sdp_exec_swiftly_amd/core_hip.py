@@ -144,7 +144,7 @@ class SwiftlyCoreHip:
         # (r6) axis-1-first forward band pipeline (finish_axis1_rows): the streaming classes read this switch
         # False / True / "fused" (SwiftlyConfig): the axis-1-first order of the band pipeline, with a row pass per wave or --
         # where the configuration allows -- with the contiguous-axis finish fused into K1 (window half spectra)
-        self.axis1_first = "fused" if axis1_first == "fused" else bool(axis1_first)
+        self.axis1_first = axis1_first if axis1_first in ("fused", "halves") else bool(axis1_first)
         self.W = W
         self.N = N
         self.xM_size = xM_size
@@ -624,6 +624,8 @@ class SwiftlyCoreHip:
     #: kept band columns per output parity the window-spectra store of the forward K1 can stage in LDS (row_pass.hip,
     #: row_pass_window_stage_columns)
     WINDOW_SPECTRA_STAGE_COLUMNS = 5888
+    #: physical band columns the window-rows epilogue of the whole-row K1 can stage (row_whole.hip, row_pass_whole_stage_columns)
+    WINDOW_ROWS_STAGE_COLUMNS = 12800
 
     def window_starts(self, band, wave_off1s):
         """``(first logical column of the contribution window of wave off1 - band start) mod yN`` for every wave: the
@@ -639,6 +641,38 @@ class SwiftlyCoreHip:
             (int(band[1]) + 1) // 2 <= self.WINDOW_SPECTRA_STAGE_COLUMNS and int(band[1]) < self.yN_size and
             int(facet_size) % 2 == 0 and all(int(o) % 2 == 0 for o in facet_off1s)
         )
+
+    def supports_window_rows(self, band, facet_size, facet_off1s):
+        """can K1 finish the contiguous axis for every planned window in its epilogue (``prepare_facet_window_rows``)?
+        (yN = 32768, m = 512, xM <= 2048 for the placed subgrid side, the band fits the LDS stage, 16-byte loads possible)"""
+        return (
+            self.yN_size == 32768 and self.xM_yN_size == 512 and self.xM_size <= 2048 and
+            self.band_columns(band) <= self.WINDOW_ROWS_STAGE_COLUMNS and int(band[1]) < self.yN_size and
+            int(facet_size) % 2 == 0 and all(int(o) % 2 == 0 for o in facet_off1s)
+        )
+
+    def prepare_facet_window_rows(self, facet, facet_off, band, window_starts, out, fold_other_axis_window=True,
+                                  rows_of=None):
+        """K1 of the axis-1-first pipeline with the COMPLETE contiguous-axis finish in its epilogue
+        (``swiftly_hip_prepare_facet_window_rows``, whole-row kernel): ``out[row, w*m:(w+1)*m]`` = what
+        ``finish_axis1_rows`` gives for wave ``w`` (the parity-split window band of ``Fn * cfft_m``).  ``window_starts``:
+        int32 DEVICE tensor (``window_starts(band, off1s)``); ``out[rows, nwin * m]`` row-major.  Hand the column blocks to
+        K2 with the band ``(window start, m)`` and run ``wave_subgrid_side(..., placed=1)``."""
+        if facet.dim() != 2 or facet.stride(1) != 1 or out.stride(1) != 1:
+            raise ValueError("prepare_facet_window_rows needs row-major 2-D device tensors")
+        nwin = int(window_starts.numel())
+        if tuple(out.shape) != (facet.shape[0], nwin * self.xM_yN_size):
+            raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(facet.shape[0], nwin * self.xM_yN_size)}!")
+        size, row0 = rows_of if rows_of is not None else (facet.shape[0], 0)
+        cvp = ctypes.c_void_p
+        _lib.check(
+            self._lib.swiftly_hip_prepare_facet_window_rows(
+                self._handle, self._code(facet), cvp(facet.data_ptr()), int(facet.shape[0]), int(facet.shape[1]),
+                facet.stride(0), cvp(out.data_ptr()), out.stride(0), int(facet_off), int(band[0]), int(band[1]),
+                int(size) if fold_other_axis_window else 0, int(row0), cvp(window_starts.data_ptr()), nwin, self._stream(),
+            )
+        )
+        return out
 
     def prepare_facet_window_spectra(self, facet, facet_off, band, window_starts, out, fold_other_axis_window=True,
                                      rows_of=None):

@@ -421,9 +421,10 @@ class SwiftlyForward(WavePrefetch):
             )
             F, yB = len(self._facet_info), self._facet_info[0][1][0]
             mode = self.__dict__["_axis1_mode"] = self._choose_axis1_mode()
-            if mode == 2:
-                # axis-1-first pipeline, contiguous-axis finish fused into K1: per facet row the two half spectra of every
-                # planned window instead of the band (core.prepare_facet_window_spectra)
+            if mode >= 2:
+                # axis-1-first pipeline, contiguous-axis finish fused into K1: per facet row, for every planned window, the
+                # finished window row (mode 3, core.prepare_facet_window_rows) or its two half spectra (mode 2,
+                # core.prepare_facet_window_spectra) instead of the band
                 keys = sorted(self._planned_keys)
                 self.__dict__["_window_of"] = {k: w for w, k in enumerate(keys)}
                 starts = torch.tensor(core.window_starts(self._band, keys), dtype=torch.int32, device=core.device)
@@ -433,7 +434,9 @@ class SwiftlyForward(WavePrefetch):
             for j, cfg in enumerate(self.facet_configs):
                 data = self._ingest.ready(j)
                 t0 = timer.start() if timer is not None else None
-                if mode == 2:
+                if mode == 3:
+                    core.prepare_facet_window_rows(data, cfg.off1, self._band, starts, bands[j])
+                elif mode == 2:
                     core.prepare_facet_window_spectra(data, cfg.off1, self._band, starts, bands[j])
                 else:
                     core.prepare_facet_band(data, cfg.off1, self._band, out=bands[j])
@@ -471,10 +474,13 @@ class SwiftlyForward(WavePrefetch):
         waves -- and a configuration with core.supports_window_spectra, else 1)."""
         if not (self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False))):
             return 0
-        if (self.core.axis1_first == "fused" and self.axis1_fused and self._plan is not None and self._band is not None and
-                self.core.supports_window_spectra(self._band, self._facet_info[0][1][1],
-                                                  [cfg.off1 for cfg in self.facet_configs])):
-            return 2
+        how = self.core.axis1_first
+        if how in ("fused", "halves") and self.axis1_fused and self._plan is not None and self._band is not None:
+            args = (self._band, self._facet_info[0][1][1], [cfg.off1 for cfg in self.facet_configs])
+            if how == "fused" and self.core.supports_window_rows(*args):
+                return 3
+            if how == "halves" and self.core.supports_window_spectra(*args):
+                return 2
         return 1
 
     def _axis1(self):
@@ -486,6 +492,10 @@ class SwiftlyForward(WavePrefetch):
             mode = self._choose_axis1_mode() if self.BF_Fs_persist is None else 0
         return mode
 
+    def _placed(self):
+        """the ``placed`` argument of the subgrid side for this object's axis-1-first mode (0 none, 1 finished rows, 2 halves)"""
+        return (0, 1, 2, 1)[self._axis1()]
+
     def _k2_source(self, off1):
         """``(bands, band)`` that K2 of wave ``off1`` reads: the K1 band buffers and the plan's band -- or, in the
         axis-1-first pipeline (``SwiftlyConfig(axis1_first=True)``), the rows finished along the contiguous axis for this
@@ -494,7 +504,7 @@ class SwiftlyForward(WavePrefetch):
         mode = self._axis1()
         if not mode:
             return bands, self._band
-        if mode == 2:  # the window's half spectra: m columns of the K1 output, read as a band that is exactly the window
+        if mode >= 2:  # the window's finished row / half spectra: m columns of the K1 output, read as a band that is exactly the window
             core = self.core
             m, w = core.xM_yN_size, self._window_of[int(off1)]
             start = (core.window_starts(self._band, [off1])[0] + self._band[0]) % core.yN_size
@@ -531,7 +541,7 @@ class SwiftlyForward(WavePrefetch):
         Q, rowmap = self._get_wave_columns(sgs[0].off1)
         self._check_planned(sgs)
         return _finish_from_columns(self.core, Q, 1, self.facet_configs, sgs, [sg.off0 for sg in sgs], rowmap=rowmap,
-                                    placed=self._axis1())
+                                    placed=self._placed())
 
     def _wave_Q(self, off1):
         """(Q workspace, rowmap, n_rows, needs computing) of wave ``off1`` (LRU cached like _get_wave_columns)"""
@@ -574,7 +584,7 @@ class SwiftlyForward(WavePrefetch):
             raise
         if compute:  # (this wave's own K2 was enqueued on the current stream just now: the next one goes behind it)
             self._prefetch_waves(nxt)
-        return _finish_from_G(core, G, self.facet_configs, sgs, placed=self._axis1())
+        return _finish_from_G(core, G, self.facet_configs, sgs, placed=self._placed())
 
 
 def _finish_from_columns(core, src, layout, facet_configs, sgs, window_offs, rowmap=None, band=None, placed=False):

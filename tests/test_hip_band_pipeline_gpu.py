@@ -426,6 +426,19 @@ def test_window_spectra_store_of_k1_matches_the_band_store():
                 want = numpy.fft.fft(b[:, p::2], axis=1)
                 rel = relrms(got[:, w * m + p * (m // 2):w * m + (p + 1) * (m // 2)], want)
                 assert rel < 5e-7, (foff, w, p, rel)
+        # ... and the form with the COMPLETE contiguous-axis finish in the epilogue of the whole-row K1: for every window what
+        # finish_axis1_rows makes of the band for that wave
+        assert core.supports_window_rows(band, size, [foff])
+        full = torch.full((rows, len(starts) * m), float("nan"), dtype=torch.complex64, device="cuda")
+        core.prepare_facet_window_rows(dev, foff, band, sd, full)
+        gotf = full.cpu().numpy()
+        assert numpy.isfinite(gotf.view(numpy.float32)).all()
+        bands1 = core.prepare_facet_band(dev, foff, band)[None]
+        for w, off1 in enumerate(wave_off1s):
+            want, wband = core.finish_axis1_rows(bands1, [foff], band, off1)
+            assert wband[0] == (band[0] + starts[w]) % yN64
+            rel = relrms(gotf[:, w * m:(w + 1) * m], want[0].cpu().numpy())
+            assert rel < 5e-7, (foff, w, rel)
     # unsupported shapes are refused, not approximated: a band with more kept columns per parity than the LDS stage holds
     wide = (0, 2 * core.WINDOW_SPECTRA_STAGE_COLUMNS + 2)
     assert not core.supports_window_spectra(wide, size, [0])
@@ -455,11 +468,11 @@ def test_axis1_first_pipeline_matches_oracle_and_default_order():
     for c in sg_cfgs:
         waves.setdefault(c.off1, []).append(c)
     ref = sw.SwiftlyForward(cfg0, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
-    for prefetch, fused in ((True, True), (False, True), (True, False), (False, False)):
+    for prefetch, fused in ((True, "fused"), (False, "fused"), (True, "halves"), (False, "halves"), (True, True), (False, True)):
         old = sw.api._PREFETCH
         sw.api._PREFETCH = prefetch
         try:
-            cfg.core.axis1_first = "fused" if fused else True
+            cfg.core.axis1_first = fused
             fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
             for key in (sorted(waves) if prefetch else sorted(waves)[::-1]):
                 got = fwd.get_wave(waves[key]).cpu().numpy()
@@ -468,7 +481,7 @@ def test_axis1_first_pipeline_matches_oracle_and_default_order():
                     want = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))
                     assert relrms(got[k], want) < 4e-6, (prefetch, fused, key, k, relrms(got[k], want))
                     assert relrms(got[k], base[k]) < 3e-5
-            assert fwd._axis1() == (2 if fused else 1)  # pylint: disable=protected-access
+            assert fwd._axis1() == {"fused": 3, "halves": 2, True: 1}[fused]  # pylint: disable=protected-access
         finally:
             sw.api._PREFETCH = old
     # without a plan there are no windows to fuse: the row pass per wave
