@@ -58,8 +58,6 @@ BACKWARD_PARITY_TOL = 3.5e-5
 HIGH_PRECISION_PARITY_TOL = 5e-6
 # forward relRMSE bound of the axis-1-first pipeline (float32 arithmetic, SwiftlyConfig(axis1_first=True); model: 2.1e-6)
 AXIS1_FIRST_PARITY_TOL = 4e-6
-# ... and of its form with the contiguous-axis finish fused into K1 (axis1_first="fused"; measured 5.8e-6 on the 64k workload)
-AXIS1_FUSED_PARITY_TOL = 7.5e-6
 HIGH_PRECISION_BACKWARD_PARITY_TOL = 1e-5
 
 WORKLOADS = {
@@ -726,11 +724,10 @@ def main():
                     help="multi-GPU: 'group' (default) = every wave's subgrids are finished by ONE rank and the waves are "
                          "exchanged in groups of n_gpus waves with distinct owners (one balanced all-to-all per group); "
                          "'wave' = the subgrids of every wave dealt out round-robin, one all-to-all per wave")
-    ap.add_argument("--axis1-first", nargs="?", const="rows", default=None, choices=["rows", "fused", "halves"],
-                    help="time the axis-1-first forward pipeline: 'rows' = SwiftlyConfig(axis1_first=True), the contiguous axis "
-                         "finished by a row pass per wave before the strided-axis transforms (float32 arithmetic at ~5x "
-                         "smaller error); 'fused' = axis1_first='fused', that finish inside K1 (window half spectra; cheaper, "
-                         "~1.8x smaller error than the default order)")
+    ap.add_argument("--axis1-first", nargs="?", const="fused", default=None, choices=["fused", "rows"],
+                    help="time the axis-1-first forward pipeline (float32 arithmetic at ~5x smaller error): 'fused' = "
+                         "SwiftlyConfig(axis1_first=True), the contiguous axis finished in the epilogue of K1; 'rows' = "
+                         "axis1_first='rows', by a row pass per wave")
     ap.add_argument("--column-precision", type=int, default=32, choices=[32, 64],
                     help="arithmetic of the column passes K2 / K3 (complex64 data): 32 = float32 (default, the timed "
                          "configuration of every round), 64 = float64 butterflies (3.7x smaller error, 1.5x the time)")
@@ -798,7 +795,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     p = wl["params"]
-    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, axis1_first={None: False, "rows": True, "fused": "fused", "halves": "halves"}[args.axis1_first], **p)
+    cfg = sw.SwiftlyConfig(backend="hip", column_precision=args.column_precision, axis1_first={None: False, "rows": "rows", "fused": True}[args.axis1_first], **p)
     all_facet_cfgs = sw.make_full_facet_cover(cfg)
     # a rank holds at most `max_facets_per_rank` facets (HBM capacity): with too few ranks only the first cap * world
     # facets of the cover take part -- a stated subset; contributions are counted for those only
@@ -952,8 +949,7 @@ def main():
             kept = {k: v for d in gathered for k, v in d.items()}
         if rank == 0:
             parity = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept,
-                                     tol={None: wl.get("parity_tol"), "rows": AXIS1_FIRST_PARITY_TOL, "fused": AXIS1_FIRST_PARITY_TOL,
-                                          "halves": AXIS1_FUSED_PARITY_TOL}[args.axis1_first])
+                                     tol=AXIS1_FIRST_PARITY_TOL if args.axis1_first else wl.get("parity_tol"))
 
     # (r6) the axis-1-first pipeline beside the timed default order: same objects, same facets, float32 arithmetic -- the
     # contiguous axis finished (m-point transform x Fn per wave window) BEFORE K2 / K3, which then see ONE facet window
@@ -983,27 +979,18 @@ def main():
 
         accurate = dict(
             mode="axis1_first",
-            what="SwiftlyConfig(axis1_first=True): per wave, the rows of the K1 output go through the contiguous-axis half "
-                 "of add_to_subgrid (window gather, m-point transform, Fn; swiftly_hip_finish_axis1_rows) before K2; K2 / "
-                 "K3 unchanged, sum_finish_facets without its m-point transforms; float32 arithmetic throughout; not "
-                 "part of `value`",
+            what="SwiftlyConfig(axis1_first=True): the contiguous-axis half of add_to_subgrid (window gather, m-point "
+                 "transform, Fn) runs in the epilogue of K1 -- one persistent workgroup per CU owns whole rows, stages the band of "
+                 "a row in LDS and stores the finished window rows of every planned wave (swiftly_hip_prepare_facet_window_rows; "
+                 "no band buffer, no row pass per wave); K2 / K3 unchanged on singly windowed data, sum_finish_facets without "
+                 "its m-point transforms; float32 arithmetic throughout; not part of `value`",
             **axis1_leg(True, AXIS1_FIRST_PARITY_TOL),
         )
-        accurate["fused_into_k1"] = dict(
-            what="SwiftlyConfig(axis1_first='fused'): the same order with the contiguous-axis finish in the epilogue of K1 -- "
-                 "one persistent workgroup per CU owns whole rows (both output parities), parks the band of a row in an "
-                 "L2-resident scratch slot and stores the finished window rows of every planned wave; no band buffer in HBM, "
-                 "no row pass per wave; K2 / K3 / placed sum_finish as above",
-            **axis1_leg("fused", AXIS1_FIRST_PARITY_TOL),
-        )
-        accurate["halves_from_k1"] = dict(
-            what="SwiftlyConfig(axis1_first='halves'): the same order with the contiguous-axis finish inside the TWO-workgroup K1 -- each of a "
-                 "row's two workgroups stores the half spectrum (m/2-point transform) of its output parity for every planned "
-                 "window instead of the band; K2 / K3 unchanged on the halves, sum_finish_facets joins them (radix-2 step, "
-                 "window phase, Fn).  No band buffer, no row pass per wave; the column passes work on ALIASED spectra "
-                 "(frequency u folded onto u + m/2, where Fn has not yet suppressed the window's leakage), which costs "
-                 "part of the accuracy gain",
-            **axis1_leg("halves", AXIS1_FUSED_PARITY_TOL),
+        accurate["row_pass_per_wave"] = dict(
+            what="SwiftlyConfig(axis1_first='rows'): the same order on top of the default K1 -- per wave, the rows of the band "
+                 "buffers go through a pass of their own (swiftly_hip_finish_axis1_rows) before K2; what configurations "
+                 "without the fused K1 (other sizes, no plan, cooperative facets of the multi-GPU pass) run",
+            **axis1_leg("rows", AXIS1_FIRST_PARITY_TOL),
         )
 
     # the float64-arithmetic column passes (column_precision = 64) beside the timed float32 configuration: same objects,

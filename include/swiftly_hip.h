@@ -430,45 +430,20 @@ int swiftly_hip_wave_subgrid_side_placed(swiftly_hip_t* h, int dtype, const void
                                          int64_t mask1_bs, void* tmp_work, void* out, void* scratch, int64_t scratch_bytes,
                                          void* stream);
 
-/* AXIS-1-FIRST pipeline with the contiguous-axis finish FUSED INTO THE FORWARD K1 (r6): the same mathematics as
- * finish_axis1_rows, split so that no band buffer and no per-wave row pass exist.
- * prepare_facet_window_spectra: prepare_facet_band_rows whose kernel keeps the band in LDS and stores, for each of the
- *   `nwindows` contribution windows of the plan (window w = the m columns from logical column band_start +
- *   window_starts[w], all inside the band), the two decimation-in-time HALF SPECTRA of the window:
- *       out[row][w*m + p*(m/2) + q] = sum_j b_w[2j + p] exp(-2 pi i j q / (m/2)),   b_w[i] = prepared row[window column i]
- *   (each of the two workgroups of a row holds the outputs of one parity: it can transform its half of every window by
- *   itself).  The m columns at w*m are read by prepare_facet_columns / wave_facet_side as a parity-split band buffer whose
- *   band is window w (band_start' = window start, band_len' = m, row stride out_row_stride); the strided-axis transforms
- *   are linear and act per column, so the join of the halves waits until ...
- * wave_subgrid_side_halves: wave_subgrid_side for such blocks -- sum_finish_facets applies the radix-2 step that joins the
- *   halves, the phase of the window rotation and Fn (reference core.py:255-285 along the contiguous axis), places and sums.
- *   One wave per call (all subgrids share off1).
- * window_starts: DEVICE int32 table.  yN_size 32768, m = 512, xM <= 2048, at most 5888 kept columns per output parity
- * (SWIFTLY_ERR_UNSUPPORTED otherwise: use finish_axis1_rows).  complex64. */
-int swiftly_hip_prepare_facet_window_spectra(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
-                                             int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
-                                             int64_t band_start, int64_t band_len, int64_t other_axis_size,
-                                             int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
-                                             void* stream);
-/* ... and the form that finishes the contiguous axis COMPLETELY inside K1 (r6): one persistent workgroup per CU owns whole
- * rows -- both output parities -- stages the band of a row in LDS (it never reaches memory) and stores for every window w
- * exactly what finish_axis1_rows produces for wave w from that band:
+/* AXIS-1-FIRST pipeline with the contiguous-axis finish FUSED INTO THE FORWARD K1 (r6): prepare_facet_band_rows as one
+ * persistent workgroup per CU that owns whole rows -- both output parities -- stages the band of a row in LDS (it never
+ * reaches memory) and stores for each of the `nwindows` contribution windows of the plan (window w = the m columns from
+ * logical column band_start + window_starts[w], all inside the band) exactly what finish_axis1_rows produces for wave w:
  *     out[row][w*m ..] = parity-split window band of  Fn[k] cfft_m(window w)[(k + s'1) mod m]
  * so the columns [w*m, (w+1)*m) go to prepare_facet_columns / wave_facet_side with the band (window start, m) and the
- * blocks to wave_subgrid_side_placed.  Same shape limits as prepare_facet_window_spectra, with a band of at most ~13000
- * columns (LDS stage) instead of the per-parity limit. */
+ * blocks to wave_subgrid_side_placed.  No band buffer, no row pass per wave.  window_starts: DEVICE int32 table.
+ * yN_size 32768, m = 512, even facet size / offset / row stride, a band of at most 12800 physical columns (the LDS stage);
+ * SWIFTLY_ERR_UNSUPPORTED otherwise: use prepare_facet_band + finish_axis1_rows.  complex64. */
 int swiftly_hip_prepare_facet_window_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                           int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                           int64_t band_start, int64_t band_len, int64_t other_axis_size,
                                           int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
                                           void* stream);
-int swiftly_hip_wave_subgrid_side_halves(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
-                                         int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
-                                         int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s,
-                                         int64_t subgrid_size, const void* mask0, int64_t mask0_bs, const void* mask1,
-                                         int64_t mask1_bs, void* tmp_work, void* out, void* scratch, int64_t scratch_bytes,
-                                         void* stream);
-
 /* Backward subgrid side for all facets at once (mirror of sum_finish_facets): in[b] = [xM, subgrid_size] =
  * prepare_subgrid of subgrid b along axis 0 ONLY (core.py:328-368); out[f][b] = [m, m] contiguous = the contribution
  * of subgrid b to facet f, i.e. api_helper.prepare_and_split_subgrid (api_helper.py:115-139): prepare_subgrid along

@@ -204,14 +204,11 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
         const int c_ = (int)(((long long)a.ld_a + n_ / 2 + (long long)first * SEGLEN) % n_);   \
         a.ld_win4 = (w4cache && win4_enabled()) ? w4cache->get(a.ld_win, c_, a.ld_len, NS, n_, SEGLEN, s) : nullptr; \
         a.twc = (a.ld_win4 && win4_enabled() >= 2) ? w4cache->twc : nullptr;               \
-        if (a.win_d && !a.twc) return -2;                                                      \
-        if (a.win_full || !a.win_d) {                                                          \
+        {   /* whole-row form: the window-rows store (win_full), or SWIFTLY_K1_WHOLE=1 for the band store */ \
             const int ew_ = launch_row_pass_whole(a, NS, tw14, tw_full, s);                    \
             if (ew_ != -2 || a.win_full) return ew_;                                           \
         }                                                                                      \
-        if (a.win_d)                                                                           \
-            launch_band_inst<GC, PAIR, true, 3, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
-        else if (a.twc)                                                                        \
+        if (a.twc)                                                                        \
             launch_band_inst<GC, PAIR, true, 1, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
         else if (a.ld_win4)                                                                    \
             launch_band_inst<GP, PAIR, true, 1, NS, 1, true>(a, blocks, tw14, tw_full, s);     \
@@ -223,7 +220,7 @@ static int launch_band_geo(const RowPassArgs& a0, const cx<float>* tw14, const c
                 SWF_TRY_SEG_PRE(22)
                 SWF_TRY_SEG_PRE(24)
 #undef SWF_TRY_SEG_PRE
-                if (a.win_d) return -2;  // window-spectra store: only the instances above
+                if (a.win_full) return -2;  // window-rows store: only the instances above
             } else if (a.band_len < 0 && fwd) {
                 // backward finish: compact twiddle sections when the caller owns the tables
                 using GB = RGeoC<G::LOGN, G::LOGP, G::SPLIT>;
@@ -269,12 +266,9 @@ int launch_row_pass_band(const RowPassArgs& a, const cx<float>* tw14, const cx<f
 int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_half, const cx<float>* tw_full, hipStream_t s,
                            Win4Cache* w4) {
     if (a.nrows <= 0) return 0;
-    if (a.win_d) {
-        // window-spectra store (ST = 3): 32768-point rows, 512-column windows, the kept columns of one parity staged in the
-        // LDS the 256-point window transforms leave free
-        const int ncol = (a.band_len + 1) >> 1;
-        if (logn != 15 || a.win_logm != 9 || a.nwin <= 0 || a.band_len <= 0) return -2;
-        if (!a.win_full && (!a.tw_win || ncol > row_pass_window_stage_columns())) return -2;
+    if (a.win_full) {
+        // window-rows store (whole-row kernel): 32768-point rows, 512-column windows, 16-byte loads
+        if (logn != 15 || a.win_logm != 9 || a.nwin <= 0 || !a.win_d || a.band_len <= 0) return -2;
         const bool pair_ok_w = !(a.ld_a & 1) && !(a.ld_len & 1) && !(a.in_pitch & 1) && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
         if (!pair_ok_w || !a.ld_win || !(a.conj_ld && a.conj_st)) return -2;
         return launch_band_geo<BandGeo5, true>(a, tw_half, tw_full, s, w4);
@@ -290,10 +284,6 @@ int launch_row_pass_band_n(int logn, const RowPassArgs& a, const cx<float>* tw_h
     const bool pair_ok = !(a.ld_a & 1) && !(a.ld_len & 1) && !(a.in_pitch & 1) && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
     if (pair_ok) return launch_band_geo<BandGeo5, true>(a, tw14, tw_full, s, w4);
     return launch_band_geo<BandGeo5>(a, tw14, tw_full, s);
-}
-int row_pass_window_stage_columns() {
-    using GW = Geo<float, 8, 2, BandGeo5::NT, false>;
-    return (int)(((BandGeo5::LDS_BYTES - GW::LDS_BYTES) & ~(size_t)15) / 8);
 }
 int row_pass_band_occupancy() {
     int n = -1;
@@ -354,9 +344,6 @@ int init_row_pass() {
         if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 1, 16, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 1, 22, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 1, 24, true, 1, true>();
-        if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 3, 16, true, 1, true>();
-        if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 3, 22, true, 1, true>();
-        if (!rcb) rcb = init_band_pair<BandGeo5PreC, true, 3, 24, true, 1, true>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 13, true, 0>();
         if (!rcb) rcb = init_band_pair<BandGeo5, false, 2, 16, true, 0>();
         using BandGeo5C = RGeoC<14, 5, true>;

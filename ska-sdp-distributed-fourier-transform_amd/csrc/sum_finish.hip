@@ -30,21 +30,6 @@ static int init_one_f() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&sum_finish_facets_kernel<LOGM, LOGX>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sum_finish_facets_kernel_lds<LOGM, LOGX>()));
 }
-// HALVES instances (SumFinishFacetArgs::placed = 2): the contribution size of the window-spectra store of the forward K1
-template <int LOGX>
-static int launch_halves(const SumFinishFacetArgs& a, int nbatch, hipStream_t s) {
-    using S = SFGeo<9, LOGX>;
-    dim3 grid((unsigned)((a.nrows + S::RB - 1) / S::RB), (unsigned)nbatch);
-    constexpr size_t lds = sum_finish_facets_kernel_lds<9, LOGX>();
-    hipLaunchKernelGGL((sum_finish_facets_kernel<9, LOGX, true>), grid, dim3(S::NT), lds, s, a);
-    return (int)hipGetLastError();
-}
-template <int LOGX>
-static int init_halves() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&sum_finish_facets_kernel<9, LOGX, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sum_finish_facets_kernel_lds<9, LOGX>()));
-}
-
 template <int LOGM, int LOGX>
 static int launch_one_s(const SplitFacetArgs& a, int nbatch, hipStream_t s) {
     using S = SFGeo<LOGM, LOGX>;
@@ -86,11 +71,6 @@ int launch_sum_finish_rows(int logm, int logx, const SumFinishArgs& a, int nbatc
     return -1;
 }
 int launch_sum_finish_facets(int logm, int logx, const SumFinishFacetArgs& a, int nbatch, hipStream_t s) {
-    if (a.placed == 2) {
-        if (logm == 9 && logx == 10) return launch_halves<10>(a, nbatch, s);
-        if (logm == 9 && logx == 11) return launch_halves<11>(a, nbatch, s);
-        return -1;
-    }
 #define SF_CASE_F(M, XX) \
     if (logm == M && logx == XX) return launch_one_f<M, XX>(a, nbatch, s);
     SF_PAIRS(SF_CASE_F)
@@ -112,8 +92,6 @@ int init_sum_finish_rows() {
     if (!rc) rc = init_one_s<M, XX>();
     SF_PAIRS(SF_INIT)
 #undef SF_INIT
-    if (!rc) rc = init_halves<10>();
-    if (!rc) rc = init_halves<11>();
     return rc;
 }
 bool sum_finish_supported(int logm, int logx) {

@@ -284,7 +284,6 @@ int swiftly_hip_create(swiftly_hip_t** out, int64_t N, int64_t yN, int64_t xM, d
             if (!rc && l == 15) rc = make_twiddles(h, 13);
             if (!rc && (l == 16 || l == 14)) rc = make_twiddles(h, l - 1);  // band row kernel halves
         }
-    if (!rc && h->log_yN == 15 && h->log_m == 9) rc = make_twiddles(h, h->log_m - 1);  // window half spectra of the forward K1
     // compact copies for the contiguous-axis kernels whose lanes gather table values (swiftly_fft.h): the forward K1 / backward
     // finish of 32768-point rows (2 x 16384 points, 32 per lane) and the facet kernels of the subgrid side (64 lanes per transform)
     if (!rc && h->log_yN == 15) {
@@ -1537,12 +1536,9 @@ static int prepare_facet_band_rows_impl(swiftly_hip_t* h, int dtype, const void*
     const cx<float>* twh = twiddles<float>(h, h->log_yN - 1);
     const cx<float>* twf = twiddles<float>(h, h->log_yN);
     if (!twh || !twf) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
-    if (win_d) {
-        r.win_d = win_d; r.nwin = (int)nwin; r.win_logm = h->log_m;
-        r.tw_win = h->log_m > 1 ? twiddles<float>(h, h->log_m - 1) : nullptr;
-    }
     if (win_d && win_full) {  // complete window rows (whole-row kernel)
         r.win_full = 1;
+        r.win_d = win_d; r.nwin = (int)nwin; r.win_logm = h->log_m;
         r.win_sp = pmod(floordiv(facet_off * h->xM, h->N), (int)h->m);
         r.win_fn = h->fn_f;
         r.win_tw_m = twiddles<float>(h, h->log_m);
@@ -1550,9 +1546,8 @@ static int prepare_facet_band_rows_impl(swiftly_hip_t* h, int dtype, const void*
     }
     int e = launch_row_pass_band_n(h->log_yN, r, twh, twf, (hipStream_t)stream, &h->win4);
     if (e == -2)
-        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_window_%s: needs yN_size 32768, contribution size 512, even facet "
-                    "size / offset / row stride%s", r.win_full ? "rows" : "spectra",
-                    r.win_full ? " and a band of at most 12800 physical columns" : " and at most 5888 kept columns per output parity");
+        return fail(SWIFTLY_ERR_UNSUPPORTED, "prepare_facet_window_rows: needs yN_size 32768, contribution size 512, even facet "
+                    "size / offset / row stride and a band of at most %d physical columns", row_pass_whole_stage_columns());
     if (e) return fail(SWIFTLY_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return 0;
 }
@@ -1565,23 +1560,8 @@ int swiftly_hip_prepare_facet_band_rows(swiftly_hip_t* h, int dtype, const void*
                                         band_len, other_axis_size, other_axis_row0, nullptr, 0, 0, stream);
 }
 
-// (r6, axis-1-first pipeline) prepare_facet_band_rows whose kernel, instead of storing the band, stores for each of the
-// `nwindows` contribution windows of the plan the two HALF SPECTRA of the window (RowPassArgs::win_d, swiftly_rowpass.h):
-// out[row][w * m + p * m/2 + q], the m/2-point plain transform of the window samples of parity p.  window_starts = DEVICE
-// table of (first logical column of window w - band_start) mod yN; every window must lie inside the band.
-int swiftly_hip_prepare_facet_window_spectra(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
-                                             int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
-                                             int64_t band_start, int64_t band_len, int64_t other_axis_size,
-                                             int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
-                                             void* stream) {
-    if (!window_starts || nwindows <= 0) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_spectra: no windows");
-    if (h && out_row_stride < nwindows * h->m) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_spectra: output rows hold nwindows * m columns");
-    return prepare_facet_band_rows_impl(h, dtype, in, rows, facet_size, in_row_stride, out, out_row_stride, facet_off, band_start,
-                                        band_len, other_axis_size, other_axis_row0, window_starts, nwindows, 0, stream);
-}
-
-// (r6, axis-1-first pipeline) ... and the form that finishes the contiguous axis COMPLETELY inside K1: one persistent workgroup
-// per CU owns whole rows (both output parities; swiftly_rowwhole.h), stages the band of a row in LDS and stores, for every
+// (r6, axis-1-first pipeline) prepare_facet_band_rows that finishes the contiguous axis COMPLETELY inside K1: one persistent
+// workgroup per CU owns whole rows (both output parities; swiftly_rowwhole.h), stages the band of a row in LDS and stores, for every
 // window w, what swiftly_hip_finish_axis1_rows would produce for wave w from that band:
 // out[row][w*m ..] = parity-split window band of  Fn[k] cfft_m(window w)[(k + s'1) mod m].
 int swiftly_hip_prepare_facet_window_rows(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,

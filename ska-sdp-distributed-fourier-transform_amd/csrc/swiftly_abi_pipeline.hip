@@ -453,16 +453,7 @@ static int sum_finish_facets_impl(swiftly_hip_t* h, int dtype, const void* in, i
     a.xA = xA;
     fill_facet_groups(a, h, nfacets, facet_off0s, facet_off1s);
     fill_group_rounds(a, h);
-    a.placed = placed;
-    if (placed == 2) {
-        // the half spectra of one wave: every subgrid of the call shares off1
-        for (int64_t b = 1; b < nsub; b++)
-            if (subgrid_off1s[b] != subgrid_off1s[0])
-                return fail(SWIFTLY_ERR_PARAM, "wave_subgrid_side_halves: the subgrids of a call share their off1 (one wave)");
-        if (h->log_m != 9 || h->log_xM > 11)
-            return fail(SWIFTLY_ERR_UNSUPPORTED, "wave_subgrid_side_halves: contribution size 512, subgrids up to 2048");
-        a.wave_s = pmod(subgrid_off1s[0] * h->yN / h->N, (int)h->m);
-    }
+    a.placed = placed ? 1 : 0;
     if (placed && h->log_xM >= 12)
         return fail(SWIFTLY_ERR_UNSUPPORTED, "axis-1-first pipeline: rows of %lld points run the wave-parallel sum_finish form, "
                     "which has no placed mode", (long long)h->xM);
@@ -728,20 +719,6 @@ int swiftly_hip_wave_subgrid_side_placed(swiftly_hip_t* h, int dtype, const void
     return wave_subgrid_side_impl(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, facet_off0s, facet_off1s, nsub, sub_off0s,
                                   sub_off1s, subgrid_size, mask0, mask0_bs, mask1, mask1_bs, tmp_work, out, scratch, scratch_bytes,
                                   1, stream);
-}
-
-/* ... and of the pipeline whose forward K1 stored window HALF SPECTRA (swiftly_hip_prepare_facet_window_spectra): the rows of
- * g[f][b] hold, at column (2 u' + p + s) mod m, the strided-axis transforms of G_p[u']; sum_finish_facets joins the two halves
- * (radix-2 step + window phase + Fn), places and sums.  One wave per call: all subgrids share off1. */
-int swiftly_hip_wave_subgrid_side_halves(swiftly_hip_t* h, int dtype, const void* g, int64_t nfacets, int64_t g_facet_stride,
-                                         int64_t g_sub_stride, const int64_t* facet_off0s, const int64_t* facet_off1s,
-                                         int64_t nsub, const int64_t* sub_off0s, const int64_t* sub_off1s,
-                                         int64_t subgrid_size, const void* mask0, int64_t mask0_bs, const void* mask1,
-                                         int64_t mask1_bs, void* tmp_work, void* out, void* scratch, int64_t scratch_bytes,
-                                         void* stream) {
-    return wave_subgrid_side_impl(h, dtype, g, nfacets, g_facet_stride, g_sub_stride, facet_off0s, facet_off1s, nsub, sub_off0s,
-                                  sub_off1s, subgrid_size, mask0, mask0_bs, mask1, mask1_bs, tmp_work, out, scratch, scratch_bytes,
-                                  2, stream);
 }
 
 

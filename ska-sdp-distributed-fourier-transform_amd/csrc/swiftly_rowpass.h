@@ -73,22 +73,14 @@ struct RowPassArgs {
     const float* ld_win4;
     // ... and the compact twiddle sections of geometries with COMPACT_TW (Win4Cache::compact_tw; swiftly_fft.h, preload_compact)
     const cx<float>* twc;
-    // WINDOW-SPECTRA store (r6, ST = 3 instances; axis-1-first pipeline): instead of the band, the kernel stores for each of
-    // the nwin windows of the plan (window w = the 2^win_logm columns from logical column band_start + win_d[w]) the plain
-    // (2^win_logm / 2)-point transform of the window samples of ITS output parity:
-    //     out[row][w * m + p * m/2 + q] = sum_j b_w[2 j + p] exp(-2 pi i j q / (m/2)),   b_w[i] = X[band_start + win_d[w] + i]
-    // (a decimation-in-time half spectrum; the radix-2 step that joins the two parities is linear and is applied after the
-    // strided-axis transforms, by sum_finish_facets with placed = 2).  The buffer is read by the column kernels as a band
-    // buffer whose band is window w: parity-split, m columns at w * m.
-    const int* win_d;     // device table, nwin entries: (first logical column of window w - band_start) mod N
-    int nwin, win_logm;
-    const cx<float>* tw_win;  // twiddle table of length m / 2
     // WINDOW-ROWS store (r6, whole-row kernel swiftly_rowwhole.h, WIN instances): one workgroup owns BOTH output parities of a
     // row, so the complete contiguous-axis half of add_to_subgrid runs in its epilogue (what swiftly_hip_finish_axis1_rows does
     // per wave in a pass of its own): the band of the row is staged in LDS (the exchange buffer, free after the last gather),
     // and for every window w   out[row][w * m + parity-split position of (kk - s_w) mod m] =
     // Fn[kk] cfft_m(window w)[(kk + win_sp) mod m]   -- the layout finish_axis1_rows produces for wave w.
-    int win_full;                 // 1: this form (needs win_d / nwin / win_logm above)
+    int win_full;                 // 1: this form
+    const int* win_d;             // device table, nwin entries: (first logical column of window w - band_start) mod N
+    int nwin, win_logm;           // windows of 2^win_logm columns, every one inside the band
     int win_sp;                   // s'1 = floor(facet_off1 * xM / N) mod m of this facet
     const float* win_fn;          // Fn[m]
     const cx<float>* win_tw_m;    // twiddle table of length m and its compact sections for m / 64 points per lane
@@ -703,53 +695,6 @@ __global__ __launch_bounds__(G::NT, 4) void row_pass_band_kernel(const RowPassAr
         return;
     }
     constexpr bool ONEBLK = PAIR || (G::LOGN % G::LOGP == 0);  // last phase: one block per lane, outputs e = t + r T
-    if constexpr (ST == 3) {
-        // (r6) window spectra: the kept outputs of this workgroup's parity are staged in LDS (column q = d >> 1 of the parity
-        // region, as the band store would lay them out in memory), then every wave transforms the windows w = wave, wave + 8, ..
-        static_assert(ONEBLK && CJ == 1 && !G::WAVE_ROWS, "forward K1 instances");
-        constexpr int LNS = G::LOGN - G::LOGP;
-        constexpr int LOGMH = 8;  // m / 2 = 256 (host-checked: win_logm == 9)
-        using GW = Geo<float, LOGMH, LOGMH - 6, G::NT, false>;  // one wave per transform, 4 points per lane
-        static_assert(GW::T == 64 && GW::WAVE_ROWS && GW::LDS_BYTES < G::LDS_BYTES, "window transform geometry");
-        constexpr int STAGE_BYTES = (int)(G::LDS_BYTES - GW::LDS_BYTES) & ~15;  // host-checked: kept columns per parity fit
-        cx<float>* __restrict__ stage = reinterpret_cast<cx<float>*>(smem);
-        unsigned char* exw = smem + STAGE_BYTES;
-        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-        const int lane = t & 63;
-        const int dw = ((wave << 7) + (N >> 1) - A.band_start + h) & (N - 1);  // d of lane 0, output r = 0
-        const int lane2 = lane << 1;
-        const f32x2 sc = {scale, scale};
-        const int par = (h ^ A.band_start) & 1;
-        // (the exchange of the last phase ends with a workgroup barrier behind its reads: the buffer is free)
-        run_phases([&](int, cx<float> v, auto sI) {
-            constexpr int r = decltype(sI)::value;
-            const int base = (dw + (r << (LNS + 1))) & (N - 1);  // wave-uniform
-            const bool none_in = base >= A.band_len && base + 126 < N;
-            if (none_in) return;
-            if constexpr (SEGSKIP) v = cmul(v, rphi);
-            f32x2 val;
-            const f32x2 vv = pkv(v);
-            asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(val) : "v"(vv), "v"(sc));
-            const int d = (base + lane2) & (N - 1);
-            if (d < A.band_len) *reinterpret_cast<f32x2*>(stage + (d >> 1)) = val;
-        });
-        __syncthreads();
-        const int m = 2 << LOGMH;
-        cx<float>* __restrict__ orow = reinterpret_cast<cx<float>*>(outb);
-        for (int w = wave; w < A.nwin; w += G::NT / 64) {   // wave-uniform
-            const int D = __builtin_amdgcn_readfirstlane(A.win_d[w]);
-            const int pw = (par - D) & 1;          // parity of the window samples this workgroup holds
-            const int q0 = (D + pw) >> 1;          // their first staged column
-            cx<float> xw[GW::P];
-            static_for<0, GW::P>([&](auto vI) {
-                constexpr int v = decltype(vI)::value;
-                xw[v] = stage[q0 + lane + v * 64];
-            });
-            cx<float>* __restrict__ ow = orow + (long long)w * m + pw * (m >> 1);
-            fft_phases<GW, float, 0>(xw, lane, wave, false, exw, A.tw_win, [&](int e, cx<float> v) { ow[e] = v; });
-        }
-        return;
-    }
     if constexpr (BAND && ONEBLK && CJ >= 0) {
         constexpr int LNS = G::LOGN - G::LOGP;
         static_assert(T == (1 << LNS), "e = t + (r << LNS)");
@@ -868,6 +813,5 @@ int launch_row_pass_whole(const RowPassArgs& a, int nseg, const cx<float>* tw14,
 int init_row_pass_whole();
 int row_pass_whole_grid();  // workgroups of a whole-row launch (one per CU)
 int row_pass_whole_stage_columns();  // physical band columns (both parities) the window-rows epilogue can stage
-int row_pass_window_stage_columns();  // kept columns per output parity the window-spectra store (RowPassArgs::win_d) can stage
 
 }  // namespace swf

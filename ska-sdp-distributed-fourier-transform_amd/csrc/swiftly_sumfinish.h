@@ -219,17 +219,11 @@ struct SumFinishFacetArgs {
     // (r6, axis-1-first pipeline) 1 = the rows of `in` already ARE  Fn[k] * cfft_m(contribution)[(k + s'1) mod m]  along the
     // contiguous axis (axis1_rows_kernel ran before the strided-axis transforms): no m-point transform here, the rows of
     // a group are summed and placed.  Register form only.
-    // 2 (HALVES instances of the kernel): the rows of `in` are the two decimation-in-time HALF SPECTRA of the contribution
-    // window (the window-spectra store of the forward K1, swiftly_rowpass.h) after the strided-axis transforms: column
-    // (2 u' + p + wave_s) mod m holds G_p[u'], and  Fn[k] cfft_m(.)[(k + s'1) mod m] = Fn[k] W^((wave_s - m/2) u) (G_0[u'] + W^u G_1[u'])
-    // with u = (k + s'1) mod m - m/2, u' = u mod m/2, W = exp(-2 pi i / m): the radix-2 step that joins the halves, applied
-    // to the sum of the group's rows, then placed as for 1.
     int placed;
-    int wave_s;            // placed = 2: s = off1 yN / N (mod m) of the wave's subgrids
 };
 
 // (register form, 1024-point rows: 4 waves per SIMD = 16 rows per CU, which the 8.7 KB of LDS per row now allow)
-template <int LOGM, int LOGX, bool HALVES = false>
+template <int LOGM, int LOGX>
 __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void sum_finish_facets_kernel(const SumFinishFacetArgs A) {
     using S = SFGeo<LOGM, LOGX>;
     using GX = typename S::GX;
@@ -350,13 +344,10 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
     static_for<0, PX>([&](auto vI) { y[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
     __syncthreads();
     // (8 points per lane and 1024-point rows: two facets in flight keep the kernel at 128 VGPRs without spills)
-    constexpr int NB = HALVES ? 1 : (PM >= 8 && LOGX <= 10 && kSumFinishInFlight > 2) ? 2 : kSumFinishInFlight;
-    constexpr int PH = HALVES ? PM : 1;
+    constexpr int NB = (PM >= 8 && LOGX <= 10 && kSumFinishInFlight > 2) ? 2 : kSumFinishInFlight;
     for (int g = 0; g < A.ngroups; g++) {  // workgroup-uniform
         cx<float> xs[PM];
-        cx<float> xs1[PH];  // HALVES: the odd half spectrum
         static_for<0, PM>([&](auto vI) { xs[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
-        static_for<0, PH>([&](auto vI) { xs1[decltype(vI)::value] = cx<float>{0.f, 0.f}; });
         bool anyg = false;
         int n = A.gstart[g];
         const int ne = A.gstart[g + 1];
@@ -372,7 +363,6 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
             if (cnt == 0) break;
             anyg = true;
             cx<float> x[NB][PM];
-            cx<float> x1[NB][PH];
             float wgt[NB];
             static_for<0, NB>([&](auto sI) {
                 constexpr int sl = decltype(sI)::value;
@@ -383,22 +373,12 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
                     const cx<float>* __restrict__ in =
                         A.in + (long long)A.fidx[nn] * A.in_fs + (long long)b * A.in_bs + (long long)(on ? k : 0) * A.in_rs;
                     wgt[sl] = on ? 1.f : 0.f;
-                    if constexpr (HALVES) {
-                        static_for<0, PM>([&](auto vI) {
-                            constexpr int v = decltype(vI)::value;
-                            const int u2 = (((t + v * TR) ^ (M >> 1)) & ((M >> 1) - 1)) << 1;  // 2 (u mod m/2)
-                            const int j0 = (u2 + A.wave_s) & (M - 1);
-                            x[sl][v] = in[j0];
-                            x1[sl][v] = in[(j0 + 1) & (M - 1)];
-                        });
-                    } else {
-                        // placed rows are indexed by kk = (centred output index - s'1) mod m of the slot the value lands in
-                        const int rot = A.placed ? A.gsp1[g] : 0;
-                        static_for<0, PM>([&](auto vI) {
-                            constexpr int v = decltype(vI)::value;
-                            x[sl][v] = in[(((t + v * TR) ^ (M >> 1)) - rot) & (M - 1)];  // plain index -> centred element
-                        });
-                    }
+                    // placed rows are indexed by kk = (centred output index - s'1) mod m of the slot the value lands in
+                    const int rot = A.placed ? A.gsp1[g] : 0;
+                    static_for<0, PM>([&](auto vI) {
+                        constexpr int v = decltype(vI)::value;
+                        x[sl][v] = in[(((t + v * TR) ^ (M >> 1)) - rot) & (M - 1)];  // plain index -> centred element
+                    });
                 }
             });
             static_for<0, NB>([&](auto sI) {
@@ -409,42 +389,11 @@ __global__ __launch_bounds__((SFGeo<LOGM, LOGX>::NT), (LOGX <= 10 ? 4 : 1)) void
                         xs[v].x += x[sl][v].x * wgt[sl];
                         xs[v].y += x[sl][v].y * wgt[sl];
                     });
-                    static_for<0, PH>([&](auto vI) {
-                        constexpr int v = decltype(vI)::value;
-                        if constexpr (HALVES) {
-                            xs1[v].x += x1[sl][v].x * wgt[sl];
-                            xs1[v].y += x1[sl][v].y * wgt[sl];
-                        }
-                    });
                 }
             });
         }
         if (!anyg) continue;
         const int sp = A.gsp1[g];
-        if constexpr (HALVES) {
-            static_for<0, PM>([&](auto vI) {
-                constexpr int v = decltype(vI)::value;
-                const int ck = (t + v * TR) ^ (M >> 1);
-                const int u = ck - (M >> 1);                       // signed output frequency of the m-point transform
-                const cx<float> wu = A.tw_m[u & (M - 1)];
-                const cx<float> w1 = A.tw_m[((A.wave_s - (M >> 1)) * u) & (M - 1)];
-                cx<float> z = cmul(wu, xs1[v]);
-                z.x += xs[v].x;
-                z.y += xs[v].y;
-                z = cmul(w1, z);
-                const int kk = (ck - sp) & (M - 1);
-                const float w = fn_l[kk];
-                const int p = (kk - (M >> 1) + sp) & (X - 1);
-                const int c = p >> LOGM;
-                static_for<0, RATIO>([&](auto cI) {
-                    constexpr int cc = decltype(cI)::value;
-                    const float wc = c == cc ? w : 0.f;
-                    y[v + PM * cc].x += z.x * wc;
-                    y[v + PM * cc].y += z.y * wc;
-                });
-            });
-            continue;
-        }
         if (A.placed) {  // workgroup-uniform: xs[v] = sum of the group's rows at element kk_v (loaded below in that order)
             static_for<0, PM>([&](auto vI) {
                 constexpr int v = decltype(vI)::value;

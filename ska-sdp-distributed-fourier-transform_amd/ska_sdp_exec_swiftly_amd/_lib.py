@@ -121,12 +121,6 @@ def _declare(lib):
     ]
     lib.swiftly_hip_wave_subgrid_side_placed.restype = c_int
     lib.swiftly_hip_wave_subgrid_side_placed.argtypes = list(lib.swiftly_hip_wave_subgrid_side.argtypes)
-    lib.swiftly_hip_wave_subgrid_side_halves.restype = c_int
-    lib.swiftly_hip_wave_subgrid_side_halves.argtypes = list(lib.swiftly_hip_wave_subgrid_side.argtypes)
-    lib.swiftly_hip_prepare_facet_window_spectra.restype = c_int
-    lib.swiftly_hip_prepare_facet_window_spectra.argtypes = [
-        vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp, i64, vp,
-    ]
     lib.swiftly_hip_prepare_facet_window_rows.restype = c_int
     lib.swiftly_hip_prepare_facet_window_rows.argtypes = [
         vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp, i64, vp,

@@ -100,9 +100,9 @@ class SwiftlyConfig:
         self._xM_size = xM_size
         self.dask_client = dask_client  # unused: there is no Dask in this backend
         if backend == "hip":
-            # column_precision=64 / axis1_first=True or "fused": the opt-in accuracy modes of the complex64 band pipeline
-            # (float64 arithmetic in the column passes; the contiguous axis finished before the strided one, per wave or
-            # -- cheaper, less accurate: the column passes then work on aliased half spectra -- inside K1)
+            # column_precision=64 / axis1_first=True: the two opt-in accuracy modes of the complex64 band pipeline
+            # (float64 arithmetic in the column passes; the contiguous axis finished before the strided one -- in the
+            # epilogue of K1 where the configuration allows, axis1_first="rows": always by a row pass per wave)
             self._core = SwiftlyCoreHip(W, N, xM_size, yN_size, column_precision=column_precision, axis1_first=axis1_first)
         elif backend in ("numpy", "ska_sdp_func"):
             # reference api.py:137-141 -- those cores live in the reference package; this one is GPU only

@@ -142,9 +142,9 @@ class SwiftlyCoreHip:
 
     def __init__(self, W, N, xM_size, yN_size, device=None, column_precision=None, axis1_first=False):
         # (r6) axis-1-first forward band pipeline (finish_axis1_rows): the streaming classes read this switch
-        # False / True / "fused" (SwiftlyConfig): the axis-1-first order of the band pipeline, with a row pass per wave or --
-        # where the configuration allows -- with the contiguous-axis finish fused into K1 (window half spectra)
-        self.axis1_first = axis1_first if axis1_first in ("fused", "halves") else bool(axis1_first)
+        # False / True / "rows" (SwiftlyConfig): the axis-1-first order of the band pipeline -- True: with the contiguous-axis
+        # finish fused into K1 where the configuration allows (else as "rows"); "rows": always a row pass per wave
+        self.axis1_first = "rows" if axis1_first == "rows" else bool(axis1_first)
         self.W = W
         self.N = N
         self.xM_size = xM_size
@@ -621,26 +621,14 @@ class SwiftlyCoreHip:
         )
         return out
 
-    #: kept band columns per output parity the window-spectra store of the forward K1 can stage in LDS (row_pass.hip,
-    #: row_pass_window_stage_columns)
-    WINDOW_SPECTRA_STAGE_COLUMNS = 5888
     #: physical band columns the window-rows epilogue of the whole-row K1 can stage (row_whole.hip, row_pass_whole_stage_columns)
     WINDOW_ROWS_STAGE_COLUMNS = 12800
 
     def window_starts(self, band, wave_off1s):
         """``(first logical column of the contribution window of wave off1 - band start) mod yN`` for every wave: the
-        ``window_starts`` table of ``swiftly_hip_prepare_facet_window_spectra`` (host list)."""
+        ``window_starts`` table of ``swiftly_hip_prepare_facet_window_rows`` (host list)."""
         m, yN = self.xM_yN_size, self.yN_size
         return [((yN // 2 - m // 2 + int(o) * yN // self.N) - int(band[0])) % yN for o in wave_off1s]
-
-    def supports_window_spectra(self, band, facet_size, facet_off1s):
-        """can the forward K1 store window half spectra (``prepare_facet_window_spectra``) for this band / these facets?
-        (yN = 32768, m = 512, xM <= 2048, the kept columns of one parity fit the LDS stage, 16-byte loads possible)"""
-        return (
-            self.yN_size == 32768 and self.xM_yN_size == 512 and self.xM_size <= 2048 and
-            (int(band[1]) + 1) // 2 <= self.WINDOW_SPECTRA_STAGE_COLUMNS and int(band[1]) < self.yN_size and
-            int(facet_size) % 2 == 0 and all(int(o) % 2 == 0 for o in facet_off1s)
-        )
 
     def supports_window_rows(self, band, facet_size, facet_off1s):
         """can K1 finish the contiguous axis for every planned window in its epilogue (``prepare_facet_window_rows``)?
@@ -667,29 +655,6 @@ class SwiftlyCoreHip:
         cvp = ctypes.c_void_p
         _lib.check(
             self._lib.swiftly_hip_prepare_facet_window_rows(
-                self._handle, self._code(facet), cvp(facet.data_ptr()), int(facet.shape[0]), int(facet.shape[1]),
-                facet.stride(0), cvp(out.data_ptr()), out.stride(0), int(facet_off), int(band[0]), int(band[1]),
-                int(size) if fold_other_axis_window else 0, int(row0), cvp(window_starts.data_ptr()), nwin, self._stream(),
-            )
-        )
-        return out
-
-    def prepare_facet_window_spectra(self, facet, facet_off, band, window_starts, out, fold_other_axis_window=True,
-                                     rows_of=None):
-        """K1 of the axis-1-first pipeline with the contiguous-axis finish fused in
-        (``swiftly_hip_prepare_facet_window_spectra``): ``out[row, w*m + p*m/2 + q]`` = the two half spectra of window
-        ``w`` of every prepared facet row.  ``window_starts``: int32 DEVICE tensor (``window_starts(band, off1s)``);
-        ``out[rows, nwin * m]`` row-major.  The columns ``[w*m, (w+1)*m)`` go to K2 as a band buffer with the band
-        ``(window start, m)``; the subgrid side must run ``wave_subgrid_side(..., placed=2)``."""
-        if facet.dim() != 2 or facet.stride(1) != 1 or out.stride(1) != 1:
-            raise ValueError("prepare_facet_window_spectra needs row-major 2-D device tensors")
-        nwin = int(window_starts.numel())
-        if tuple(out.shape) != (facet.shape[0], nwin * self.xM_yN_size):
-            raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(facet.shape[0], nwin * self.xM_yN_size)}!")
-        size, row0 = rows_of if rows_of is not None else (facet.shape[0], 0)
-        cvp = ctypes.c_void_p
-        _lib.check(
-            self._lib.swiftly_hip_prepare_facet_window_spectra(
                 self._handle, self._code(facet), cvp(facet.data_ptr()), int(facet.shape[0]), int(facet.shape[1]),
                 facet.stride(0), cvp(out.data_ptr()), out.stride(0), int(facet_off), int(band[0]), int(band[1]),
                 int(size) if fold_other_axis_window else 0, int(row0), cvp(window_starts.data_ptr()), nwin, self._stream(),
@@ -862,9 +827,7 @@ class SwiftlyCoreHip:
         cvp = ctypes.c_void_p
         scr = self.scratch("k5b", min(S, 64) * self.xM_size * int(subgrid_size) * 8)
         # axis-1-first pipeline: the rows of G already are Fn * cfft_m along the contiguous axis (finish_axis1_rows)
-        # ... or (placed = 2) the two half spectra of the window (prepare_facet_window_spectra), joined by sum_finish_facets
-        entry = (self._lib.swiftly_hip_wave_subgrid_side, self._lib.swiftly_hip_wave_subgrid_side_placed,
-                 self._lib.swiftly_hip_wave_subgrid_side_halves)[int(placed)]
+        entry = self._lib.swiftly_hip_wave_subgrid_side_placed if placed else self._lib.swiftly_hip_wave_subgrid_side
         _lib.check(
             entry(
                 self._handle, self._code(G), cvp(G.data_ptr()), F, G.stride(0), G.stride(1), self._i64(facet_off0s),

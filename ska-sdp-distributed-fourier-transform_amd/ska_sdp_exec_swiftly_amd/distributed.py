@@ -402,7 +402,6 @@ class DistributedForward:
             if local and self.local.dtype != self.dtype:
                 raise ValueError(f"local facets are {self.local.dtype}, the pass was declared {self.dtype}")
             self.local.dtype = self.dtype
-            self.local.axis1_fused = False  # the receivers place blocks of the per-wave axis-1-first form (unpack_wave)
         self.arrival_cfgs = [self.facet_configs[j] for j in self.sharding.arrival_order]
         # cooperative facets: one single-facet SwiftlyForward per facet over the waves this rank owns; its band buffer
         # is assembled by the band-row exchange of prepare_all_facets instead of its own K1

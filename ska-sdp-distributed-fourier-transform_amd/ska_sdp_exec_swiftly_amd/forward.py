@@ -421,10 +421,9 @@ class SwiftlyForward(WavePrefetch):
             )
             F, yB = len(self._facet_info), self._facet_info[0][1][0]
             mode = self.__dict__["_axis1_mode"] = self._choose_axis1_mode()
-            if mode >= 2:
+            if mode == 2:
                 # axis-1-first pipeline, contiguous-axis finish fused into K1: per facet row, for every planned window, the
-                # finished window row (mode 3, core.prepare_facet_window_rows) or its two half spectra (mode 2,
-                # core.prepare_facet_window_spectra) instead of the band
+                # finished window row (core.prepare_facet_window_rows) instead of the band
                 keys = sorted(self._planned_keys)
                 self.__dict__["_window_of"] = {k: w for w, k in enumerate(keys)}
                 starts = torch.tensor(core.window_starts(self._band, keys), dtype=torch.int32, device=core.device)
@@ -434,10 +433,8 @@ class SwiftlyForward(WavePrefetch):
             for j, cfg in enumerate(self.facet_configs):
                 data = self._ingest.ready(j)
                 t0 = timer.start() if timer is not None else None
-                if mode == 3:
+                if mode == 2:
                     core.prepare_facet_window_rows(data, cfg.off1, self._band, starts, bands[j])
-                elif mode == 2:
-                    core.prepare_facet_window_spectra(data, cfg.off1, self._band, starts, bands[j])
                 else:
                     core.prepare_facet_band(data, cfg.off1, self._band, out=bands[j])
                 if timer is not None:
@@ -464,37 +461,32 @@ class SwiftlyForward(WavePrefetch):
             self._wave_rowmaps[key] = self.core.subgrid_column_rows(by_key.get(key, []))
         return self._wave_rowmaps[key]
 
-    #: may ``axis1_first="fused"`` fuse the contiguous-axis finish into K1 (window half spectra)?  The multi-GPU classes
-    #: exchange band rows / blocks of the per-wave form and switch this off for their local objects.
+    #: may the axis-1-first pipeline fuse the contiguous-axis finish into K1?  The multi-GPU classes switch this off for the
+    #: objects whose band buffers come from the band-row exchange (cooperative facets).
     axis1_fused = True
 
     def _choose_axis1_mode(self):
-        """0: default order; 1: axis-1-first with a row pass per wave (core.finish_axis1_rows; ``axis1_first=True``);
-        2: axis-1-first with the finish fused into K1 (``axis1_first="fused"``; needs a plan -- the windows are the plan's
-        waves -- and a configuration with core.supports_window_spectra, else 1)."""
+        """0: default order; 1: axis-1-first with a row pass per wave (core.finish_axis1_rows; ``axis1_first="rows"``, or
+        ``True`` where 2 is not available); 2: axis-1-first with the finish in the epilogue of K1 (``axis1_first=True``;
+        needs a plan -- the windows are the plan's waves -- and a configuration with core.supports_window_rows)."""
         if not (self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False))):
             return 0
-        how = self.core.axis1_first
-        if how in ("fused", "halves") and self.axis1_fused and self._plan is not None and self._band is not None:
-            args = (self._band, self._facet_info[0][1][1], [cfg.off1 for cfg in self.facet_configs])
-            if how == "fused" and self.core.supports_window_rows(*args):
-                return 3
-            if how == "halves" and self.core.supports_window_spectra(*args):
-                return 2
+        if (self.core.axis1_first is True and self.axis1_fused and self._plan is not None and self._band is not None and
+                self.core.supports_window_rows(self._band, self._facet_info[0][1][1], [cfg.off1 for cfg in self.facet_configs])):
+            return 2
         return 1
 
     def _axis1(self):
         """the axis-1-first mode of this object (``SwiftlyConfig(axis1_first=True)``, wave_axis = 1): 0 = off, 1 = row pass
-        per wave, 2 = fused into K1 (decided when the facets are prepared); doubles as the ``placed`` argument of the
-        subgrid side"""
+        per wave, 2 = fused into K1 (decided when the facets are prepared)"""
         mode = self.__dict__.get("_axis1_mode")
         if mode is None:
             mode = self._choose_axis1_mode() if self.BF_Fs_persist is None else 0
         return mode
 
     def _placed(self):
-        """the ``placed`` argument of the subgrid side for this object's axis-1-first mode (0 none, 1 finished rows, 2 halves)"""
-        return (0, 1, 2, 1)[self._axis1()]
+        """the ``placed`` argument of the subgrid side: in both axis-1-first modes the blocks arrive finished along axis 1"""
+        return bool(self._axis1())
 
     def _k2_source(self, off1):
         """``(bands, band)`` that K2 of wave ``off1`` reads: the K1 band buffers and the plan's band -- or, in the
@@ -504,7 +496,7 @@ class SwiftlyForward(WavePrefetch):
         mode = self._axis1()
         if not mode:
             return bands, self._band
-        if mode >= 2:  # the window's finished row / half spectra: m columns of the K1 output, read as a band that is exactly the window
+        if mode == 2:  # the window's finished rows: m columns of the K1 output, read as a band that is exactly the window
             core = self.core
             m, w = core.xM_yN_size, self._window_of[int(off1)]
             start = (core.window_starts(self._band, [off1])[0] + self._band[0]) % core.yN_size

@@ -116,8 +116,9 @@ def forward_chain_reordered(P, facet, fo, so, bits, scratch_split=None, round_st
     its m-point transforms (placement + xM-point inverse + crop).  Same stored intermediates otherwise.  bits as in
     forward_chain (k1 covers the fused epilogue).
 
-    halves=True: the form that CAN live in the K1 epilogue of the HIP kernels (SwiftlyConfig(axis1_first="fused")) -- each of
-    a row's two workgroups holds the outputs of one parity, so K1 stores the two decimation-in-time half spectra of the window
+    halves=True: the form that can live in the epilogue of the TWO-workgroup K1 (built and measured in r6, then replaced by the
+    whole-row K1 that finishes the window itself) -- each of a row's two workgroups holds the outputs of one parity, so that
+    K1 can only store the two decimation-in-time half spectra of the window
     (m/2-point transforms of the even / odd window samples); K2 and K3 run on those, and the radix-2 step that joins them,
     the phase of the window rotation and Fn follow K3.  The halves are ALIASED (frequency u folded onto u + m/2): the column
     passes round at the level of the window's leakage that Fn would have suppressed."""

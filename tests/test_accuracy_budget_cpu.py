@@ -49,13 +49,14 @@ def test_axis1_first_order_removes_the_double_window_from_the_column_passes():
         assert rows[f"reordered: float32 arithmetic in {st} only"] < 2e-6
 
 
-def test_fusing_the_axis1_finish_into_k1_costs_part_of_the_gain():
-    """(r6) The form of the axis-1-first order that fits the K1 epilogue of the HIP kernels (axis1_first="fused"): each of a
-    row's two workgroups holds one output parity, so what K1 can store per window are the two decimation-in-time HALF spectra;
-    K2 / K3 run on those and the radix-2 join + Fn follow.  The halves are aliased (u folded onto u + m/2), so the column
-    passes -- and even the complex64 STORES -- round at the level of the window leakage that Fn has not yet suppressed:
-    7.4e-6 all-float32 on the probe configuration (default order 1.3e-5, row pass per wave 2.1e-6), 1.8e-6 with float64
-    arithmetic everywhere (3.7e-7 for the row pass).  HIP kernels on the N = 65536 workload: 5.8e-6 against 1.03e-5 / 2.04e-6."""
+def test_half_spectra_from_the_two_workgroup_k1_would_cost_part_of_the_gain():
+    """(r6, measured and removed) The two-workgroup K1 holds one output parity per workgroup, so what IT can store per window
+    are the two decimation-in-time HALF spectra; K2 / K3 would run on those and the radix-2 join + Fn follow.  The halves are
+    aliased (u folded onto u + m/2), so the column passes -- and even the complex64 STORES -- round at the level of the window
+    leakage that Fn has not yet suppressed: 7.4e-6 all-float32 on the probe configuration (default order 1.3e-5, finished
+    rows 2.1e-6), 1.8e-6 with float64 arithmetic everywhere (3.7e-7 for finished rows).  HIP kernels of that form on the
+    N = 65536 workload: 5.8e-6 at 41.0 ms.  What ships instead finishes the window in the epilogue of a WHOLE-ROW K1 (one
+    workgroup owns both parities): 2.04e-6 at 39.2 ms."""
     all32 = am.halves_error()
     stores_only = am.halves_error(bits=dict(k1=64, k2=64, k3=64, sf=64, k5=64))
     print(f"{all32:.3e}  halves: float32 arithmetic everywhere")

@@ -393,65 +393,48 @@ def test_finish_axis1_rows_matches_oracle():
             assert rel < 2e-6, (sub_off1, f, rel)
 
 
-def test_window_spectra_store_of_k1_matches_the_band_store():
-    """(r6) the forward K1 with the contiguous-axis finish fused in (swiftly_hip_prepare_facet_window_spectra): for every
-    planned window w the two decimation-in-time half spectra of the window samples, computed by the workgroup that holds
-    the outputs of that parity.  Checked against numpy transforms of the SAME kernel's band store (which the oracle pins:
-    test_prepare_facet_band_*), including a window at the very start / end of the band, odd and even window starts and a
-    band that wraps around the padded axis."""
+def test_window_rows_store_of_the_whole_row_k1_matches_the_row_pass_per_wave():
+    """(r6) the forward K1 with the contiguous-axis finish in its epilogue (swiftly_hip_prepare_facet_window_rows: one
+    persistent workgroup per CU owns whole rows, stages the band in LDS and finishes every planned window): for every window
+    what finish_axis1_rows (pinned on the oracle above) makes of the band store of the two-workgroup K1 for that wave --
+    including windows at the very start / end of the band, odd and even window starts and a band that wraps around."""
     import torch
 
     core, _ = core64()
     rng = numpy.random.default_rng(17)
-    rows, size, m = 10, 352, 512
+    rows, size, m = 300, 352, 512   # more rows than workgroups: the persistent loop (row prefetch, stage reuse) runs
     facet = (rng.standard_normal((rows, size)) + 1j * rng.standard_normal((rows, size))).astype(numpy.complex64)
     dev = torch.from_numpy(facet).cuda()
     for foff, wave_off1s in ((0, [0, 928, 3 * 928, -2 * 928]), (64 * 352, [-928, 5 * 928, 7 * 928 + 2, 12 * 928 + 6]),
-                             (-32 * 352, [30 * 928, 33 * 928, 35 * 928 + 4])):
+                             (-32 * 352, [30 * 928, 33 * 928, 35 * 928 + 4] + [30 * 928 + 2 * k for k in range(1, 9)])):
         band = core.band_for_offsets(wave_off1s)
-        assert core.supports_window_spectra(band, size, [foff])
+        assert core.supports_window_rows(band, size, [foff])
         starts = core.window_starts(band, wave_off1s)
         assert min(starts) >= 0 and max(starts) + m <= band[1]
-        plain = core.prepare_facet_band(dev, foff, band).cpu().numpy()
-        pc = band_cols(yN64, band)
         sd = torch.tensor(starts, dtype=torch.int32, device="cuda")
-        out = torch.full((rows, len(starts) * m), float("nan"), dtype=torch.complex64, device="cuda")
-        core.prepare_facet_window_spectra(dev, foff, band, sd, out)
-        got = out.cpu().numpy()
-        assert numpy.isfinite(got.view(numpy.float32)).all()
-        for w, d in enumerate(starts):
-            i = numpy.arange(m)
-            b = plain[:, pc[(band[0] + d + i) % yN64]].astype(complex)          # logical window samples
-            for p in (0, 1):
-                want = numpy.fft.fft(b[:, p::2], axis=1)
-                rel = relrms(got[:, w * m + p * (m // 2):w * m + (p + 1) * (m // 2)], want)
-                assert rel < 5e-7, (foff, w, p, rel)
-        # ... and the form with the COMPLETE contiguous-axis finish in the epilogue of the whole-row K1: for every window what
-        # finish_axis1_rows makes of the band for that wave
-        assert core.supports_window_rows(band, size, [foff])
         full = torch.full((rows, len(starts) * m), float("nan"), dtype=torch.complex64, device="cuda")
         core.prepare_facet_window_rows(dev, foff, band, sd, full)
-        gotf = full.cpu().numpy()
-        assert numpy.isfinite(gotf.view(numpy.float32)).all()
+        got = full.cpu().numpy()
+        assert numpy.isfinite(got.view(numpy.float32)).all()
         bands1 = core.prepare_facet_band(dev, foff, band)[None]
         for w, off1 in enumerate(wave_off1s):
             want, wband = core.finish_axis1_rows(bands1, [foff], band, off1)
             assert wband[0] == (band[0] + starts[w]) % yN64
-            rel = relrms(gotf[:, w * m:(w + 1) * m], want[0].cpu().numpy())
+            rel = relrms(got[:, w * m:(w + 1) * m], want[0].cpu().numpy())
             assert rel < 5e-7, (foff, w, rel)
-    # unsupported shapes are refused, not approximated: a band with more kept columns per parity than the LDS stage holds
-    wide = (0, 2 * core.WINDOW_SPECTRA_STAGE_COLUMNS + 2)
-    assert not core.supports_window_spectra(wide, size, [0])
+    # unsupported shapes are refused, not approximated: a band wider than the LDS stage
+    wide = (0, core.WINDOW_ROWS_STAGE_COLUMNS + 64)
+    assert not core.supports_window_rows(wide, size, [0])
     with pytest.raises(Exception):
-        core.prepare_facet_window_spectra(dev, 0, wide, torch.zeros(1, dtype=torch.int32, device="cuda"),
-                                          torch.empty((rows, m), dtype=torch.complex64, device="cuda"))
+        core.prepare_facet_window_rows(dev, 0, wide, torch.zeros(1, dtype=torch.int32, device="cuda"),
+                                       torch.empty((rows, m), dtype=torch.complex64, device="cuda"))
 
 
 def test_axis1_first_pipeline_matches_oracle_and_default_order():
     """(r6) SwiftlyConfig(axis1_first=True): the forward band pipeline with the contiguous axis finished before K2 / K3
     gives the oracle's subgrids (tighter than the default order: its float32 rounding acts on singly windowed data) in
-    any request order, with and without the planned-wave prefetch -- in both of its forms: the finish fused into K1 (window
-    half spectra, joined by sum_finish_facets; what a planned pass on this configuration runs) and a row pass per wave."""
+    any request order, with and without the planned-wave prefetch -- in both of its forms: the finish in the epilogue of the
+    whole-row K1 (what a planned pass on this configuration runs) and a row pass per wave (axis1_first="rows")."""
     import torch
 
     import ska_sdp_exec_swiftly_amd as sw
@@ -468,7 +451,7 @@ def test_axis1_first_pipeline_matches_oracle_and_default_order():
     for c in sg_cfgs:
         waves.setdefault(c.off1, []).append(c)
     ref = sw.SwiftlyForward(cfg0, list(zip(facet_cfgs, facets)), subgrid_configs=sg_cfgs, wave_axis=1)
-    for prefetch, fused in ((True, "fused"), (False, "fused"), (True, "halves"), (False, "halves"), (True, True), (False, True)):
+    for prefetch, fused in ((True, True), (False, True), (True, "rows"), (False, "rows")):
         old = sw.api._PREFETCH
         sw.api._PREFETCH = prefetch
         try:
@@ -481,11 +464,11 @@ def test_axis1_first_pipeline_matches_oracle_and_default_order():
                     want = so.subgrid(orc.CoverItem(c.off0, c.off1, c.size))
                     assert relrms(got[k], want) < 4e-6, (prefetch, fused, key, k, relrms(got[k], want))
                     assert relrms(got[k], base[k]) < 3e-5
-            assert fwd._axis1() == {"fused": 3, "halves": 2, True: 1}[fused]  # pylint: disable=protected-access
+            assert fwd._axis1() == {True: 2, "rows": 1}[fused]  # pylint: disable=protected-access
         finally:
             sw.api._PREFETCH = old
     # without a plan there are no windows to fuse: the row pass per wave
-    cfg.core.axis1_first = "fused"
+    cfg.core.axis1_first = True
     fwd = sw.SwiftlyForward(cfg, list(zip(facet_cfgs, facets)), wave_axis=1)
     key = sorted(waves)[1]
     got = fwd.get_wave(waves[key]).cpu().numpy()
@@ -495,8 +478,8 @@ def test_axis1_first_pipeline_matches_oracle_and_default_order():
     # pickling carries the switch (core.py:512-525: only parameters travel)
     import pickle
 
-    assert pickle.loads(pickle.dumps(cfg.core)).axis1_first == "fused"
-    assert sw.SwiftlyConfig(backend="hip", axis1_first=True, **P).core.axis1_first is True
+    assert pickle.loads(pickle.dumps(cfg.core)).axis1_first is True
+    assert pickle.loads(pickle.dumps(sw.SwiftlyConfig(backend="hip", axis1_first="rows", **P).core)).axis1_first == "rows"
 
 
 def test_axis1_first_through_the_multi_gpu_classes():
