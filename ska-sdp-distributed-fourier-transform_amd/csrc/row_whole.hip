@@ -36,7 +36,7 @@ int row_pass_whole_grid() {  // one workgroup per CU (256 VGPRs x 512 threads: a
 template <int NSEG, bool WIN = false>
 static int launch_whole_inst(const RowPassArgs& a, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
     const int grid = a.nrows < row_pass_whole_grid() ? a.nrows : row_pass_whole_grid();
-    hipLaunchKernelGGL((row_pass_whole_kernel<NSEG, WIN>), dim3((unsigned)grid), dim3(RGeoWhole::NT), RGeoWhole::LDS_BYTES, s, a,
+    hipLaunchKernelGGL((row_pass_whole_kernel<NSEG, WIN>), dim3((unsigned)grid), dim3(RGeoWhole::NT), WIN ? kWholeWinLds : RGeoWhole::LDS_BYTES, s, a,
                        a.in, a.out, tw14, tw_full, a.row_win, a.in_rowmap);
     return (int)hipGetLastError();
 }
@@ -46,7 +46,7 @@ static int launch_whole_inst(const RowPassArgs& a, const cx<float>* tw14, const 
 int launch_row_pass_whole(const RowPassArgs& a, int nseg, const cx<float>* tw14, const cx<float>* tw_full, hipStream_t s) {
     if (!a.ld_win4 || !a.twc || a.band_len <= 0 || !(a.conj_ld && a.conj_st)) return -2;
     if (a.win_full) {
-        if (a.win_logm != 9 || !a.win_d || a.nwin <= 0 || !a.win_fn || !a.win_tw_m || !a.win_twc_m ||
+        if (a.win_logm != 9 || !a.win_d || a.nwin <= 0 || a.nwin > kWholeMaxWindows || !a.win_fn || !a.win_tw_m || !a.win_twc_m ||
             2 * a.band_half > row_pass_whole_stage_columns())
             return -2;
         switch (nseg) {
@@ -67,12 +67,12 @@ int launch_row_pass_whole(const RowPassArgs& a, int nseg, const cx<float>* tw14,
 
 int row_pass_whole_stage_columns() {
     using GM = Geo<float, 9, 3, RGeoWhole::NT, false>;
-    return (int)((RGeoWhole::LDS_BYTES - GM::LDS_BYTES) / 8) & ~31;
+    return (int)((RGeoWhole::LDS_BYTES - GM::LDS_BYTES) / 8) & ~31;  // stage | m-point exchange rows
 }
 template <int NSEG, bool WIN>
 static int init_whole_inst() {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_pass_whole_kernel<NSEG, WIN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)RGeoWhole::LDS_BYTES);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WIN ? kWholeWinLds : RGeoWhole::LDS_BYTES));
 }
 int init_row_pass_whole() {
     int rc = init_whole_inst<16, false>();

@@ -109,6 +109,9 @@ __device__ __forceinline__ void opaque_values(cx<float> (&v)[K]) {
 
 // WIN (RowPassArgs::win_full): the band of a row is staged in the exchange buffer (free once the last gather is done) and the
 // epilogue finishes the contiguous axis for every planned window (see RowPassArgs) -- the K1 of the axis-1-first pipeline.
+constexpr int kWholeMaxWindows = 256;
+// exchange buffer | Fn | window table of the window epilogue
+constexpr size_t kWholeWinLds = RGeoWhole::LDS_BYTES + 512 * sizeof(float) + kWholeMaxWindows * sizeof(int);
 template <int NSEG, bool WIN = false>
 __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArgs A, const cx<float>* __restrict__ gin,
                                                                 cx<float>* __restrict__ gout,
@@ -212,6 +215,13 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
     };
     int row = blockIdx.x;
     if (row >= A.nrows) return;
+    if constexpr (WIN) {
+        // Fn (m floats) BEHIND the exchange buffer: the row exchanges never touch it (kWholeWinLds bytes of LDS for WIN launches)
+        float* fn_w = reinterpret_cast<float*>(smem + G::LDS_BYTES);
+        if (t < 512) fn_w[t] = A.win_fn[t];
+        int* wd = reinterpret_cast<int*>(fn_w + 512);   // ... and the window table (host-checked: nwin <= kWholeMaxWindows)
+        if (t < A.nwin) wd[t] = A.win_d[t];
+    }
 #if SWF_TRACE
 #define SWF_WTRACE(id)                                                                                             \
     do {                                                                                                           \
@@ -439,18 +449,33 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
         store_half(xb, 1, rphi1, region1, [](auto) {});
         if constexpr (WIN) {
             // -- window epilogue: the row's band is staged once every wave has passed the barrier ----------------------------
-            using GM = Geo<float, 9, 3, G::NT, false>;   // m = 512 (host-checked): one wave per transform, 8 points per lane
-            static_assert(GM::T == 64 && GM::WAVE_ROWS && GM::LDS_BYTES <= G::LDS_BYTES, "window transform geometry");
+            // Nothing in the window loop reads global memory (a load behind the previous window's stores waits for THEIR
+            // completion: one counter for both): Fn and the window table sit in LDS behind the exchange buffer, the six twiddle
+            // table values of the lane in registers.  A round of eight windows (one per wave) costs 1.8 us per row either way --
+            // 268 vector instructions per window with two waves per SIMD, i.e. the epilogue is bound by its own arithmetic and
+            // index calculations, and a 25th window rides in the slack of the waves that have only three (tools/time_k1_window_rows.py).
+            using GM = SFCompact<Geo<float, 9, 3, G::NT, false>>;   // m = 512 (host-checked): one wave per transform, 8 points per lane
+            static_assert(GM::T == 64 && GM::WAVE_ROWS && GM::LOGP == 3, "window transform geometry");
             constexpr int M = GM::N;
             wg_sync();
             const int lane = tt & 63;
             const int wv = __builtin_amdgcn_readfirstlane(tt >> 6);
             const cx<float>* __restrict__ stage = buf;
             cx<float>* ex = buf + 2 * A.band_half;       // the m-point exchanges behind the stage (host-checked: it fits)
+            const float* __restrict__ fn_l = reinterpret_cast<const float*>(smem + G::LDS_BYTES);
+            const int* __restrict__ wd_l = reinterpret_cast<const int*>(fn_l + 512);
             cx<float>* __restrict__ orow = gout + (long long)urow * A.out_pitch;
             const int sp = A.win_sp;
+            cx<float> pre1[3], pre2[3];
+            load_compact<GM, float, 3, 3>(pre1, lane, A.win_twc_m);
+            load_compact<GM, float, 6, 3>(pre2, lane, A.win_twc_m);
+            float wgt[GM::P];   // Fn at the lane's outputs e = lane + 64 r
+            static_for<0, GM::P>([&](auto rI) {
+                constexpr int r = decltype(rI)::value;
+                wgt[r] = fn_l[(((lane + 64 * r) ^ (M >> 1)) - sp) & (M - 1)];
+            });
             for (int w = wv; w < A.nwin; w += G::NT / 64) {   // wave-uniform
-                const int D = __builtin_amdgcn_readfirstlane(A.win_d[w]);
+                const int D = __builtin_amdgcn_readfirstlane(wd_l[w]);
                 const int s = (A.band_start + D - (N / 2 - M / 2)) & (M - 1);   // off1 yN / N of the wave, mod m
                 cx<float> xw[GM::P];
                 static_for<0, GM::P>([&](auto vI) {
@@ -461,13 +486,17 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
                     xw[v] = stage[(d & 1) * A.band_half + (d >> 1)];
                 });
                 cx<float>* __restrict__ ow = orow + (long long)w * M;
-                fft_phases<SFCompact<GM>, float, 0>(xw, lane, wv, false, ex, A.win_tw_m, [&](int e, cx<float> v) {
-                    const int ck = e ^ (M >> 1);
-                    const int kk = (ck - sp) & (M - 1);
-                    const float wgt = A.win_fn[kk];
+                phase_compute<GM, float, 0, 3>(xw, lane, A.win_tw_m, nullptr, A.win_twc_m);
+                phase_exchange<GM, float, 0, 3>(xw, lane, wv, false, ex);
+                phase_compute<GM, float, 3, 3>(xw, lane, A.win_tw_m, pre1, A.win_twc_m);
+                phase_exchange<GM, float, 3, 3>(xw, lane, wv, false, ex);
+                phase_compute<GM, float, 6, 3>(xw, lane, A.win_tw_m, pre2, A.win_twc_m);
+                phase_scatter<GM, float, 6, 3>(xw, lane, [&](int e, cx<float> v, auto rI) {
+                    constexpr int r = decltype(rI)::value;       // e = lane + 64 r
+                    const int kk = ((e ^ (M >> 1)) - sp) & (M - 1);
                     const int i2 = (kk - s) & (M - 1);
-                    ow[(i2 & 1) * (M >> 1) + (i2 >> 1)] = cx<float>{v.x * wgt, v.y * wgt};
-                }, nullptr, A.win_twc_m);
+                    ow[(i2 & 1) * (M >> 1) + (i2 >> 1)] = cx<float>{v.x * wgt[r], v.y * wgt[r]};
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
         }
