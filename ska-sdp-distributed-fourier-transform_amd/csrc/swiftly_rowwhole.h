@@ -477,25 +477,32 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
             for (int w = wv; w < A.nwin; w += G::NT / 64) {   // wave-uniform
                 const int D = __builtin_amdgcn_readfirstlane(wd_l[w]);
                 const int s = (A.band_start + D - (N / 2 - M / 2)) & (M - 1);   // off1 yN / N of the wave, mod m
+                // The lane's eight elements (plain index lane + 64 v = centred element lane + 64 (v ^ 4)) are the window elements
+                // i_v = (r0 + 64 (v ^ 4)) mod m with r0 = (lane - s) mod m = 64 h + l: they share their parity, and their
+                // band distances D + i_v differ by multiples of 64, i.e. their stage columns by multiples of 32 --
+                // one base address per window, three instructions per element.
                 cx<float> xw[GM::P];
-                static_for<0, GM::P>([&](auto vI) {
-                    constexpr int v = decltype(vI)::value;
-                    const int ci = (lane + v * 64) ^ (M >> 1);   // centred element of x (plain index lane + 64 v)
-                    const int i = (ci - s) & (M - 1);            // window element that lands there
-                    const int d = D + i;                         // its band distance (windows lie inside the band)
-                    xw[v] = stage[(d & 1) * A.band_half + (d >> 1)];
-                });
-                cx<float>* __restrict__ ow = orow + (long long)w * M;
+                {
+                    const int r0 = (lane - s) & (M - 1), h = r0 >> 6, l = r0 & 63;
+                    const int d0 = D + l;                              // band distance of element 64 k + l is d0 + 64 k
+                    const cx<float>* __restrict__ g0 = stage + (d0 & 1) * A.band_half + (d0 >> 1);
+                    static_for<0, GM::P>([&](auto vI) {
+                        constexpr int v = decltype(vI)::value;
+                        xw[v] = g0[((h + (v ^ 4)) & 7) << 5];
+                    });
+                }
                 phase_compute<GM, float, 0, 3>(xw, lane, A.win_tw_m, nullptr, A.win_twc_m);
                 phase_exchange<GM, float, 0, 3>(xw, lane, wv, false, ex);
                 phase_compute<GM, float, 3, 3>(xw, lane, A.win_tw_m, pre1, A.win_twc_m);
                 phase_exchange<GM, float, 3, 3>(xw, lane, wv, false, ex);
                 phase_compute<GM, float, 6, 3>(xw, lane, A.win_tw_m, pre2, A.win_twc_m);
-                phase_scatter<GM, float, 6, 3>(xw, lane, [&](int e, cx<float> v, auto rI) {
-                    constexpr int r = decltype(rI)::value;       // e = lane + 64 r
-                    const int kk = ((e ^ (M >> 1)) - sp) & (M - 1);
-                    const int i2 = (kk - s) & (M - 1);
-                    ow[(i2 & 1) * (M >> 1) + (i2 >> 1)] = cx<float>{v.x * wgt[r], v.y * wgt[r]};
+                // outputs e = lane + 64 r = centred lane + 64 (r ^ 4): kk = (centred - s'1) mod m, window-band position
+                // i2 = (kk - s) mod m = (t0 + 64 (r ^ 4)) mod m with t0 = (lane - s'1 - s) mod m -- the same structure
+                const int t0 = (lane - sp - s) & (M - 1), h2 = t0 >> 6, l2 = t0 & 63;
+                cx<float>* __restrict__ o0 = orow + (long long)w * M + (l2 & 1) * (M >> 1) + (l2 >> 1);
+                phase_scatter<GM, float, 6, 3>(xw, lane, [&](int, cx<float> v, auto rI) {
+                    constexpr int r = decltype(rI)::value;
+                    o0[((h2 + (r ^ 4)) & 7) << 5] = pkc(pkv(v) * f32x2{wgt[r], wgt[r]});
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
