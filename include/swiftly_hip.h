@@ -434,8 +434,10 @@ int swiftly_hip_wave_subgrid_side_placed(swiftly_hip_t* h, int dtype, const void
  * persistent workgroup per CU that owns whole rows -- both output parities -- stages the band of a row in LDS (it never
  * reaches memory) and stores for each of the `nwindows` contribution windows of the plan (window w = the m columns from
  * logical column band_start + window_starts[w], all inside the band) exactly what finish_axis1_rows produces for wave w:
- *     out[row][w*m ..] = parity-split window band of  Fn[k] cfft_m(window w)[(k + s'1) mod m]
- * so the columns [w*m, (w+1)*m) go to prepare_facet_columns / wave_facet_side with the band (window start, m) and the
+ *     out[row*out_row_stride + w*out_window_stride ..] = parity-split window band of  Fn[k] cfft_m(window w)[(k + s'1) mod m]
+ * (wave-major [nwindows][rows][m]: out_row_stride = m, out_window_stride = rows*m -- what the pipeline uses: K2 of wave w then
+ * reads one contiguous block; or side by side in a row: out_row_stride >= nwindows*m, out_window_stride = m)
+ * so the rows of window w go to prepare_facet_columns / wave_facet_side with the band (window start, m) and the
  * blocks to wave_subgrid_side_placed.  No band buffer, no row pass per wave.  window_starts: DEVICE int32 table.
  * yN_size 32768, m = 512, even facet size / offset / row stride, a band of at most 12800 physical columns (the LDS stage);
  * SWIFTLY_ERR_UNSUPPORTED otherwise: use prepare_facet_band + finish_axis1_rows.  complex64. */
@@ -443,7 +445,7 @@ int swiftly_hip_prepare_facet_window_rows(swiftly_hip_t* h, int dtype, const voi
                                           int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                           int64_t band_start, int64_t band_len, int64_t other_axis_size,
                                           int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
-                                          void* stream);
+                                          int64_t out_window_stride, void* stream);
 /* Backward subgrid side for all facets at once (mirror of sum_finish_facets): in[b] = [xM, subgrid_size] =
  * prepare_subgrid of subgrid b along axis 0 ONLY (core.py:328-368); out[f][b] = [m, m] contiguous = the contribution
  * of subgrid b to facet f, i.e. api_helper.prepare_and_split_subgrid (api_helper.py:115-139): prepare_subgrid along

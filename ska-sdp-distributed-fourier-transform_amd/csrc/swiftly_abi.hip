@@ -1491,7 +1491,7 @@ int swiftly_hip_prepare_facet_band(swiftly_hip_t* h, int dtype, const void* in, 
 static int prepare_facet_band_rows_impl(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t facet_size,
                                         int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                         int64_t band_start, int64_t band_len, int64_t other_axis_size,
-                                        int64_t other_axis_row0, const int32_t* win_d, int64_t nwin, int win_full,
+                                        int64_t other_axis_row0, const int32_t* win_d, int64_t nwin, int64_t win_full,
                                         void* stream) {
     const int fold_other_axis_window = other_axis_size > 0;
     if (!h || !in || !out) return fail(SWIFTLY_ERR_PARAM, "null argument");
@@ -1538,6 +1538,7 @@ static int prepare_facet_band_rows_impl(swiftly_hip_t* h, int dtype, const void*
     if (!twh || !twf) return fail(SWIFTLY_ERR_HIP, "internal: missing twiddle tables");
     if (win_d && win_full) {  // complete window rows (whole-row kernel)
         r.win_full = 1;
+        r.win_pitch = win_full;  // (the flag carries the window stride)
         r.win_d = win_d; r.nwin = (int)nwin; r.win_logm = h->log_m;
         r.win_sp = pmod(floordiv(facet_off * h->xM, h->N), (int)h->m);
         r.win_fn = h->fn_f;
@@ -1568,11 +1569,14 @@ int swiftly_hip_prepare_facet_window_rows(swiftly_hip_t* h, int dtype, const voi
                                           int64_t in_row_stride, void* out, int64_t out_row_stride, int64_t facet_off,
                                           int64_t band_start, int64_t band_len, int64_t other_axis_size,
                                           int64_t other_axis_row0, const int32_t* window_starts, int64_t nwindows,
-                                          void* stream) {
+                                          int64_t out_window_stride, void* stream) {
     if (!window_starts || nwindows <= 0) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_rows: no windows");
-    if (h && out_row_stride < nwindows * h->m) return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_rows: output rows hold nwindows * m columns");
+    if (h && (out_window_stride < h->m || out_row_stride < h->m ||
+              (out_window_stride < rows * out_row_stride && out_row_stride < nwindows * out_window_stride)))
+        return fail(SWIFTLY_ERR_PARAM, "prepare_facet_window_rows: the window rows of the output overlap (row stride %lld, window stride %lld)",
+                    (long long)out_row_stride, (long long)out_window_stride);
     return prepare_facet_band_rows_impl(h, dtype, in, rows, facet_size, in_row_stride, out, out_row_stride, facet_off, band_start,
-                                        band_len, other_axis_size, other_axis_row0, window_starts, nwindows, 1, stream);
+                                        band_len, other_axis_size, other_axis_row0, window_starts, nwindows, out_window_stride, stream);
 }
 
 int swiftly_hip_finish_facet_band(swiftly_hip_t* h, int dtype, const void* in, int64_t rows, int64_t in_row_stride,

@@ -81,6 +81,7 @@ struct RowPassArgs {
     int win_full;                 // 1: this form
     const int* win_d;             // device table, nwin entries: (first logical column of window w - band_start) mod N
     int nwin, win_logm;           // windows of 2^win_logm columns, every one inside the band
+    long long win_pitch;          // elements between the rows of consecutive windows in `out` (m: side by side in a row)
     int win_sp;                   // s'1 = floor(facet_off1 * xM / N) mod m of this facet
     const float* win_fn;          // Fn[m]
     const cx<float>* win_tw_m;    // twiddle table of length m and its compact sections for m / 64 points per lane

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
                 // outputs e = lane + 64 r = centred lane + 64 (r ^ 4): kk = (centred - s'1) mod m, window-band position
                 // i2 = (kk - s) mod m = (t0 + 64 (r ^ 4)) mod m with t0 = (lane - s'1 - s) mod m -- the same structure
                 const int t0 = (lane - sp - s) & (M - 1), h2 = t0 >> 6, l2 = t0 & 63;
-                cx<float>* __restrict__ o0 = orow + (long long)w * M + (l2 & 1) * (M >> 1) + (l2 >> 1);
+                cx<float>* __restrict__ o0 = orow + (long long)w * A.win_pitch + (l2 & 1) * (M >> 1) + (l2 >> 1);
                 phase_scatter<GM, float, 6, 3>(xw, lane, [&](int, cx<float> v, auto rI) {
                     constexpr int r = decltype(rI)::value;
                     o0[((h2 + (r ^ 4)) & 7) << 5] = pkc(pkv(v) * f32x2{wgt[r], wgt[r]});

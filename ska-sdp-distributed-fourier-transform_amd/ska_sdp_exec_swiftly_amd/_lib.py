@@ -123,7 +123,7 @@ def _declare(lib):
     lib.swiftly_hip_wave_subgrid_side_placed.argtypes = list(lib.swiftly_hip_wave_subgrid_side.argtypes)
     lib.swiftly_hip_prepare_facet_window_rows.restype = c_int
     lib.swiftly_hip_prepare_facet_window_rows.argtypes = [
-        vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp, i64, vp,
+        vp, c_int, vp, i64, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp, i64, i64, vp,
     ]
     lib.swiftly_hip_finish_axis1_rows.restype = c_int
     lib.swiftly_hip_finish_axis1_rows.argtypes = [vp, c_int, vp, i64, i64, i64, i64, pi64, i64, i64, i64, vp, i64, i64, vp]

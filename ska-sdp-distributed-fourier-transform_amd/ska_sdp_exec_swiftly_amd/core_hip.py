@@ -642,22 +642,30 @@ class SwiftlyCoreHip:
     def prepare_facet_window_rows(self, facet, facet_off, band, window_starts, out, fold_other_axis_window=True,
                                   rows_of=None):
         """K1 of the axis-1-first pipeline with the COMPLETE contiguous-axis finish in its epilogue
-        (``swiftly_hip_prepare_facet_window_rows``, whole-row kernel): ``out[row, w*m:(w+1)*m]`` = what
-        ``finish_axis1_rows`` gives for wave ``w`` (the parity-split window band of ``Fn * cfft_m``).  ``window_starts``:
-        int32 DEVICE tensor (``window_starts(band, off1s)``); ``out[rows, nwin * m]`` row-major.  Hand the column blocks to
-        K2 with the band ``(window start, m)`` and run ``wave_subgrid_side(..., placed=1)``."""
-        if facet.dim() != 2 or facet.stride(1) != 1 or out.stride(1) != 1:
-            raise ValueError("prepare_facet_window_rows needs row-major 2-D device tensors")
+        (``swiftly_hip_prepare_facet_window_rows``, whole-row kernel): ``out[w, row, :]`` = what ``finish_axis1_rows`` gives
+        for wave ``w`` (the parity-split window band of ``Fn * cfft_m``).  ``window_starts``: int32 DEVICE tensor
+        (``window_starts(band, off1s)``); ``out``: ``[nwin, rows, m]`` (wave-major: K2 of a wave reads one contiguous block)
+        or ``[rows, nwin * m]`` (the windows of a row side by side).  Hand ``out[w]`` (or the column block) to K2 with the
+        band ``(window start, m)`` and run ``wave_subgrid_side(..., placed=True)``."""
+        m = self.xM_yN_size
         nwin = int(window_starts.numel())
-        if tuple(out.shape) != (facet.shape[0], nwin * self.xM_yN_size):
-            raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(facet.shape[0], nwin * self.xM_yN_size)}!")
+        if facet.dim() != 2 or facet.stride(1) != 1 or out.stride(-1) != 1:
+            raise ValueError("prepare_facet_window_rows needs row-major device tensors")
+        if out.dim() == 3 and tuple(out.shape) == (nwin, facet.shape[0], m):
+            row_stride, win_stride = out.stride(1), out.stride(0)
+        elif out.dim() == 2 and tuple(out.shape) == (facet.shape[0], nwin * m):
+            row_stride, win_stride = out.stride(0), m
+        else:
+            raise ValueError(f"Output array has shape {tuple(out.shape)}, expected {(nwin, facet.shape[0], m)} or "
+                             f"{(facet.shape[0], nwin * m)}!")
         size, row0 = rows_of if rows_of is not None else (facet.shape[0], 0)
         cvp = ctypes.c_void_p
         _lib.check(
             self._lib.swiftly_hip_prepare_facet_window_rows(
                 self._handle, self._code(facet), cvp(facet.data_ptr()), int(facet.shape[0]), int(facet.shape[1]),
-                facet.stride(0), cvp(out.data_ptr()), out.stride(0), int(facet_off), int(band[0]), int(band[1]),
-                int(size) if fold_other_axis_window else 0, int(row0), cvp(window_starts.data_ptr()), nwin, self._stream(),
+                facet.stride(0), cvp(out.data_ptr()), row_stride, int(facet_off), int(band[0]), int(band[1]),
+                int(size) if fold_other_axis_window else 0, int(row0), cvp(window_starts.data_ptr()), nwin, win_stride,
+                self._stream(),
             )
         )
         return out

@@ -427,7 +427,8 @@ class SwiftlyForward(WavePrefetch):
                 keys = sorted(self._planned_keys)
                 self.__dict__["_window_of"] = {k: w for w, k in enumerate(keys)}
                 starts = torch.tensor(core.window_starts(self._band, keys), dtype=torch.int32, device=core.device)
-                bands = torch.empty((F, yB, len(keys) * core.xM_yN_size), dtype=self.dtype, device=core.device)
+                # wave-major: K2 of wave w reads the contiguous block [f, w] (side by side in a row measured the same)
+                bands = torch.empty((F, len(keys), yB, core.xM_yN_size), dtype=self.dtype, device=core.device)
             else:
                 bands = torch.empty((F, yB, core.band_columns(self._band)), dtype=self.dtype, device=core.device)
             for j, cfg in enumerate(self.facet_configs):
@@ -500,7 +501,7 @@ class SwiftlyForward(WavePrefetch):
             core = self.core
             m, w = core.xM_yN_size, self._window_of[int(off1)]
             start = (core.window_starts(self._band, [off1])[0] + self._band[0]) % core.yN_size
-            return bands[:, :, w * m:(w + 1) * m], (start, m)
+            return bands[:, w], (start, m)
         return self.core.finish_axis1_rows(bands, [cfg.off1 for cfg in self.facet_configs], self._band, off1)
 
     def _get_wave_columns(self, off1):

@@ -412,15 +412,19 @@ def test_window_rows_store_of_the_whole_row_k1_matches_the_row_pass_per_wave():
         starts = core.window_starts(band, wave_off1s)
         assert min(starts) >= 0 and max(starts) + m <= band[1]
         sd = torch.tensor(starts, dtype=torch.int32, device="cuda")
-        full = torch.full((rows, len(starts) * m), float("nan"), dtype=torch.complex64, device="cuda")
+        # both output layouts: wave-major [windows, rows, m] (the pipeline's) and the windows of a row side by side
+        full = torch.full((len(starts), rows, m), float("nan"), dtype=torch.complex64, device="cuda")
         core.prepare_facet_window_rows(dev, foff, band, sd, full)
         got = full.cpu().numpy()
         assert numpy.isfinite(got.view(numpy.float32)).all()
+        side = torch.full((rows, len(starts) * m), float("nan"), dtype=torch.complex64, device="cuda")
+        core.prepare_facet_window_rows(dev, foff, band, sd, side)
+        assert numpy.array_equal(side.cpu().numpy().reshape(rows, len(starts), m).transpose(1, 0, 2), got)
         bands1 = core.prepare_facet_band(dev, foff, band)[None]
         for w, off1 in enumerate(wave_off1s):
             want, wband = core.finish_axis1_rows(bands1, [foff], band, off1)
             assert wband[0] == (band[0] + starts[w]) % yN64
-            rel = relrms(got[:, w * m:(w + 1) * m], want[0].cpu().numpy())
+            rel = relrms(got[w], want[0].cpu().numpy())
             assert rel < 5e-7, (foff, w, rel)
     # unsupported shapes are refused, not approximated: a band wider than the LDS stage
     wide = (0, core.WINDOW_ROWS_STAGE_COLUMNS + 64)

@@ -41,6 +41,6 @@ print(f"band store (two workgroups per row): {timed(lambda: core.prepare_facet_b
 for n in [int(a) for a in sys.argv[1:]] or (1, 8, 9, 16, 24, 25):
     use = (keys * 2)[:n]
     starts = torch.tensor(core.window_starts(band, use), dtype=torch.int32, device="cuda")
-    rows = torch.empty((yB, n * 512), dtype=torch.complex64, device="cuda")
+    rows = torch.empty((n, yB, 512) if os.environ.get("LAYOUT", "wave") == "wave" else (yB, n * 512), dtype=torch.complex64, device="cuda")
     t = timed(lambda: core.prepare_facet_window_rows(facet, 22528, band, starts, rows))
     print(f"window rows, {n:2d} windows: {t:.3f} ms")
