@@ -630,11 +630,12 @@ class SwiftlyCoreHip:
         m, yN = self.xM_yN_size, self.yN_size
         return [((yN // 2 - m // 2 + int(o) * yN // self.N) - int(band[0])) % yN for o in wave_off1s]
 
-    def supports_window_rows(self, band, facet_size, facet_off1s):
+    def supports_window_rows(self, band, facet_size, facet_off1s, n_windows=1):
         """can K1 finish the contiguous axis for every planned window in its epilogue (``prepare_facet_window_rows``)?
-        (yN = 32768, m = 512, xM <= 2048 for the placed subgrid side, the band fits the LDS stage, 16-byte loads possible)"""
+        (yN = 32768, m = 512, xM <= 2048 for the placed subgrid side, the band fits the LDS stage, at most 256 windows,
+        16-byte loads possible)"""
         return (
-            self.yN_size == 32768 and self.xM_yN_size == 512 and self.xM_size <= 2048 and
+            0 < int(n_windows) <= 256 and self.yN_size == 32768 and self.xM_yN_size == 512 and self.xM_size <= 2048 and
             self.band_columns(band) <= self.WINDOW_ROWS_STAGE_COLUMNS and int(band[1]) < self.yN_size and
             int(facet_size) % 2 == 0 and all(int(o) % 2 == 0 for o in facet_off1s)
         )

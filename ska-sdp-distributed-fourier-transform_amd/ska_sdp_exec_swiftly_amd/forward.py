@@ -473,7 +473,8 @@ class SwiftlyForward(WavePrefetch):
         if not (self.wave_axis == 1 and bool(getattr(self.core, "axis1_first", False))):
             return 0
         if (self.core.axis1_first is True and self.axis1_fused and self._plan is not None and self._band is not None and
-                self.core.supports_window_rows(self._band, self._facet_info[0][1][1], [cfg.off1 for cfg in self.facet_configs])):
+                self.core.supports_window_rows(self._band, self._facet_info[0][1][1], [cfg.off1 for cfg in self.facet_configs],
+                                               n_windows=len(self._planned_keys))):
             return 2
         return 1
 

@@ -426,6 +426,35 @@ def test_window_rows_store_of_the_whole_row_k1_matches_the_row_pass_per_wave():
             assert wband[0] == (band[0] + starts[w]) % yN64
             rel = relrms(got[w], want[0].cpu().numpy())
             assert rel < 5e-7, (foff, w, rel)
+    # the 22- and 24-segment instances (full-size facets of the timed workload; a facet whose position in the padded row is not a
+    # multiple of a segment touches 23 of them)
+    big = (rng.standard_normal((3, 22528)) + 1j * rng.standard_normal((3, 22528))).astype(numpy.complex64)
+    bdev = torch.from_numpy(big).cuda()
+    wave_off1s = [0, 928, -928 * 3, 928 * 6]
+    band = core.band_for_offsets(wave_off1s)
+    sd = torch.tensor(core.window_starts(band, wave_off1s), dtype=torch.int32, device="cuda")
+    _, ref = core64()
+    k = numpy.arange(m)
+    for foff in (22528, 22528 + 352, -22528 + 2):
+        assert core.supports_window_rows(band, 22528, [foff], n_windows=4) and not core.supports_window_rows(band, 22528, [foff], 257)
+        got = core.prepare_facet_window_rows(bdev, foff, band, sd, torch.empty((4, 3, m), dtype=torch.complex64, device="cuda"),
+                                             fold_other_axis_window=False)
+        bands1 = core.prepare_facet_band(bdev, foff, band, fold_other_axis_window=False)[None]
+        prepared = ref.prepare_facet(big.astype(complex), foff, 1)                         # [3, yN], complex128
+        sp = foff * xM64 // N64
+        for w, off1 in enumerate(wave_off1s):
+            rows_pass, wband = core.finish_axis1_rows(bands1, [foff], band, off1)
+            # the oracle's window row (as in test_finish_axis1_rows_matches_oracle): both forms are float32 roundings of it
+            s1 = off1 * yN64 // N64
+            placed = ref.add_to_subgrid(ref.extract_from_facet(prepared, off1, 1), foff, 1)
+            Z = placed[:, (k + xM64 // 2 - m // 2 + sp) % xM64]
+            want_logical = Z[:, (k + s1) % m]
+            wpc = band_cols(yN64, wband)
+            cols = wpc[(wband[0] + k) % yN64]
+            rel_fused = relrms(got[w].cpu().numpy()[:, cols], want_logical)
+            rel_rows = relrms(rows_pass[0].cpu().numpy()[:, cols], want_logical)
+            assert rel_fused < 2.5e-6 and rel_rows < 2.5e-6, (foff, w, rel_fused, rel_rows)   # measured 1.44e-6 / 1.45e-6
+            assert rel_fused < 1.25 * rel_rows + 1e-8, (foff, w, rel_fused, rel_rows)
     # unsupported shapes are refused, not approximated: a band wider than the LDS stage
     wide = (0, core.WINDOW_ROWS_STAGE_COLUMNS + 64)
     assert not core.supports_window_rows(wide, size, [0])
