@@ -9,6 +9,7 @@ import numpy
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ska-sdp-distributed-fourier-transform_amd"))
+os.environ.setdefault("SWIFTLY_K1_WHOLE", "1")  # the plain band store through the whole-row kernel (default: two workgroups per row)
 os.environ.setdefault("SWIFTLY_HIP_LIB", os.path.join(ROOT, "variants", "wtrace.so"))
 import torch  # noqa: E402
 
