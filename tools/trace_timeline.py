@@ -18,6 +18,8 @@ def short(name):
     m = re.search(r"row_pass_band_kernel", name)
     if m:
         return "K1_row_pass_band"
+    if "row_pass_whole_kernel" in name:  # the K1 of the axis-1-first order
+        return "K1_row_pass_whole"
     m = re.search(r"col_pass_kernelINS_4CGeoILi(\d+)ELi(\d+)ELb[01]ELi(\d+)ELi\d+EEELi(\d)", name)
     if m:
         return f"col_pass<{1 << int(m.group(1))},c{m.group(3)},mode{m.group(4)}>"
@@ -51,14 +53,17 @@ def dump(db_path, out_path):
     print(f"{len(rows)} dispatches -> {out_path}")
 
 
-def gaps(csv_path, k1_pattern="K1_row_pass_band"):
+def gaps(csv_path, k1_pattern="K1_row_pass"):
     rows = []
     with open(csv_path) as f:
         for st, en, q, name in csv.reader(f):
             rows.append((int(st), int(en), q, name))
     rows.sort()
     # passes: a pass starts at a K1 dispatch whose predecessor (in time) is not a K1 dispatch
-    starts = [i for i, r in enumerate(rows) if k1_pattern in r[3] and (i == 0 or k1_pattern not in rows[i - 1][3])]
+    def is_k1(n):
+        return k1_pattern in n or n == "row_pass_whole_kernel"
+
+    starts = [i for i, r in enumerate(rows) if is_k1(r[3]) and (i == 0 or not is_k1(rows[i - 1][3]))]
     starts.append(len(rows))
     for p in range(len(starts) - 1):
         seg = rows[starts[p] : starts[p + 1]]
