@@ -452,8 +452,8 @@ __global__ __launch_bounds__(512, 2) void row_pass_whole_kernel(const RowPassArg
             // Nothing in the window loop reads global memory (a load behind the previous window's stores waits for THEIR
             // completion: one counter for both): Fn and the window table sit in LDS behind the exchange buffer, the six twiddle
             // table values of the lane in registers.  A round of eight windows (one per wave) costs 1.8 us per row either way --
-            // 268 vector instructions per window with two waves per SIMD, i.e. the epilogue is bound by its own arithmetic and
-            // index calculations, and a 25th window rides in the slack of the waves that have only three (tools/time_k1_window_rows.py).
+            // ~200 vector instructions and 40 LDS operations per window with two waves per SIMD in step, i.e. the epilogue is
+            // bound by its own arithmetic and exchanges, and a 25th window rides in the slack of the waves that have only three (tools/time_k1_window_rows.py).
             using GM = SFCompact<Geo<float, 9, 3, G::NT, false>>;   // m = 512 (host-checked): one wave per transform, 8 points per lane
             static_assert(GM::T == 64 && GM::WAVE_ROWS && GM::LOGP == 3, "window transform geometry");
             constexpr int M = GM::N;

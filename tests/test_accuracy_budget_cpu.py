@@ -56,7 +56,7 @@ def test_half_spectra_from_the_two_workgroup_k1_would_cost_part_of_the_gain():
     leakage that Fn has not yet suppressed: 7.4e-6 all-float32 on the probe configuration (default order 1.3e-5, finished
     rows 2.1e-6), 1.8e-6 with float64 arithmetic everywhere (3.7e-7 for finished rows).  HIP kernels of that form on the
     N = 65536 workload: 5.8e-6 at 41.0 ms.  What ships instead finishes the window in the epilogue of a WHOLE-ROW K1 (one
-    workgroup owns both parities): 2.04e-6 at 39.2 ms."""
+    workgroup owns both parities): 2.04e-6 at 39.0 ms."""
     all32 = am.halves_error()
     stores_only = am.halves_error(bits=dict(k1=64, k2=64, k3=64, sf=64, k5=64))
     print(f"{all32:.3e}  halves: float32 arithmetic everywhere")
