@@ -970,7 +970,10 @@ def main():
                 one_pass(keep=kept_a)
                 fence()
                 a_par = verify_subgrids(p, facet_cfgs, vectors, sg_cfgs, kept_a, tol=tol)
-                return dict(ms_per_step=round(sorted(each)[1], 3), each_ms=[round(t, 2) for t in each],
+                med = sorted(each)[1]
+                return dict(ms_per_step=round(med, 3), each_ms=[round(t, 2) for t in each],
+                            contributions_per_s=round(F * S / (med * 1e-3), 1),
+                            hbm_algorithmic_frac_of_peak=round(algorithmic_bytes(p, F, S, C)[0] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             parity={k: a_par[k] for k in ("rel_rmse", "rel_rmse_each", "max_abs_over_rms", "tol_rel_rmse", "ok")})
             except NotImplementedError as err:
                 return dict(error=str(err))
